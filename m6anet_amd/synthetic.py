@@ -1,0 +1,31 @@
+"""Deterministic synthetic DRACH site bags.
+
+Generator: numpy.random.Generator(PCG64(seed)); per site one of the 288 N-DRACH-N 7-mers
+uniformly -> three vocabulary ids (u8); already-normalised signal features
+X ~ N(0,1) clipped to +-6, float32, [R, 9] (they are z-scores after
+m6anet/utils/data_utils.py:216-218); bag size fixed (20) or integers(lo, hi+1); CSR `off`.
+"""
+import numpy as np
+
+from .constants import ALL_7MERS, kmer7_to_ids
+
+_IDS_288 = np.array([kmer7_to_ids(k) for k in ALL_7MERS], dtype=np.uint8)   # [288,3]
+
+
+def make_sites(n_sites, bag=20, seed=20250328, chunk_reads=1 << 22):
+    """Returns dict(X f32 [R,9], site_kmers u8 [S,3], off i64 [S+1])."""
+    g = np.random.Generator(np.random.PCG64(seed))
+    site_kmers = _IDS_288[g.integers(0, len(ALL_7MERS), size=n_sites)]
+    if isinstance(bag, (tuple, list)):
+        n_reads = g.integers(bag[0], bag[1] + 1, size=n_sites).astype(np.int64)
+    else:
+        n_reads = np.full(n_sites, int(bag), np.int64)
+    off = np.zeros(n_sites + 1, np.int64)
+    np.cumsum(n_reads, out=off[1:])
+    R = int(off[-1])
+    X = np.empty((R, 9), np.float32)
+    for a in range(0, R, chunk_reads):
+        b = min(R, a + chunk_reads)
+        blk = g.standard_normal((b - a, 9), dtype=np.float32)
+        np.clip(blk, -6.0, 6.0, out=X[a:b])
+    return {"X": X, "site_kmers": np.ascontiguousarray(site_kmers), "off": off}
