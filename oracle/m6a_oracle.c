@@ -1,0 +1,321 @@
+/*
+ * m6a_oracle.c -- CPU restatement of m6anet's inference hot path (plain C, float32).
+ * TEST INFRASTRUCTURE ONLY -- see m6a_oracle.h.  Parity status: PINNED by
+ * tests/test_oracle_golden.py against vectors captured from the imported reference.
+ *
+ * Third-party arithmetic the reference delegates to, restated here from the published
+ * algorithms (the reference pins torch==1.6.0 / numpy>=1.18.0 in setup.py:34,41):
+ *   - MT19937 (Matsumoto & Nishimura 1998) with init_genrand seeding, which is what
+ *     np.random.seed(int) does (called at m6anet/scripts/inference.py:86);
+ *   - legacy RandomState.randint/choice bounded draw: masked rejection on 32-bit words;
+ *   - NumPy's float32 pairwise summation (block 128, 8 accumulators) behind ndarray.mean();
+ *   - torch eval-mode BatchNorm1d: y*alpha + (beta - mean*alpha), alpha = gamma/sqrt(var+eps).
+ */
+#include "m6a_oracle.h"
+
+#include <math.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------ MT19937 ------------ */
+void m6a_or_mt_seed(m6a_or_mt *st, uint32_t seed)
+{
+    st->mt[0] = seed;
+    for (int i = 1; i < 624; i++)
+        st->mt[i] = 1812433253u * (st->mt[i - 1] ^ (st->mt[i - 1] >> 30)) + (uint32_t)i;
+    st->pos = 624;
+}
+
+static void mt_regen(m6a_or_mt *st)
+{
+    uint32_t *mt = st->mt;
+    for (int k = 0; k < 624; k++) {
+        uint32_t y = (mt[k] & 0x80000000u) | (mt[(k + 1) % 624] & 0x7fffffffu);
+        mt[k] = mt[(k + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    }
+    st->pos = 0;
+}
+
+uint32_t m6a_or_mt_next(m6a_or_mt *st)
+{
+    if (st->pos >= 624) mt_regen(st);
+    uint32_t y = st->mt[st->pos++];
+    y ^= y >> 11;
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= y >> 18;
+    return y;
+}
+
+void m6a_or_mt_fill(uint32_t seed, int64_t count, uint32_t *out)
+{
+    m6a_or_mt st;
+    m6a_or_mt_seed(&st, seed);
+    for (int64_t i = 0; i < count; i++) out[i] = m6a_or_mt_next(&st);
+}
+
+/* ------------------------------------------------- choice(n, count, replace=True) ------ */
+/* m6anet/utils/inference_utils.py:85 -> RandomState.choice -> randint(0, n): for
+ * rng = n-1: rng == 0 draws nothing; otherwise mask = smallest 2^k-1 >= rng and
+ * `do v = next32() & mask; while (v > rng)`. */
+void m6a_or_choice(m6a_or_mt *st, int64_t n, int64_t count, int32_t *out_idx)
+{
+    uint32_t rng = (uint32_t)(n - 1);
+    if (rng == 0) { memset(out_idx, 0, (size_t)count * sizeof(int32_t)); return; }
+    uint32_t mask = rng;
+    mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+    for (int64_t i = 0; i < count; i++) {
+        uint32_t v;
+        do { v = m6a_or_mt_next(st) & mask; } while (v > rng);
+        out_idx[i] = (int32_t)v;
+    }
+}
+
+/* ------------------------------------------------------ NumPy pairwise float32 sum ----- */
+float m6a_or_pairwise_sum_f32(const float *a, int64_t n)
+{
+    if (n < 8) {
+        float res = 0.0f;
+        for (int64_t i = 0; i < n; i++) res += a[i];
+        return res;
+    } else if (n <= 128) {
+        float r[8], res;
+        int64_t i;
+        for (i = 0; i < 8; i++) r[i] = a[i];
+        for (i = 8; i < n - (n % 8); i += 8)
+            for (int k = 0; k < 8; k++) r[k] += a[i + k];
+        res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; i++) res += a[i];
+        return res;
+    } else {
+        int64_t n2 = n / 2;
+        n2 -= n2 % 8;
+        return m6a_or_pairwise_sum_f32(a, n2) + m6a_or_pairwise_sum_f32(a + n2, n - n2);
+    }
+}
+
+/* --------------------------------------------------------------- read encoder ---------- */
+/* weights blob layout (floats): E[66][2] | W1[150][15] | b1 | gamma | beta | mu | var (150 each)
+ *                               | W2[32][150] | b2[32] | W3[32] | b3[1] */
+enum { O_E = 0, O_W1 = 132, O_B1 = 2382, O_G = 2532, O_BE = 2682, O_MU = 2832, O_VAR = 2982,
+       O_W2 = 3132, O_B2 = 7932, O_W3 = 7964, O_B3 = 7996 };
+
+/* a1-a3: [X | emb(k0) emb(k1) emb(k2)] (m6anet/model/model_blocks/blocks.py:126,205,65);
+ * a4: relu(BN_eval(x W1^T + b1)) (blocks.py:249-254, m6anet.toml:16-21);
+ * a5: relu(h W2^T + b2) (m6anet.toml:23-28);
+ * a6: sigmoid(h W3^T + b3) (pooling_blocks.py:52, called at inference_utils.py:37). */
+typedef struct {
+    float w1t[15][152];   /* W1 transposed: [k][j], so the j loop vectorises while every */
+    float w2t[150][32];   /* output still sums its k terms strictly left to right        */
+    float b1[152], alpha[152], shift[152], b2[32], w3[32], b3;
+    const float *emb;
+} enc_tables;
+
+static void enc_prepare(const float *w, enc_tables *t)
+{
+    memset(t, 0, sizeof(*t));
+    for (int j = 0; j < 150; j++) {
+        for (int k = 0; k < 15; k++) t->w1t[k][j] = w[O_W1 + 15 * j + k];
+        float invstd = 1.0f / sqrtf(w[O_VAR + j] + 1e-5f);
+        t->alpha[j] = w[O_G + j] * invstd;
+        t->shift[j] = w[O_BE + j] - w[O_MU + j] * t->alpha[j];
+        t->b1[j] = w[O_B1 + j];
+    }
+    for (int j = 0; j < 32; j++) {
+        for (int k = 0; k < 150; k++) t->w2t[k][j] = w[O_W2 + 150 * j + k];
+        t->b2[j] = w[O_B2 + j];
+        t->w3[j] = w[O_W3 + j];
+    }
+    t->b3 = w[O_B3];
+    t->emb = w + O_E;
+}
+
+__attribute__((target_clones("avx2", "default")))
+static void enc_range(const enc_tables *t, const float *X, const uint8_t *site_kmers,
+                      const int64_t *off, int64_t s0, int64_t s1, float *read_prob)
+{
+    for (int64_t s = s0; s < s1; s++) {
+        float in[15], h1[152], h2[32];
+        for (int c = 0; c < 3; c++) {
+            int id = site_kmers[3 * s + c];
+            in[9 + 2 * c] = t->emb[2 * id];
+            in[10 + 2 * c] = t->emb[2 * id + 1];
+        }
+        for (int64_t r = off[s]; r < off[s + 1]; r++) {
+            memcpy(in, X + 9 * r, 9 * sizeof(float));
+            for (int j = 0; j < 152; j++) h1[j] = 0.0f;
+            for (int k = 0; k < 15; k++) {
+                const float xk = in[k];
+                for (int j = 0; j < 152; j++) h1[j] += xk * t->w1t[k][j];
+            }
+            for (int j = 0; j < 152; j++) {
+                float a = (h1[j] + t->b1[j]) * t->alpha[j] + t->shift[j];
+                h1[j] = a > 0.0f ? a : 0.0f;
+            }
+            for (int j = 0; j < 32; j++) h2[j] = 0.0f;
+            for (int k = 0; k < 150; k++) {
+                const float hk = h1[k];
+                for (int j = 0; j < 32; j++) h2[j] += hk * t->w2t[k][j];
+            }
+            float z = 0.0f;
+            for (int j = 0; j < 32; j++) {
+                float a = h2[j] + t->b2[j];
+                a = a > 0.0f ? a : 0.0f;
+                z += a * t->w3[j];
+            }
+            z += t->b3;
+            read_prob[r] = 1.0f / (1.0f + expf(-z));
+        }
+    }
+}
+
+typedef struct {
+    const enc_tables *t; const float *X; const uint8_t *km; const int64_t *off;
+    int64_t s0, s1; float *out;
+} enc_job;
+
+static void *enc_worker(void *arg)
+{
+    enc_job *j = (enc_job *)arg;
+    enc_range(j->t, j->X, j->km, j->off, j->s0, j->s1, j->out);
+    return NULL;
+}
+
+void m6a_or_encode_reads_mt(const float *w, const float *X, const uint8_t *site_kmers,
+                            const int64_t *off, int64_t n_sites, int n_threads, float *read_prob)
+{
+    enc_tables *t = (enc_tables *)malloc(sizeof(enc_tables));
+    enc_prepare(w, t);
+    if (n_threads <= 1 || n_sites < 2 * n_threads) {
+        enc_range(t, X, site_kmers, off, 0, n_sites, read_prob);
+    } else {
+        pthread_t *th = (pthread_t *)malloc((size_t)n_threads * sizeof(pthread_t));
+        enc_job *jobs = (enc_job *)malloc((size_t)n_threads * sizeof(enc_job));
+        /* contiguous site ranges balanced by read count */
+        int64_t R = off[n_sites], s = 0;
+        for (int i = 0; i < n_threads; i++) {
+            int64_t target = R * (i + 1) / n_threads, e = s;
+            while (e < n_sites && off[e + 1] <= target) e++;
+            if (i == n_threads - 1) e = n_sites;
+            jobs[i] = (enc_job){ t, X, site_kmers, off, s, e, read_prob };
+            pthread_create(&th[i], NULL, enc_worker, &jobs[i]);
+            s = e;
+        }
+        for (int i = 0; i < n_threads; i++) pthread_join(th[i], NULL);
+        free(th); free(jobs);
+    }
+    free(t);
+}
+
+void m6a_or_encode_reads(const float *w, const float *X, const uint8_t *site_kmers,
+                         const int64_t *off, int64_t n_sites, float *read_prob)
+{
+    m6a_or_encode_reads_mt(w, X, site_kmers, off, n_sites, 1, read_prob);
+}
+
+/* --------------------------------------------------------------- site sampling --------- */
+/* inference_utils.py:85-86:  idx = choice(n, T*K); reshape (T,K);
+ * (1 - prod(1 - p[idx], axis=1)).mean()  -- all float32: sequential product left to right,
+ * pairwise sum, then one float32 divide by T. */
+float m6a_or_site_proba(m6a_or_mt *st, const float *p, int64_t n, int n_iters, int n_samples,
+                        int32_t *idx, float *vals)
+{
+    m6a_or_choice(st, n, (int64_t)n_iters * n_samples, idx);
+    for (int t = 0; t < n_iters; t++) {
+        float prod = 1.0f;
+        const int32_t *row = idx + (int64_t)t * n_samples;
+        for (int k = 0; k < n_samples; k++) prod *= (1.0f - p[row[k]]);
+        vals[t] = 1.0f - prod;
+    }
+    return m6a_or_pairwise_sum_f32(vals, n_iters) / (float)n_iters;
+}
+
+/* inference_utils.py:33,47: batches of `batch_size` sites; batch `it` closes a flush group
+ * when (it+1) % save_per_batch != 0.  Batches after the last flush are never written by
+ * the reference; here they form a final group so every site gets a value. */
+int64_t m6a_or_flush_groups(int64_t n_sites, int64_t batch_size, int64_t save_per_batch,
+                            int64_t *group_off)
+{
+    int64_t n_batches = (n_sites + batch_size - 1) / batch_size, g = 0, start_b = 0;
+    group_off[0] = 0;
+    for (int64_t it = 0; it < n_batches; it++) {
+        if ((it + 1) % save_per_batch) {
+            int64_t end = (it + 1) * batch_size;
+            group_off[++g] = end < n_sites ? end : n_sites;
+            start_b = it + 1;
+        }
+    }
+    if (start_b < n_batches) group_off[++g] = n_sites;
+    return g;
+}
+
+typedef struct {
+    const float *p; const int64_t *off; const int64_t *goff; int64_t n_groups;
+    int n_iters, n_samples; uint32_t seed; float *site; int64_t *next; pthread_mutex_t *mu;
+} pool_job;
+
+static void *pool_worker(void *arg)
+{
+    pool_job *j = (pool_job *)arg;
+    int32_t *idx = (int32_t *)malloc((size_t)j->n_iters * j->n_samples * sizeof(int32_t));
+    float *vals = (float *)malloc((size_t)j->n_iters * sizeof(float));
+    for (;;) {
+        pthread_mutex_lock(j->mu);
+        int64_t g0 = *j->next;
+        *j->next = g0 + 64;
+        pthread_mutex_unlock(j->mu);
+        if (g0 >= j->n_groups) break;
+        int64_t g1 = g0 + 64 < j->n_groups ? g0 + 64 : j->n_groups;
+        for (int64_t g = g0; g < g1; g++) {
+            /* every flush group's Pool worker starts from the parent's never-advanced state
+             * (inference_utils.py:102-104 forks after inference.py:86 seeded): reseed. */
+            m6a_or_mt st;
+            m6a_or_mt_seed(&st, j->seed);
+            for (int64_t s = j->goff[g]; s < j->goff[g + 1]; s++)
+                j->site[s] = m6a_or_site_proba(&st, j->p + j->off[s], j->off[s + 1] - j->off[s],
+                                               j->n_iters, j->n_samples, idx, vals);
+        }
+    }
+    free(idx); free(vals);
+    return NULL;
+}
+
+int m6a_or_site_pool(const float *read_prob, const int64_t *off, int64_t n_sites, int n_iters,
+                     int n_samples, float thr, uint32_t seed, int64_t batch_size,
+                     int64_t save_per_batch, int n_threads, float *site_prob, double *mod_ratio)
+{
+    if (n_sites <= 0) return 0;
+    int64_t n_batches = (n_sites + batch_size - 1) / batch_size;
+    int64_t *goff = (int64_t *)malloc((size_t)(n_batches + 2) * sizeof(int64_t));
+    if (!goff) return -1;
+    int64_t G = m6a_or_flush_groups(n_sites, batch_size, save_per_batch, goff);
+    int64_t next = 0;
+    pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER;
+    pool_job job = { read_prob, off, goff, G, n_iters, n_samples, seed, site_prob, &next, &mu };
+    if (n_threads <= 1) {
+        pool_worker(&job);
+    } else {
+        pthread_t *th = (pthread_t *)malloc((size_t)n_threads * sizeof(pthread_t));
+        for (int i = 0; i < n_threads; i++) pthread_create(&th[i], NULL, pool_worker, &job);
+        for (int i = 0; i < n_threads; i++) pthread_join(th[i], NULL);
+        free(th);
+    }
+    /* inference_utils.py:53: np.mean(x >= thr): float32 compare, float64 mean */
+    for (int64_t s = 0; s < n_sites; s++) {
+        int64_t n = off[s + 1] - off[s], c = 0;
+        for (int64_t r = off[s]; r < off[s + 1]; r++) c += read_prob[r] >= thr;
+        mod_ratio[s] = n ? (double)c / (double)n : NAN;
+    }
+    free(goff);
+    return 0;
+}
+
+void m6a_or_bag_noisy_or(const float *read_prob, int64_t n_bags, int bag, float *site_prob)
+{
+    for (int64_t b = 0; b < n_bags; b++) {
+        float prod = 1.0f;
+        for (int k = 0; k < bag; k++) prod *= (1.0f - read_prob[b * bag + k]);
+        site_prob[b] = 1.0f - prod;
+    }
+}
