@@ -1,0 +1,136 @@
+/*
+ * m6a.h -- C ABI of libm6a_hip.so: m6anet's inference hot path on MI355X (gfx950).
+ *
+ * The reference (GoekeLab/m6anet) is pure Python and has no FFI; its seams for this path are
+ * Python call sites.  Each entry point below names the reference interface it replaces
+ * (paths relative to the reference checkout).  INTEGRATION.md shows the ctypes binding a
+ * maintainer would add on the reference side.
+ *
+ * Conventions
+ *   - every function returns M6A_OK (0) or a negative M6A_E* code; m6a_last_error(ctx) gives text;
+ *   - the caller owns every buffer; the library keeps no input pointer after a call returns;
+ *   - data pointers may be HOST or DEVICE pointers (detected with hipPointerGetAttributes):
+ *       all-host   -> the library stages through its own device buffers and the call is
+ *                     synchronous (results are in the host buffers on return);
+ *       all-device -> kernels are enqueued on the context's stream (m6a_set_stream); the
+ *                     caller synchronises (m6a_sync or its own stream sync).  Entry points
+ *                     read back a few bytes first (off[S]; min/max bag size to choose the
+ *                     sampling kernel) and so block on the stream once or twice per call;
+ *   - one ctx per (process, GPU, stream); calls on one ctx are not thread-safe;
+ *   - no exceptions, no callbacks, no torch types cross this boundary.
+ */
+#ifndef M6A_H
+#define M6A_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct m6a_ctx m6a_ctx;
+
+enum {
+    M6A_OK = 0,
+    M6A_EINVAL = -1,     /* bad argument */
+    M6A_ENOMEM = -2,     /* host or device allocation failed */
+    M6A_EHIP = -3,       /* HIP runtime error (text in m6a_last_error) */
+    M6A_ESTREAM = -4,    /* a flush group needs more MT19937 words than the stream cap allows */
+    M6A_ENODEV = -5,     /* no usable gfx950 device */
+    M6A_EUNSUPPORTED = -6
+};
+
+enum { M6A_RNG_NUMPY = 0 /* exact replay of the reference's NumPy stream */ };
+
+#define M6A_N_WEIGHTS 7997
+#define M6A_N_FEATURES 9     /* [dwell, std, mean] x {-1,0,+1}: DeaggregateNanopolish, blocks.py:113 */
+#define M6A_MAX_SAMPLES 64
+
+/* Flat float32 weight blob, in this order (state-dict keys of m6anet/model/model.py:40-69,
+ * files under m6anet/model/model_states/):
+ *   E[66][2] | W1[150][15] | b1[150] | bn_gamma[150] | bn_beta[150] | bn_mean[150] | bn_var[150]
+ *   | W2[32][150] | b2[32] | W3[32] | b3[1]                                     = 7997 floats.
+ * Replaces: MILModel(...).load_state_dict(torch.load(...)) at m6anet/scripts/inference.py:88-90.
+ * `weights` is a host pointer.  BatchNorm (eval, eps 1e-5) is folded into W1/b1 here. */
+int m6a_create(m6a_ctx **out, const float *weights, size_t n_floats, int device_id);
+void m6a_destroy(m6a_ctx *ctx);
+const char *m6a_last_error(const m6a_ctx *ctx);   /* ctx may be NULL: last create error */
+
+/* Use the caller's HIP stream (a hipStream_t, e.g. torch.cuda.current_stream().cuda_stream).
+ * NULL selects the context's own stream. */
+int m6a_set_stream(m6a_ctx *ctx, void *hip_stream);
+/* Multi-GPU sharding: the sites passed to m6a_site_pool / m6a_infer on this context are sites
+ * [first_site, first_site + n_sites) of a larger job.  Batch indices, hence flush groups and RNG
+ * restarts (inference_utils.py:33,47), are counted from the job's first site, so results do not
+ * depend on how the job is cut.  first_site must start a flush group (m6a_shard_plan returns
+ * such cuts).  Default 0. */
+int m6a_set_job_offset(m6a_ctx *ctx, int64_t first_site);
+int m6a_sync(m6a_ctx *ctx);    /* waits for the stream; returns a deferred kernel-side error if any */
+
+/* Read encoder.  Replaces, for one batch of sites,
+ *     model.get_read_representation({'X','kmer'}) + model.pooling_filter.probability_layer(.)
+ * (m6anet/utils/inference_utils.py:35-37 -> m6anet/model/model.py:85-97,
+ *  m6anet/model/model_blocks/blocks.py:116-126,194-205,55-66,257-266, pooling_blocks.py:52).
+ *   X          [R][9] float32, already z-normalised (data_utils.py:216-218)
+ *   site_kmers [S][3] uint8 vocabulary ids 0..65 of the three 5-mers (stored once per site;
+ *              the reference repeats them per read as int64, data_utils.py:223-224)
+ *   off        [S+1] int64 CSR read offsets, off[0]=0, off[S]=R (the reference's n_reads vector,
+ *              data_utils.py:499)
+ *   read_prob  [R] float32 out */
+int m6a_encode_reads(m6a_ctx *ctx, const float *X, const uint8_t *site_kmers, const int64_t *off,
+                     int64_t n_sites, float *read_prob);
+
+/* Site pooling.  Replaces calculate_site_proba(read_probs, n_iters, n_samples, n_processes) +
+ * the mod_ratio line (m6anet/utils/inference_utils.py:53-54,74-104) for ALL flush groups of a
+ * job at once, with the reference's n_processes=1 semantics: the NumPy MT19937 stream restarts
+ * from `seed` at every flush group (groups follow batch_size/save_per_batch exactly as the
+ * loop at inference_utils.py:33,47 forms them -- see m6a_flush_groups), sites inside a group
+ * consume it sequentially, indices come from masked rejection, the 20-term product is float32
+ * left-to-right, the mean over iterations float32.
+ *   site_prob [S] float32 out;  mod_ratio [S] float64 out = mean(read_prob >= thr)
+ *   n_samples <= M6A_MAX_SAMPLES (the reference passes 20, inference_utils.py:54). */
+int m6a_site_pool(m6a_ctx *ctx, const float *read_prob, const int64_t *off, int64_t n_sites,
+                  int n_iters, int n_samples, float read_proba_threshold, uint32_t seed,
+                  int rng_mode, int64_t batch_size, int64_t save_per_batch,
+                  float *site_prob, double *mod_ratio);
+
+/* Fused encode + pool (what run_inference does per job, inference_utils.py:14-71, minus text
+ * I/O).  read_prob may be NULL when per-read output (data.indiv_proba.csv) is not wanted. */
+int m6a_infer(m6a_ctx *ctx, const float *X, const uint8_t *site_kmers, const int64_t *off,
+              int64_t n_sites, int n_iters, int n_samples, float read_proba_threshold,
+              uint32_t seed, int rng_mode, int64_t batch_size, int64_t save_per_batch,
+              float *read_prob, float *site_prob, double *mod_ratio);
+
+/* MILModel.forward on fixed-size bags (m6anet/model/model.py:155-164 ->
+ * SigmoidProdPooling.forward, pooling_blocks.py:127-129): X [B*bag][9], site_kmers [B][3],
+ * site_prob[b] = 1 - prod_k (1 - p[b*bag+k]) in float32, left to right. */
+int m6a_bag_forward(m6a_ctx *ctx, const float *X, const uint8_t *site_kmers, int64_t n_bags,
+                    int bag, float *site_prob);
+
+/* Host-only helpers (no GPU, usable with ctx == NULL semantics: they take no ctx). */
+
+/* Flush groups of the reference's loop (inference_utils.py:33,47): batches of `batch_size`
+ * sites; batch `it` closes a group when (it+1) % save_per_batch != 0 (the reference's inverted
+ * test).  Batches after the last flush -- which the reference silently never writes -- form a
+ * final group here.  Writes group_off[0..G] and returns G, or M6A_EINVAL if cap < G+1. */
+int64_t m6a_flush_groups(int64_t n_sites, int64_t batch_size, int64_t save_per_batch,
+                         int64_t *group_off, int64_t cap);
+
+/* Contiguous, flush-group-aligned site shards balanced by read count for n_shards GPUs
+ * (sites are independent; aligning to groups keeps results independent of the GPU count).
+ * off is a HOST pointer.  Writes shard_site_off[0..n_shards]. */
+int m6a_shard_plan(const int64_t *off, int64_t n_sites, int64_t batch_size, int64_t save_per_batch,
+                   int n_shards, int64_t *shard_site_off);
+
+/* Per-kernel timing with HIP events on the context's stream (bench.py's live roofline).
+ * kind: 0 = read encoder, 1 = site pooling.  m6a_profile_read synchronises the stream. */
+int m6a_profile_enable(m6a_ctx *ctx, int on);
+int m6a_profile_read(m6a_ctx *ctx, int kind, double *total_ms, int64_t *n_launches);
+/* name of the pooling kernel variant used by the last pool/infer call ("table" | "scan") */
+const char *m6a_last_pool_variant(const m6a_ctx *ctx);
+
+const char *m6a_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

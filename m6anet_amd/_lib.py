@@ -1,0 +1,64 @@
+"""ctypes binding of libm6a_hip.so (include/m6a.h).  No CPU fallback: if the HIP library is
+missing or a call fails, this raises."""
+import ctypes as C
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libm6a_hip.so")
+
+M6A_OK = 0
+ERRORS = {-1: "M6A_EINVAL", -2: "M6A_ENOMEM", -3: "M6A_EHIP", -4: "M6A_ESTREAM", -5: "M6A_ENODEV",
+          -6: "M6A_EUNSUPPORTED"}
+RNG_NUMPY = 0
+
+# every symbol include/m6a.h declares (tests check the .so exports exactly these)
+SYMBOLS = ["m6a_create", "m6a_destroy", "m6a_last_error", "m6a_set_stream", "m6a_set_job_offset", "m6a_sync",
+           "m6a_encode_reads", "m6a_site_pool", "m6a_infer", "m6a_bag_forward", "m6a_flush_groups",
+           "m6a_shard_plan", "m6a_profile_enable", "m6a_profile_read", "m6a_last_pool_variant",
+           "m6a_version"]
+
+_lib = None
+
+
+class M6AError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("%s (%d): %s" % (ERRORS.get(code, "M6A_E?"), code, msg))
+        self.code = code
+
+
+def load():
+    """Loads the in-tree HIP library.  Raises if it has not been built (python -m m6anet_amd.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("libm6a_hip.so is not built: run `python -m m6anet_amd.build` "
+                          "(or __graft_entry__.build()); there is no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    vp, i64, i32, u32, f32, sz = C.c_void_p, C.c_int64, C.c_int, C.c_uint32, C.c_float, C.c_size_t
+    L.m6a_create.argtypes = [C.POINTER(vp), vp, sz, i32]
+    L.m6a_destroy.argtypes = [vp]
+    L.m6a_destroy.restype = None
+    L.m6a_last_error.argtypes = [vp]
+    L.m6a_last_error.restype = C.c_char_p
+    L.m6a_set_stream.argtypes = [vp, vp]
+    L.m6a_sync.argtypes = [vp]
+    L.m6a_set_job_offset.argtypes = [vp, i64]
+    L.m6a_encode_reads.argtypes = [vp, vp, vp, vp, i64, vp]
+    L.m6a_site_pool.argtypes = [vp, vp, vp, i64, i32, i32, f32, u32, i32, i64, i64, vp, vp]
+    L.m6a_infer.argtypes = [vp, vp, vp, vp, i64, i32, i32, f32, u32, i32, i64, i64, vp, vp, vp]
+    L.m6a_bag_forward.argtypes = [vp, vp, vp, i64, i32, vp]
+    L.m6a_flush_groups.argtypes = [i64, i64, i64, vp, i64]
+    L.m6a_flush_groups.restype = i64
+    L.m6a_shard_plan.argtypes = [vp, i64, i64, i64, i32, vp]
+    L.m6a_profile_enable.argtypes = [vp, i32]
+    L.m6a_profile_read.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(i64)]
+    L.m6a_last_pool_variant.argtypes = [vp]
+    L.m6a_last_pool_variant.restype = C.c_char_p
+    L.m6a_version.restype = C.c_char_p
+    for name in SYMBOLS:
+        fn = getattr(L, name)
+        if fn.restype is C.c_int and name not in ("m6a_flush_groups",):
+            fn.restype = C.c_int
+    _lib = L
+    return L

@@ -1,0 +1,672 @@
+// m6a_api.hip -- host side of libm6a_hip.so: the C ABI of include/m6a.h.
+// Context/weights management, MT19937 stream + index-table preparation, launches.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "m6a.h"
+#include "m6a_kernels.h"
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+constexpr int kMaxProfiled = 8192;
+
+struct Profiler {
+    bool on = false;
+    std::vector<hipEvent_t> start[2], stop[2];
+    int used[2] = {0, 0};
+    int64_t dropped[2] = {0, 0};
+};
+
+}  // namespace
+
+struct m6a_ctx {
+    int device = 0;
+    int n_cu = 256;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    std::string err;
+    // model
+    float *d_wfrag = nullptr, *d_emb = nullptr;
+    float b3 = 0.f;
+    // sampling state (device) + what it was built for
+    DevBuf raw, tab, goff, rp_scratch, off_scratch;
+    uint32_t raw_seed = 0; int64_t raw_len = 0;
+    struct { uint32_t seed; int n, T, K, jmax; bool valid; } tab_key = {0, 0, 0, 0, 0, false};
+    struct { int64_t S, bs, spb, base, G, gmax; bool valid; } goff_key = {0, 0, 0, 0, 0, 0, false};
+    int64_t job_offset = 0;
+    int *d_err = nullptr;
+    unsigned long long *d_minmax = nullptr;
+    unsigned long long *h_minmax = nullptr;   // pinned
+    int *h_err = nullptr;                     // pinned
+    // host-pointer staging
+    DevBuf sX, sK, sOff, sP, sSite, sMod;
+    Profiler prof;
+    const char *pool_variant = "none";
+};
+
+namespace {
+
+int fail(m6a_ctx *c, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIPCHK(c, expr)                                                                    \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess) {                                                            \
+            (void)hipGetLastError();                                                       \
+            return fail((c), e_ == hipErrorOutOfMemory ? M6A_ENOMEM : M6A_EHIP, "%s: %s (%s:%d)", \
+                        #expr, hipGetErrorString(e_), __FILE__, __LINE__);                 \
+        }                                                                                  \
+    } while (0)
+
+bool is_device_ptr(const void *p)
+{
+    if (!p) return false;
+    hipPointerAttribute_t at;
+    hipError_t e = hipPointerGetAttributes(&at, p);
+    if (e != hipSuccess) { (void)hipGetLastError(); return false; }
+    return at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeManaged;
+}
+
+// ---- weights: fold eval-mode BatchNorm into layer 1, lay out MFMA fragments ------------------
+// blob offsets (floats), see include/m6a.h
+enum { O_E = 0, O_W1 = 132, O_B1 = 2382, O_G = 2532, O_BE = 2682, O_MU = 2832, O_VAR = 2982,
+       O_W2 = 3132, O_B2 = 7932, O_W3 = 7964, O_B3 = 7996 };
+
+void build_fragments(const float *w, std::vector<float> &frag)
+{
+    // W1aug[160][16]: columns 0..14 = alpha*W1, column 15 = alpha*b1 + (beta - mean*alpha)
+    // (torch eval BatchNorm1d: y*alpha + beta - mean*alpha, alpha = gamma/sqrt(var+eps), blocks.py:250);
+    // row 150 = constant-one unit (carries b2), rows 151..159 = 0.
+    std::vector<float> w1(160 * 16, 0.f), w2(32 * 160, 0.f);
+    for (int j = 0; j < 150; j++) {
+        const float invstd = 1.0f / std::sqrt(w[O_VAR + j] + 1e-5f);
+        const float alpha = w[O_G + j] * invstd;
+        const float shift = w[O_BE + j] - w[O_MU + j] * alpha;
+        for (int k = 0; k < 15; k++) w1[j * 16 + k] = alpha * w[O_W1 + 15 * j + k];
+        w1[j * 16 + 15] = alpha * w[O_B1 + j] + shift;
+    }
+    w1[150 * 16 + 15] = 1.0f;
+    for (int o = 0; o < 32; o++) {
+        for (int k = 0; k < 150; k++) w2[o * 160 + k] = w[O_W2 + 150 * o + k];
+        w2[o * 160 + 150] = w[O_B2 + o];
+    }
+    frag.assign(M6A_WFRAG_FLOATS, 0.f);
+    for (int lane = 0; lane < 64; lane++) {
+        const int col = lane & 31, half = lane >> 5;
+        for (int m = 0; m < 5; m++) {
+            for (int st = 0; st < 8; st++)      // A[i=col][k=2st+half] <-> feature st + 8*half
+                frag[(m * 8 + st) * 64 + lane] = w1[(32 * m + col) * 16 + st + 8 * half];
+            for (int q = 0; q < 16; q++) {      // K index = hidden unit held by acc register q
+                const int unit = 32 * m + (q & 3) + 8 * (q >> 2) + 4 * half;
+                frag[(40 + m * 16 + q) * 64 + lane] = w2[col * 160 + unit];
+            }
+        }
+        for (int q = 0; q < 16; q++)
+            frag[(120 + q) * 64 + lane] = w[O_W3 + (q & 3) + 8 * (q >> 2) + 4 * half];
+    }
+}
+
+// ---- flush groups (inference_utils.py:33,47) --------------------------------------------------
+// `base` = index of the first site within the whole job (a multiple of bs that starts a group):
+// batch indices -- and with them the flush pattern -- are global, offsets returned are local.
+int64_t flush_groups(int64_t S, int64_t bs, int64_t spb, int64_t base, std::vector<int64_t> &goff)
+{
+    goff.clear();
+    goff.push_back(0);
+    if (S <= 0) return 0;
+    const int64_t it0 = base / bs;
+    const int64_t nb = (S + bs - 1) / bs;
+    int64_t start_b = 0;
+    for (int64_t b = 0; b < nb; b++) {
+        if ((it0 + b + 1) % spb) {
+            goff.push_back(std::min((b + 1) * bs, S));
+            start_b = b + 1;
+        }
+    }
+    if (start_b < nb) goff.push_back(S);
+    return (int64_t)goff.size() - 1;
+}
+
+bool base_is_group_start(int64_t base, int64_t bs, int64_t spb)
+{
+    if (base < 0 || base % bs) return false;
+    const int64_t it0 = base / bs;
+    return it0 == 0 || (it0 % spb) != 0;     // batch it0-1 closed a group
+}
+
+int ensure_groups(m6a_ctx *c, int64_t S, int64_t bs, int64_t spb)
+{
+    const int64_t base = c->job_offset;
+    if (c->goff_key.valid && c->goff_key.S == S && c->goff_key.bs == bs && c->goff_key.spb == spb &&
+        c->goff_key.base == base) return M6A_OK;
+    if (!base_is_group_start(base, bs, spb))
+        return fail(c, M6A_EINVAL, "job offset %lld does not start a flush group for batch_size=%lld save_per_batch=%lld",
+                    (long long)base, (long long)bs, (long long)spb);
+    std::vector<int64_t> g;
+    const int64_t G = flush_groups(S, bs, spb, base, g);
+    int64_t gmax = 0;
+    for (int64_t i = 0; i < G; i++) gmax = std::max(gmax, g[i + 1] - g[i]);
+    HIPCHK(c, c->goff.ensure(g.size() * sizeof(int64_t)));
+    HIPCHK(c, hipMemcpyAsync(c->goff.p, g.data(), g.size() * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));   // g goes out of scope
+    c->goff_key = {S, bs, spb, base, G, gmax, true};
+    return M6A_OK;
+}
+
+// ---- NumPy legacy stream: np.random.seed(int) == init_genrand == std::mt19937(seed) ------------
+int ensure_raw(m6a_ctx *c, uint32_t seed, int64_t len)
+{
+    if (c->raw_len >= len && c->raw_seed == seed) return M6A_OK;
+    if (len > ((int64_t)1 << 31) - 512)
+        return fail(c, M6A_ESTREAM, "a flush group would need %lld MT19937 words (cap 2^31); "
+                    "reduce batch_size*save_per_batch or num_iterations", (long long)len);
+    std::vector<uint32_t> h;
+    try { h.resize((size_t)len); } catch (const std::bad_alloc &) { return fail(c, M6A_ENOMEM, "host alloc of MT stream failed"); }
+    std::mt19937 gen(seed);
+    for (int64_t i = 0; i < len; i++) h[(size_t)i] = (uint32_t)gen();
+    HIPCHK(c, c->raw.ensure((size_t)len * 4));
+    HIPCHK(c, hipMemcpyAsync(c->raw.p, h.data(), (size_t)len * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->raw_seed = seed; c->raw_len = len;
+    return M6A_OK;
+}
+
+// accepted-index table for uniform bags of n reads (legacy randint masked rejection),
+// layout tab[j][round][plane][lane], 4 byte offsets (8*idx) per dword
+int ensure_table(m6a_ctx *c, uint32_t seed, int n, int T, int K, int jmax)
+{
+    auto &k = c->tab_key;
+    if (k.valid && k.seed == seed && k.n == n && k.T == T && k.K == K && k.jmax >= jmax) return M6A_OK;
+    const int rounds = (T + 63) / 64;
+    std::vector<uint32_t> tab((size_t)jmax * rounds * 5 * 64, 0u);
+    std::mt19937 gen(seed);
+    const uint32_t rng = (uint32_t)(n - 1);
+    uint32_t mask = rng;
+    mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+    for (int j = 0; j < jmax; j++)
+        for (int t = 0; t < T; t++)
+            for (int kk = 0; kk < K; kk++) {
+                uint32_t v = 0;
+                if (rng) do { v = (uint32_t)gen() & mask; } while (v > rng);
+                const size_t word = (((size_t)j * rounds + (t >> 6)) * 5 + (kk >> 2)) * 64 + (t & 63);
+                tab[word] |= (v * 8u) << (8 * (kk & 3));
+            }
+    HIPCHK(c, c->tab.ensure(tab.size() * 4));
+    HIPCHK(c, hipMemcpyAsync(c->tab.p, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    k = {seed, n, T, K, jmax, true};
+    return M6A_OK;
+}
+
+// ---- profiling ---------------------------------------------------------------------------------
+void prof_begin(m6a_ctx *c, int kind)
+{
+    Profiler &p = c->prof;
+    if (!p.on) return;
+    if (p.used[kind] >= kMaxProfiled) { p.dropped[kind]++; return; }
+    if ((int)p.start[kind].size() <= p.used[kind]) {
+        hipEvent_t a, b;
+        (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+        p.start[kind].push_back(a); p.stop[kind].push_back(b);
+    }
+    (void)hipEventRecord(p.start[kind][p.used[kind]], c->stream);
+}
+void prof_end(m6a_ctx *c, int kind)
+{
+    Profiler &p = c->prof;
+    if (!p.on || p.used[kind] >= kMaxProfiled) return;
+    (void)hipEventRecord(p.stop[kind][p.used[kind]], c->stream);
+    p.used[kind]++;
+}
+
+// ---- launches (all pointers are device pointers here) ------------------------------------------
+int launch_encode(m6a_ctx *c, const float *X, const uint8_t *km, const int64_t *off, int64_t S,
+                  int64_t R, float *rp)
+{
+    if (R <= 0 || S <= 0) return M6A_OK;
+    EncArgs a;
+    a.X = X; a.site_kmers = km; a.off = off; a.wfrag = c->d_wfrag; a.emb = c->d_emb; a.read_prob = rp;
+    a.n_sites = S; a.n_reads = R; a.n_tiles = (R + 31) / 32; a.b3 = c->b3;
+    const int64_t max_waves = (int64_t)c->n_cu * 8;        // 2 blocks/CU x 4 waves
+    a.tiles_per_wave = (a.n_tiles + max_waves - 1) / max_waves;
+    const int64_t waves = (a.n_tiles + a.tiles_per_wave - 1) / a.tiles_per_wave;
+    const unsigned blocks = (unsigned)((waves + 3) / 4);
+    prof_begin(c, 0);
+    hipLaunchKernelGGL(enc_kernel, dim3(blocks), dim3(256), 0, c->stream, a);
+    prof_end(c, 0);
+    HIPCHK(c, hipGetLastError());
+    return M6A_OK;
+}
+
+int launch_pool(m6a_ctx *c, const float *rp, const int64_t *off, int64_t S, int T, int K, float thr,
+                uint32_t seed, int64_t bs, int64_t spb, float *site, double *mod)
+{
+    if (S <= 0) return M6A_OK;
+    int rc = ensure_groups(c, S, bs, spb);
+    if (rc) return rc;
+    // bag-size range decides the kernel: one 16-byte read-back (blocks on the stream)
+    c->h_minmax[0] = ~0ull; c->h_minmax[1] = 0ull;
+    HIPCHK(c, hipMemcpyAsync(c->d_minmax, c->h_minmax, 16, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(bag_minmax_kernel, dim3((unsigned)std::min<int64_t>((S + 255) / 256, 1024)), dim3(256), 0,
+                       c->stream, off, S, c->d_minmax);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(c->h_minmax, c->d_minmax, 16, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const int64_t nmin = (int64_t)c->h_minmax[0], nmax = (int64_t)c->h_minmax[1];
+    if (nmin < 0 || nmax > 0x7fffffff) return fail(c, M6A_EINVAL, "off[] is not a non-decreasing CSR array");
+
+    PoolArgs a;
+    memset(&a, 0, sizeof a);
+    a.read_prob = rp; a.off = off; a.goff = (const int64_t *)c->goff.p; a.site_prob = site; a.mod_ratio = mod;
+    a.err = c->d_err; a.n_groups = c->goff_key.G; a.T = T; a.K = K; a.thr = thr;
+    const int64_t gmax = c->goff_key.gmax;
+
+    if (nmin == nmax && nmin >= 1 && nmin <= M6A_TABLE_MAX_N && K == 20 && gmax <= 4096) {
+        rc = ensure_table(c, seed, (int)nmin, T, K, (int)gmax);
+        if (rc) return rc;
+        a.tab = (const uint32_t *)c->tab.p; a.uniform_n = (int)nmin; a.jmax = (int)gmax;
+        const int64_t items = ((a.n_groups + 7) / 8) * a.jmax;
+        const unsigned blocks = (unsigned)std::min<int64_t>((items + 3) / 4, (int64_t)c->n_cu * 8);
+        c->pool_variant = "table";
+        prof_begin(c, 1);
+        hipLaunchKernelGGL(pool_table_kernel, dim3(blocks), dim3(256), 0, c->stream, a);
+        prof_end(c, 1);
+    } else {
+        // expected words per accepted draw <= 2; slack covers the rejection-count spread
+        const int64_t A = (int64_t)T * K;
+        const int64_t need = gmax * (2 * A + A / 16) + 8192;
+        rc = ensure_raw(c, seed, need);
+        if (rc) return rc;
+        a.raw = (const uint32_t *)c->raw.p; a.raw_len = c->raw_len;
+        const size_t lds = (size_t)4 * (M6A_BAG_LDS + 64 * (K + 1) + 128) * sizeof(float);
+        const unsigned blocks = (unsigned)std::min<int64_t>((a.n_groups + 3) / 4, (int64_t)c->n_cu * 4);
+        c->pool_variant = "scan";
+        prof_begin(c, 1);
+        if (K == 20) hipLaunchKernelGGL(pool_scan_kernel<20>, dim3(blocks), dim3(256), lds, c->stream, a);
+        else hipLaunchKernelGGL(pool_scan_kernel<0>, dim3(blocks), dim3(256), lds, c->stream, a);
+        prof_end(c, 1);
+    }
+    HIPCHK(c, hipGetLastError());
+    return M6A_OK;
+}
+
+int check_pool_args(m6a_ctx *c, int64_t S, int T, int K, int rng_mode, int64_t bs, int64_t spb)
+{
+    if (!c) return M6A_EINVAL;
+    if (S < 0) return fail(c, M6A_EINVAL, "n_sites < 0");
+    if (T < 1) return fail(c, M6A_EINVAL, "n_iters must be >= 1");
+    if (K < 1 || K > M6A_MAX_SAMPLES) return fail(c, M6A_EINVAL, "n_samples must be in 1..%d", M6A_MAX_SAMPLES);
+    if ((int64_t)T * K > 0x3fffffff) return fail(c, M6A_EINVAL, "n_iters*n_samples too large");
+    if (rng_mode != M6A_RNG_NUMPY) return fail(c, M6A_EUNSUPPORTED, "rng_mode %d not supported", rng_mode);
+    if (bs < 1 || spb < 1) return fail(c, M6A_EINVAL, "batch_size and save_per_batch must be >= 1");
+    return M6A_OK;
+}
+
+int deferred_error(m6a_ctx *c)
+{
+    // stream is idle here
+    if (*c->h_err) { *c->h_err = 0; return fail(c, M6A_ESTREAM, "MT19937 stream too short for a flush group"); }
+    return M6A_OK;
+}
+
+int sync_and_check(m6a_ctx *c)
+{
+    HIPCHK(c, hipMemcpyAsync(c->h_err, c->d_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (*c->h_err) {
+        HIPCHK(c, hipMemsetAsync(c->d_err, 0, sizeof(int), c->stream));
+        return deferred_error(c);
+    }
+    return M6A_OK;
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+const char *m6a_version(void) { return "m6a_hip 0.1 (gfx950)"; }
+
+const char *m6a_last_error(const m6a_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int m6a_create(m6a_ctx **out, const float *weights, size_t n_floats, int device_id)
+{
+    if (!out) return M6A_EINVAL;
+    *out = nullptr;
+    if (!weights || n_floats != M6A_N_WEIGHTS)
+        return fail(nullptr, M6A_EINVAL, "weights must be %d floats (got %zu)", M6A_N_WEIGHTS, n_floats);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        (void)hipGetLastError();
+        return fail(nullptr, M6A_ENODEV, "no HIP device visible");
+    }
+    if (device_id < 0 || device_id >= ndev) return fail(nullptr, M6A_EINVAL, "device_id %d out of range (%d devices)", device_id, ndev);
+    m6a_ctx *c = new (std::nothrow) m6a_ctx;
+    if (!c) return fail(nullptr, M6A_ENOMEM, "out of host memory");
+    c->device = device_id;
+#define CRCHK(expr)                                                                                  \
+    do {                                                                                             \
+        hipError_t e_ = (expr);                                                                      \
+        if (e_ != hipSuccess) {                                                                      \
+            (void)hipGetLastError();                                                                 \
+            fail(nullptr, M6A_EHIP, "%s: %s", #expr, hipGetErrorString(e_));                         \
+            m6a_destroy(c);                                                                          \
+            return M6A_EHIP;                                                                         \
+        }                                                                                            \
+    } while (0)
+    CRCHK(hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    CRCHK(hipGetDeviceProperties(&prop, device_id));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        fail(nullptr, M6A_ENODEV, "device %d is %s; this library is built for gfx950 only", device_id, prop.gcnArchName);
+        m6a_destroy(c);
+        return M6A_ENODEV;
+    }
+    c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    CRCHK(hipStreamCreate(&c->own_stream));
+    c->stream = c->own_stream;
+    std::vector<float> frag;
+    build_fragments(weights, frag);
+    CRCHK(hipMalloc((void **)&c->d_wfrag, frag.size() * sizeof(float)));
+    CRCHK(hipMalloc((void **)&c->d_emb, 132 * sizeof(float)));
+    CRCHK(hipMemcpy(c->d_wfrag, frag.data(), frag.size() * sizeof(float), hipMemcpyHostToDevice));
+    CRCHK(hipMemcpy(c->d_emb, weights + O_E, 132 * sizeof(float), hipMemcpyHostToDevice));
+    c->b3 = weights[O_B3];
+    CRCHK(hipMalloc((void **)&c->d_err, sizeof(int)));
+    CRCHK(hipMemset(c->d_err, 0, sizeof(int)));
+    CRCHK(hipMalloc((void **)&c->d_minmax, 16));
+    CRCHK(hipHostMalloc((void **)&c->h_minmax, 16, hipHostMallocDefault));
+    CRCHK(hipHostMalloc((void **)&c->h_err, sizeof(int), hipHostMallocDefault));
+    *c->h_err = 0;
+#undef CRCHK
+    *out = c;
+    return M6A_OK;
+}
+
+void m6a_destroy(m6a_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (int k = 0; k < 2; k++) {
+        for (auto e : c->prof.start[k]) (void)hipEventDestroy(e);
+        for (auto e : c->prof.stop[k]) (void)hipEventDestroy(e);
+    }
+    for (DevBuf *b : {&c->raw, &c->tab, &c->goff, &c->rp_scratch, &c->off_scratch, &c->sX, &c->sK, &c->sOff,
+                      &c->sP, &c->sSite, &c->sMod}) b->release();
+    if (c->d_wfrag) (void)hipFree(c->d_wfrag);
+    if (c->d_emb) (void)hipFree(c->d_emb);
+    if (c->d_err) (void)hipFree(c->d_err);
+    if (c->d_minmax) (void)hipFree(c->d_minmax);
+    if (c->h_minmax) (void)hipHostFree(c->h_minmax);
+    if (c->h_err) (void)hipHostFree(c->h_err);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+int m6a_set_stream(m6a_ctx *c, void *hip_stream)
+{
+    if (!c) return M6A_EINVAL;
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return M6A_OK;
+}
+
+int m6a_set_job_offset(m6a_ctx *c, int64_t first_site)
+{
+    if (!c) return M6A_EINVAL;
+    if (first_site < 0) return fail(c, M6A_EINVAL, "job offset must be >= 0");
+    c->job_offset = first_site;
+    return M6A_OK;
+}
+
+int m6a_sync(m6a_ctx *c)
+{
+    if (!c) return M6A_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    return sync_and_check(c);
+}
+
+int m6a_encode_reads(m6a_ctx *c, const float *X, const uint8_t *km, const int64_t *off, int64_t S, float *rp)
+{
+    if (!c) return M6A_EINVAL;
+    if (S < 0) return fail(c, M6A_EINVAL, "n_sites < 0");
+    if (S == 0) return M6A_OK;
+    if (!X || !km || !off || !rp) return fail(c, M6A_EINVAL, "null pointer argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    const bool dev = is_device_ptr(X);
+    if (dev != is_device_ptr(km) || dev != is_device_ptr(off) || dev != is_device_ptr(rp))
+        return fail(c, M6A_EINVAL, "X, site_kmers, off, read_prob must be all host or all device pointers");
+    if (!dev) {
+        if (off[0] != 0) return fail(c, M6A_EINVAL, "off[0] must be 0");
+        for (int64_t s = 0; s < S; s++) if (off[s + 1] < off[s]) return fail(c, M6A_EINVAL, "off[] must be non-decreasing");
+        const int64_t R = off[S];
+        if (R == 0) return M6A_OK;
+        HIPCHK(c, c->sX.ensure((size_t)R * 9 * 4));
+        HIPCHK(c, c->sK.ensure((size_t)S * 3));
+        HIPCHK(c, c->sOff.ensure((size_t)(S + 1) * 8));
+        HIPCHK(c, c->sP.ensure((size_t)R * 4));
+        HIPCHK(c, hipMemcpyAsync(c->sX.p, X, (size_t)R * 9 * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->sK.p, km, (size_t)S * 3, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->sOff.p, off, (size_t)(S + 1) * 8, hipMemcpyHostToDevice, c->stream));
+        int rc = launch_encode(c, (const float *)c->sX.p, (const uint8_t *)c->sK.p, (const int64_t *)c->sOff.p, S, R, (float *)c->sP.p);
+        if (rc) return rc;
+        HIPCHK(c, hipMemcpyAsync(rp, c->sP.p, (size_t)R * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return M6A_OK;
+    }
+    // device pointers: R = off[S] is needed for the grid; 8-byte read-back
+    int64_t R = 0;
+    HIPCHK(c, hipMemcpyAsync(&R, off + S, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return launch_encode(c, X, km, off, S, R, rp);
+}
+
+int m6a_site_pool(m6a_ctx *c, const float *rp, const int64_t *off, int64_t S, int T, int K, float thr,
+                  uint32_t seed, int rng_mode, int64_t bs, int64_t spb, float *site, double *mod)
+{
+    int rc = check_pool_args(c, S, T, K, rng_mode, bs, spb);
+    if (rc) return rc;
+    if (S == 0) return M6A_OK;
+    if (!rp || !off || !site || !mod) return fail(c, M6A_EINVAL, "null pointer argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    const bool dev = is_device_ptr(rp);
+    if (dev != is_device_ptr(off) || dev != is_device_ptr(site) || dev != is_device_ptr(mod))
+        return fail(c, M6A_EINVAL, "read_prob, off, site_prob, mod_ratio must be all host or all device pointers");
+    if (dev) return launch_pool(c, rp, off, S, T, K, thr, seed, bs, spb, site, mod);
+    if (off[0] != 0) return fail(c, M6A_EINVAL, "off[0] must be 0");
+    for (int64_t s = 0; s < S; s++) if (off[s + 1] < off[s]) return fail(c, M6A_EINVAL, "off[] must be non-decreasing");
+    const int64_t R = off[S];
+    HIPCHK(c, c->sP.ensure((size_t)std::max<int64_t>(R, 1) * 4));
+    HIPCHK(c, c->sOff.ensure((size_t)(S + 1) * 8));
+    HIPCHK(c, c->sSite.ensure((size_t)S * 4));
+    HIPCHK(c, c->sMod.ensure((size_t)S * 8));
+    HIPCHK(c, hipMemcpyAsync(c->sP.p, rp, (size_t)R * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->sOff.p, off, (size_t)(S + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    rc = launch_pool(c, (const float *)c->sP.p, (const int64_t *)c->sOff.p, S, T, K, thr, seed, bs, spb,
+                     (float *)c->sSite.p, (double *)c->sMod.p);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(site, c->sSite.p, (size_t)S * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(mod, c->sMod.p, (size_t)S * 8, hipMemcpyDeviceToHost, c->stream));
+    return sync_and_check(c);
+}
+
+int m6a_infer(m6a_ctx *c, const float *X, const uint8_t *km, const int64_t *off, int64_t S, int T, int K,
+              float thr, uint32_t seed, int rng_mode, int64_t bs, int64_t spb, float *rp, float *site, double *mod)
+{
+    int rc = check_pool_args(c, S, T, K, rng_mode, bs, spb);
+    if (rc) return rc;
+    if (S == 0) return M6A_OK;
+    if (!X || !km || !off || !site || !mod) return fail(c, M6A_EINVAL, "null pointer argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    const bool dev = is_device_ptr(X);
+    if (dev != is_device_ptr(km) || dev != is_device_ptr(off) || dev != is_device_ptr(site) ||
+        dev != is_device_ptr(mod) || (rp && dev != is_device_ptr(rp)))
+        return fail(c, M6A_EINVAL, "all data pointers must be host pointers or all device pointers");
+    if (dev) {
+        int64_t R = 0;
+        HIPCHK(c, hipMemcpyAsync(&R, off + S, 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        float *p = rp;
+        if (!p) { HIPCHK(c, c->rp_scratch.ensure((size_t)std::max<int64_t>(R, 1) * 4)); p = (float *)c->rp_scratch.p; }
+        rc = launch_encode(c, X, km, off, S, R, p);
+        if (rc) return rc;
+        return launch_pool(c, p, off, S, T, K, thr, seed, bs, spb, site, mod);
+    }
+    if (off[0] != 0) return fail(c, M6A_EINVAL, "off[0] must be 0");
+    for (int64_t s = 0; s < S; s++) if (off[s + 1] < off[s]) return fail(c, M6A_EINVAL, "off[] must be non-decreasing");
+    const int64_t R = off[S];
+    HIPCHK(c, c->sX.ensure((size_t)std::max<int64_t>(R, 1) * 9 * 4));
+    HIPCHK(c, c->sK.ensure((size_t)S * 3));
+    HIPCHK(c, c->sOff.ensure((size_t)(S + 1) * 8));
+    HIPCHK(c, c->sP.ensure((size_t)std::max<int64_t>(R, 1) * 4));
+    HIPCHK(c, c->sSite.ensure((size_t)S * 4));
+    HIPCHK(c, c->sMod.ensure((size_t)S * 8));
+    HIPCHK(c, hipMemcpyAsync(c->sX.p, X, (size_t)R * 9 * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->sK.p, km, (size_t)S * 3, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->sOff.p, off, (size_t)(S + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    rc = launch_encode(c, (const float *)c->sX.p, (const uint8_t *)c->sK.p, (const int64_t *)c->sOff.p, S, R, (float *)c->sP.p);
+    if (rc) return rc;
+    rc = launch_pool(c, (const float *)c->sP.p, (const int64_t *)c->sOff.p, S, T, K, thr, seed, bs, spb,
+                     (float *)c->sSite.p, (double *)c->sMod.p);
+    if (rc) return rc;
+    if (rp) HIPCHK(c, hipMemcpyAsync(rp, c->sP.p, (size_t)R * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(site, c->sSite.p, (size_t)S * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(mod, c->sMod.p, (size_t)S * 8, hipMemcpyDeviceToHost, c->stream));
+    return sync_and_check(c);
+}
+
+int m6a_bag_forward(m6a_ctx *c, const float *X, const uint8_t *km, int64_t B, int bag, float *site)
+{
+    if (!c) return M6A_EINVAL;
+    if (B < 0 || bag < 1) return fail(c, M6A_EINVAL, "n_bags must be >= 0 and bag >= 1");
+    if (B == 0) return M6A_OK;
+    if (!X || !km || !site) return fail(c, M6A_EINVAL, "null pointer argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    const bool dev = is_device_ptr(X);
+    if (dev != is_device_ptr(km) || dev != is_device_ptr(site))
+        return fail(c, M6A_EINVAL, "X, site_kmers, site_prob must be all host or all device pointers");
+    const int64_t R = B * bag;
+    HIPCHK(c, c->off_scratch.ensure((size_t)(B + 1) * 8));
+    HIPCHK(c, c->rp_scratch.ensure((size_t)R * 4));
+    int64_t *d_off = (int64_t *)c->off_scratch.p;
+    float *d_p = (float *)c->rp_scratch.p;
+    hipLaunchKernelGGL(iota_off_kernel, dim3((unsigned)((B + 1 + 255) / 256)), dim3(256), 0, c->stream, d_off, B + 1, (int64_t)bag);
+    HIPCHK(c, hipGetLastError());
+    const float *dX = X; const uint8_t *dK = km; float *dS = site;
+    if (!dev) {
+        HIPCHK(c, c->sX.ensure((size_t)R * 9 * 4));
+        HIPCHK(c, c->sK.ensure((size_t)B * 3));
+        HIPCHK(c, c->sSite.ensure((size_t)B * 4));
+        HIPCHK(c, hipMemcpyAsync(c->sX.p, X, (size_t)R * 9 * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->sK.p, km, (size_t)B * 3, hipMemcpyHostToDevice, c->stream));
+        dX = (const float *)c->sX.p; dK = (const uint8_t *)c->sK.p; dS = (float *)c->sSite.p;
+    }
+    int rc = launch_encode(c, dX, dK, d_off, B, R, d_p);
+    if (rc) return rc;
+    hipLaunchKernelGGL(bag_noisy_or_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, c->stream, d_p, B, bag, dS);
+    HIPCHK(c, hipGetLastError());
+    if (!dev) {
+        HIPCHK(c, hipMemcpyAsync(site, dS, (size_t)B * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    return M6A_OK;
+}
+
+int64_t m6a_flush_groups(int64_t S, int64_t bs, int64_t spb, int64_t *group_off, int64_t cap)
+{
+    if (S < 0 || bs < 1 || spb < 1 || !group_off) return M6A_EINVAL;
+    std::vector<int64_t> g;
+    const int64_t G = flush_groups(S, bs, spb, 0, g);
+    if (cap < G + 1) return M6A_EINVAL;
+    std::copy(g.begin(), g.end(), group_off);
+    return G;
+}
+
+int m6a_shard_plan(const int64_t *off, int64_t S, int64_t bs, int64_t spb, int n_shards, int64_t *shard_off)
+{
+    if (!off || !shard_off || S < 0 || n_shards < 1 || bs < 1 || spb < 1) return M6A_EINVAL;
+    std::vector<int64_t> g;
+    const int64_t G = flush_groups(S, bs, spb, 0, g);
+    const int64_t R = S > 0 ? off[S] : 0;
+    shard_off[0] = 0;
+    int64_t gi = 0;
+    for (int k = 1; k <= n_shards; k++) {
+        if (k == n_shards) { shard_off[k] = S; break; }
+        // smallest group boundary whose read prefix reaches k/n of the reads
+        const double target = (double)R * k / n_shards;
+        while (gi < G && (double)off[g[gi]] < target) gi++;
+        // pick the closer of the two neighbouring boundaries
+        if (gi > 0 && gi <= G) {
+            const double hi = (double)off[g[std::min(gi, G)]], lo = (double)off[g[gi - 1]];
+            if (target - lo < hi - target && g[gi - 1] >= shard_off[k - 1]) gi--;
+        }
+        shard_off[k] = std::max(g[std::min(gi, G)], shard_off[k - 1]);
+    }
+    return M6A_OK;
+}
+
+int m6a_profile_enable(m6a_ctx *c, int on)
+{
+    if (!c) return M6A_EINVAL;
+    c->prof.on = on != 0;
+    c->prof.used[0] = c->prof.used[1] = 0;
+    c->prof.dropped[0] = c->prof.dropped[1] = 0;
+    return M6A_OK;
+}
+
+int m6a_profile_read(m6a_ctx *c, int kind, double *total_ms, int64_t *n_launches)
+{
+    if (!c || kind < 0 || kind > 1 || !total_ms || !n_launches) return M6A_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    double tot = 0;
+    for (int i = 0; i < c->prof.used[kind]; i++) {
+        float ms = 0;
+        HIPCHK(c, hipEventElapsedTime(&ms, c->prof.start[kind][i], c->prof.stop[kind][i]));
+        tot += ms;
+    }
+    *total_ms = tot;
+    *n_launches = c->prof.used[kind];
+    return M6A_OK;
+}
+
+const char *m6a_last_pool_variant(const m6a_ctx *c) { return c ? c->pool_variant : "none"; }
+
+}  // extern "C"

@@ -1,0 +1,43 @@
+// m6a_kernels.h -- kernel argument blocks shared by m6a_kernels.hip and m6a_api.hip.
+#ifndef M6A_KERNELS_H
+#define M6A_KERNELS_H
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define M6A_BAG_LDS 1024          // reads of a bag kept in LDS by pool_scan_kernel (rest: global)
+#define M6A_WFRAG_FLOATS (136 * 64)   // 40 (W1) + 80 (W2) + 16 (W3) registers x 64 lanes
+#define M6A_TABLE_MAX_N 32        // pool_table_kernel: byte offsets 8*idx must fit a byte
+
+struct EncArgs {
+    const float *X;               // [R][9]
+    const uint8_t *site_kmers;    // [S][3]
+    const int64_t *off;           // [S+1]
+    const float *wfrag;           // [136][64] lane-major MFMA weight fragments
+    const float *emb;             // [66][2]
+    float *read_prob;             // [R]
+    int64_t n_sites, n_reads, n_tiles, tiles_per_wave;
+    float b3;
+};
+
+struct PoolArgs {
+    const float *read_prob;       // [R]
+    const int64_t *off;           // [S+1]
+    const int64_t *goff;          // [G+1] flush-group site offsets
+    const uint32_t *raw;          // MT19937 word stream (scan) ...
+    const uint32_t *tab;          // ... or accepted-index table (table)
+    float *site_prob;             // [S]
+    double *mod_ratio;            // [S]
+    int *err;
+    int64_t n_groups, raw_len;
+    int T, K, uniform_n, jmax;
+    float thr;
+};
+
+__global__ void enc_kernel(EncArgs a);
+template <int KT> __global__ void pool_scan_kernel(PoolArgs a);
+__global__ void pool_table_kernel(PoolArgs a);
+__global__ void bag_noisy_or_kernel(const float *read_prob, int64_t n_bags, int bag, float *site_prob);
+__global__ void iota_off_kernel(int64_t *off, int64_t n_plus_1, int64_t step);
+__global__ void bag_minmax_kernel(const int64_t *off, int64_t n_sites, unsigned long long *out);
+
+#endif

@@ -1,0 +1,400 @@
+// m6a_kernels.hip -- gfx950 (MI355X / CDNA4) kernels of the m6A inference hot path.
+//
+//   enc_kernel         read encoder: [x(9) | emb(6) | 1] -> 150 (BN folded) -> ReLU -> 32 -> ReLU
+//                      -> 1 -> sigmoid, all in registers on v_mfma_f32_32x32x2_f32 (exact f32).
+//   pool_scan_kernel   site pooling, exact NumPy-stream replay, any bag sizes: one wavefront
+//                      per flush group walks the shared MT19937 word stream (masked rejection),
+//                      compacts accepted draws through LDS and multiplies 20-term products.
+//   pool_table_kernel  same result when every bag has the same size n <= 32: the accepted
+//                      index sequence is then identical in every flush group, so it is a
+//                      precomputed table and the kernel is a pure LDS gather, 8 sites per pass.
+//   bag_noisy_or_kernel, iota_off_kernel, bag_minmax_kernel: small helpers.
+//
+// Reference lines each kernel restates are cited at the kernel.  Wave = 64 lanes throughout.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "m6a_kernels.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float wave_sum_f32(float v)
+{
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+__device__ __forceinline__ int wave_sum_i32(int v)
+{
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+// Orders this wave's LDS traffic: LDS ops of one wave execute in issue order, so a compiler
+// fence (no s_barrier) is all a single-wave producer/consumer needs.
+__device__ __forceinline__ void wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// =====================================================================================
+// Read encoder  (reference: m6anet/model/model_blocks/blocks.py:116-126 view, :194-205
+// embedding, :55-66 concat, :257-266 Linear+BN+ReLU twice per m6anet.toml:16-28;
+// pooling_blocks.py:52 Linear(32,1)+Sigmoid, as called from inference_utils.py:35-37)
+//
+// One wavefront owns a tile of 32 reads.  Everything is computed transposed,
+//     H1^T[160 x 32] = W1aug[160 x 16] . F^T[16 x 32],   H2^T[32 x 32] = W2aug[32 x 160] . H1^T,
+// so the reads sit on the MFMA N axis (lane & 31) in both layers and layer 1's accumulator
+// registers ARE layer 2's B operands: D register q of half h holds hidden unit
+// 32m + (q&3) + 8(q>>2) + 4h for read (lane&31), and an MFMA K-step wants
+// B[k = 2s + h][n = lane&31] -- the K axis of a matmul can be walked in any order, so the
+// weights are pre-permuted on the host to the order the accumulators come in.  No LDS, no
+// shuffles between layers.
+//   F (16 features) = x0..x8, e0..e5 (three 2-float embeddings), 1.0 -- the constant carries
+//   b1 (BatchNorm folded into W1aug/b1 on the host); hidden unit 150 is wired to the constant
+//   1.0 and carries b2 through W2aug[:,150]; units 151..159 are zero padding.
+// Lane halves load different features: h=0 lanes x0..x7, h=1 lanes x8, e0..e5, 1.
+// =====================================================================================
+__global__ __launch_bounds__(256, 2) void enc_kernel(EncArgs a)
+{
+    __shared__ float s_emb[132];
+    for (int i = threadIdx.x; i < 132; i += 256) s_emb[i] = a.emb[i];
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int col = lane & 31;
+    const int half = lane >> 5;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t tile0 = wave * a.tiles_per_wave;
+    if (tile0 >= a.n_tiles) return;
+    const int64_t tile1 = (tile0 + a.tiles_per_wave < a.n_tiles) ? tile0 + a.tiles_per_wave : a.n_tiles;
+
+    // weight fragments, lane-major on the host side: one coalesced load per register
+    float w1[40], w2[80], w3[16];
+#pragma unroll
+    for (int i = 0; i < 40; i++) w1[i] = a.wfrag[i * 64 + lane];
+#pragma unroll
+    for (int i = 0; i < 80; i++) w2[i] = a.wfrag[(40 + i) * 64 + lane];
+#pragma unroll
+    for (int i = 0; i < 16; i++) w3[i] = a.wfrag[(120 + i) * 64 + lane];
+
+    // site cursor for the wave's first read: largest s with off[s] <= r (upper_bound - 1)
+    int64_t s_cur;
+    {
+        const int64_t r = tile0 * 32;
+        int64_t lo = 0, hi = a.n_sites;          // invariant: off[lo] <= r < off[hi]
+        while (hi - lo > 1) {
+            int64_t mid = (lo + hi) >> 1;
+            if (a.off[mid] <= r) lo = mid; else hi = mid;
+        }
+        s_cur = lo;
+    }
+
+    for (int64_t tile = tile0; tile < tile1; ++tile) {
+        const int64_t r = tile * 32 + col;
+        const int64_t rc = r < a.n_reads ? r : a.n_reads - 1;
+        float f[8];
+        // every lane walks the cursor (cheap, keeps it wave-uniform for the next tile)
+        int64_t s = s_cur;
+        while (a.off[s + 1] <= rc) ++s;
+        s_cur = __shfl(s, 31, 64);   // site of the tile's last read; next tile starts there
+        if (half == 0) {
+            const float *x = a.X + rc * 9;
+#pragma unroll
+            for (int i = 0; i < 8; i++) f[i] = x[i];
+        } else {
+            f[0] = a.X[rc * 9 + 8];
+            const uint8_t *km = a.site_kmers + s * 3;
+            const int k0 = km[0], k1 = km[1], k2 = km[2];
+            f[1] = s_emb[2 * k0]; f[2] = s_emb[2 * k0 + 1];
+            f[3] = s_emb[2 * k1]; f[4] = s_emb[2 * k1 + 1];
+            f[5] = s_emb[2 * k2]; f[6] = s_emb[2 * k2 + 1];
+            f[7] = 1.0f;
+        }
+
+        f32x16 acc2;
+#pragma unroll
+        for (int q = 0; q < 16; q++) acc2[q] = 0.0f;
+#pragma unroll
+        for (int m = 0; m < 5; m++) {
+            f32x16 acc1;
+#pragma unroll
+            for (int q = 0; q < 16; q++) acc1[q] = 0.0f;
+#pragma unroll
+            for (int st = 0; st < 8; st++)
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[m * 8 + st], f[st], acc1, 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const float hq = fmaxf(acc1[q], 0.0f);
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(w2[m * 16 + q], hq, acc2, 0, 0, 0);
+            }
+        }
+        float z = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 16; q++) z = fmaf(fmaxf(acc2[q], 0.0f), w3[q], z);
+        z += __shfl_xor(z, 32, 64);
+        z += a.b3;
+        const float p = 1.0f / (1.0f + expf(-z));
+        if (half == 0 && r < a.n_reads) a.read_prob[r] = p;
+    }
+}
+
+// =====================================================================================
+// Site pooling, general bags -- exact replay of
+//   proba = np.random.choice(proba, n_iters*n_samples, replace=True).reshape(n_iters, n_samples)
+//   (1 - np.prod(1 - proba, axis=1)).mean()               (inference_utils.py:85-86)
+// for every site of every flush group, plus mod_ratio = mean(p >= thr) (inference_utils.py:53).
+// RandomState.choice -> legacy randint(0,n): rng = n-1, mask = 2^ceil(log2(n))-1,
+// `do v = next32() & mask; while (v > rng)`; the Pool worker of each flush group starts from
+// the seeded, never-advanced state (inference_utils.py:102-104 after inference.py:86), so all
+// groups read the SAME word stream `raw` (generated once on the host) from position 0, and the
+// sites of a group consume it back to back.
+//
+// One wavefront per flush group.  Per step 64 consecutive words are tested; accepted lanes get
+// their rank by ballot + mbcnt, gather 1-p from the LDS bag and drop it at slot -> slot +
+// slot/K (row stride K+1: conflict-free both for the rank-ordered write and for the
+// per-iteration read back).  Every 64 completed iterations the lanes multiply their K values
+// left to right (float32, same order as np.prod) and accumulate 1 - prod.
+// =====================================================================================
+template <int KT>
+__global__ __launch_bounds__(256) void pool_scan_kernel(PoolArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int K = KT ? KT : a.K;
+    const int lane = threadIdx.x & 63;
+    const int wib = threadIdx.x >> 6;
+    const int per_wave = M6A_BAG_LDS + 64 * (K + 1) + 128;
+    float *bag = smem + wib * per_wave;
+    float *buf = bag + M6A_BAG_LDS;
+    const int CH = 64 * K;
+    const int A = a.T * K;                       // accepted draws per site
+    const int64_t n_waves = (int64_t)gridDim.x * 4;
+
+    for (int64_t g = (int64_t)blockIdx.x * 4 + wib; g < a.n_groups; g += n_waves) {
+        uint32_t pos = 0;                        // next unread word of the group's stream
+        const int64_t s_end = a.goff[g + 1];
+        for (int64_t s = a.goff[g]; s < s_end; ++s) {
+            const int64_t r0 = a.off[s];
+            const int n = (int)(a.off[s + 1] - r0);
+            int cge = 0;
+            for (int i = lane; i < n; i += 64) {
+                const float v = a.read_prob[r0 + i];
+                cge += (v >= a.thr) ? 1 : 0;
+                if (i < M6A_BAG_LDS) bag[i] = 1.0f - v;
+            }
+            cge = wave_sum_i32(cge);
+            if (lane == 0) a.mod_ratio[s] = n > 0 ? (double)cge / (double)n : __builtin_nan("");
+            if (n <= 0) { if (lane == 0) a.site_prob[s] = __builtin_nanf(""); continue; }
+            wave_lds_fence();
+
+            const uint32_t rng = (uint32_t)(n - 1);
+            float sum = 0.0f;
+            if (rng == 0) {                      // bag of one read: randint draws no words
+                float prod = 1.0f;
+                const float a0 = bag[0];
+                for (int k = 0; k < K; k++) prod *= a0;
+                if (lane == 0) a.site_prob[s] = 1.0f - prod;
+                wave_lds_fence();
+                continue;
+            }
+            uint32_t mask = rng;
+            mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+
+            int acc = 0, cnt = 0;
+            bool done = false;
+            while (!done) {
+                if ((uint64_t)pos + 256 > (uint64_t)a.raw_len) {      // stream too short: report
+                    if (lane == 0) atomicExch(a.err, 1);
+                    done = true;
+                    break;
+                }
+                uint32_t w[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) w[i] = a.raw[pos + 64 * i + lane];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    if (done) break;
+                    const uint32_t v = w[i] & mask;
+                    bool ok = v <= rng;
+                    const unsigned long long bal = __ballot(ok);
+                    int c = __popcll(bal);
+                    const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32),
+                                     __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0));
+                    const int remaining = A - acc;
+                    if (c >= remaining) {        // this step completes the site
+                        ok = ok && rank < remaining;
+                        const unsigned long long lastb = __ballot(ok && rank == remaining - 1);
+                        pos += 64 * i + (uint32_t)__builtin_ctzll(lastb) + 1;
+                        c = remaining;
+                        done = true;
+                    }
+                    if (ok) {
+                        const float val = v < M6A_BAG_LDS ? bag[v] : 1.0f - a.read_prob[r0 + v];
+                        const int slot = cnt + rank;
+                        buf[slot + slot / K] = val;
+                    }
+                    cnt += c;
+                    acc += c;
+                    if (cnt >= CH) {
+                        wave_lds_fence();
+                        float prod = 1.0f;
+                        const float *row = buf + lane * (K + 1);
+                        for (int k = 0; k < K; k++) prod *= row[k];
+                        sum += 1.0f - prod;
+                        const int m = cnt - CH;  // < 64 overflow slots move to the front
+                        float tmp = 0.0f;
+                        if (lane < m) { const int sl = CH + lane; tmp = buf[sl + sl / K]; }
+                        wave_lds_fence();
+                        if (lane < m) buf[lane + lane / K] = tmp;
+                        cnt = m;
+                        wave_lds_fence();
+                    }
+                }
+                if (!done) pos += 256;
+            }
+            wave_lds_fence();
+            const int t_rem = cnt / K;           // iterations left in the buffer (< 64)
+            if (lane < t_rem) {
+                float prod = 1.0f;
+                const float *row = buf + lane * (K + 1);
+                for (int k = 0; k < K; k++) prod *= row[k];
+                sum += 1.0f - prod;
+            }
+            sum = wave_sum_f32(sum);
+            if (lane == 0) a.site_prob[s] = sum / (float)a.T;
+            wave_lds_fence();
+        }
+    }
+}
+
+template __global__ void pool_scan_kernel<20>(PoolArgs);
+template __global__ void pool_scan_kernel<0>(PoolArgs);
+
+// =====================================================================================
+// Site pooling, uniform bags (every site has the same n <= 32 reads), K = 20.
+// Same arithmetic as pool_scan_kernel; because every site consumes the stream identically,
+// the accepted indices of "the j-th site of a flush group" are the same in every group:
+// tab[j][round][plane][lane] packs, for iteration t = 64*round + lane, byte offsets 8*idx of
+// its 20 draws (5 dwords).  One wavefront takes position j of 8 consecutive groups: the 8
+// bags sit in LDS as 4 arrays of float2 (two sites per 8-byte entry, 160 B per array, one
+// array per 256 B bank row), so each ds_read_b64 gathers for two sites, conflict-free, and
+// one v_pk_mul_f32 advances both products.
+// =====================================================================================
+__global__ __launch_bounds__(256) void pool_table_kernel(PoolArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float s_bag[4][4 * 64];   // [wave][pair*64 + 2*i + e]
+    const int lane = threadIdx.x & 63;
+    const int wib = threadIdx.x >> 6;
+    float *bag = s_bag[wib];
+    const int n = a.uniform_n;
+    const int rounds = (a.T + 63) >> 6;
+    const int64_t gblocks = (a.n_groups + 7) >> 3;
+    const int64_t n_items = gblocks * a.jmax;
+    const int64_t n_waves = (int64_t)gridDim.x * 4;
+
+    for (int64_t item = (int64_t)blockIdx.x * 4 + wib; item < n_items; item += n_waves) {
+        const int j = (int)(item % a.jmax);
+        const int64_t g0 = (item / a.jmax) * 8;
+        int64_t site[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int64_t g = g0 + q;
+            site[q] = -1;
+            if (g < a.n_groups) {
+                const int64_t s = a.goff[g] + j;
+                if (s < a.goff[g + 1]) site[q] = s;
+            }
+        }
+        // bags + mod_ratio
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            float v = 0.0f;
+            bool ge = false;
+            if (site[q] >= 0 && lane < n) {
+                v = a.read_prob[a.off[site[q]] + lane];
+                ge = v >= a.thr;
+            }
+            const int cge = __popcll(__ballot(ge));
+            if (lane < 32) bag[(q >> 1) * 64 + 2 * lane + (q & 1)] = 1.0f - v;
+            if (lane == 0 && site[q] >= 0) a.mod_ratio[site[q]] = (double)cge / (double)n;
+        }
+        wave_lds_fence();
+
+        float sum[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) sum[q] = 0.0f;
+        const uint32_t *tj = a.tab + (int64_t)j * rounds * 5 * 64 + lane;
+        const char *bagb = (const char *)bag;
+        for (int rd = 0; rd < rounds; ++rd) {
+            uint32_t ix[5];
+#pragma unroll
+            for (int pl = 0; pl < 5; pl++) ix[pl] = tj[(rd * 5 + pl) * 64];
+            float2 prod[4];
+#pragma unroll
+            for (int pr = 0; pr < 4; pr++) prod[pr] = make_float2(1.0f, 1.0f);
+#pragma unroll
+            for (int k = 0; k < 20; k++) {
+                const uint32_t o = (ix[k >> 2] >> (8 * (k & 3))) & 0xffu;
+#pragma unroll
+                for (int pr = 0; pr < 4; pr++) {
+                    const float2 v = *(const float2 *)(bagb + pr * 256 + o);
+                    prod[pr].x *= v.x;
+                    prod[pr].y *= v.y;
+                }
+            }
+            const bool live = rd * 64 + lane < a.T;
+#pragma unroll
+            for (int pr = 0; pr < 4; pr++) {
+                sum[2 * pr] += live ? 1.0f - prod[pr].x : 0.0f;
+                sum[2 * pr + 1] += live ? 1.0f - prod[pr].y : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const float tot = wave_sum_f32(sum[q]);
+            if (lane == 0 && site[q] >= 0) a.site_prob[site[q]] = tot / (float)a.T;
+        }
+        wave_lds_fence();
+    }
+}
+
+// 1 - prod_k (1 - p[b*bag + k]), float32 left to right (pooling_blocks.py:127-129)
+__global__ void bag_noisy_or_kernel(const float *read_prob, int64_t n_bags, int bag, float *site_prob)
+{
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_bags) return;
+    float prod = 1.0f;
+    for (int k = 0; k < bag; k++) prod *= 1.0f - read_prob[b * bag + k];
+    site_prob[b] = 1.0f - prod;
+}
+
+__global__ void iota_off_kernel(int64_t *off, int64_t n_plus_1, int64_t step)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_plus_1) off[i] = i * step;
+}
+
+// min / max bag size over all sites -> out[0], out[1] (initialised by the host to INT64_MAX, 0)
+__global__ void bag_minmax_kernel(const int64_t *off, int64_t n_sites, unsigned long long *out)
+{
+    int64_t mn = INT64_MAX, mx = 0;
+    for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < n_sites;
+         s += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t n = off[s + 1] - off[s];
+        mn = n < mn ? n : mn;
+        mx = n > mx ? n : mx;
+    }
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        const int64_t omn = __shfl_xor(mn, m, 64), omx = __shfl_xor(mx, m, 64);
+        mn = omn < mn ? omn : mn;
+        mx = omx > mx ? omx : mx;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(&out[0], (unsigned long long)mn);
+        atomicMax(&out[1], (unsigned long long)mx);
+    }
+}

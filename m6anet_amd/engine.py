@@ -1,0 +1,224 @@
+"""Host-side mirror of the reference's operator interface for the inference hot path, on top of
+the C ABI (include/m6a.h).  Names follow the reference:
+
+  M6ANetEngine.get_read_probability(X, site_kmers, off)
+      == model.get_read_representation({'X','kmer'}) + model.pooling_filter.probability_layer(.)
+         (m6anet/utils/inference_utils.py:35-37)
+  M6ANetEngine.calculate_site_proba(read_probs, off, n_iters, n_samples, ...)
+      == calculate_site_proba(read_probs, n_iters, n_samples, n_processes=1) + mod_ratio
+         (m6anet/utils/inference_utils.py:53-54,90-104)
+  M6ANetEngine.infer(...)     == one whole run_inference job minus text I/O (inference_utils.py:14-71)
+  M6ANetEngine.forward(X, kmer)  == MILModel.forward on fixed bags (m6anet/model/model.py:155-164)
+
+Arrays may be numpy arrays (host pointers: the library stages them and the call is synchronous)
+or torch tensors on the context's GPU (device pointers: zero-copy, stream-ordered).  PyTorch is
+only plumbing here (device memory + streams); nothing in this file computes.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .constants import (DEFAULT_PRETRAINED_MODEL, DEFAULT_READ_THRESHOLD, N_SAMPLES, N_WEIGHT_FLOATS,
+                        PRETRAINED_CONFIGS, asset_path)
+
+
+def load_weights(pretrained_model=DEFAULT_PRETRAINED_MODEL):
+    """Flat float32 weight blob (layout in include/m6a.h) of a bundled pretrained model."""
+    if pretrained_model not in PRETRAINED_CONFIGS:
+        raise ValueError("Invalid pretrained model {}, must be one of {}".format(
+            pretrained_model, list(PRETRAINED_CONFIGS)))
+    w = np.fromfile(asset_path(PRETRAINED_CONFIGS[pretrained_model][0]), np.float32)
+    assert w.size == N_WEIGHT_FLOATS
+    return w
+
+
+def weights_from_state_dict(sd):
+    """Flat blob from a reference checkpoint's state_dict (m6anet/model/model_states/*.pt,
+    keys as built by m6anet/model/model.py:40-69)."""
+    order = ["read_level_encoder.1.embedding_layer.weight", "read_level_encoder.3.layers.0.weight",
+             "read_level_encoder.3.layers.0.bias", "read_level_encoder.3.layers.1.weight",
+             "read_level_encoder.3.layers.1.bias", "read_level_encoder.3.layers.1.running_mean",
+             "read_level_encoder.3.layers.1.running_var", "read_level_encoder.4.layers.0.weight",
+             "read_level_encoder.4.layers.0.bias", "pooling_filter.probability_layer.0.weight",
+             "pooling_filter.probability_layer.0.bias"]
+    w = np.concatenate([np.asarray(sd[k].detach().cpu().numpy() if hasattr(sd[k], "detach") else sd[k],
+                                   np.float32).ravel() for k in order])
+    if w.size != N_WEIGHT_FLOATS:
+        raise ValueError("state_dict does not have the m6anet.toml topology (%d floats)" % w.size)
+    return w
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+class _Arg:
+    """Pointer + keep-alive for one array argument."""
+
+    def __init__(self, x, dtype, torch_dtype_name):
+        self.is_dev = False
+        if _is_torch(x):
+            import torch
+            want = getattr(torch, torch_dtype_name)
+            if x.dtype != want or not x.is_contiguous():
+                raise TypeError("tensor must be contiguous %s" % torch_dtype_name)
+            self.keep = x
+            self.ptr = x.data_ptr()
+            self.is_dev = x.is_cuda
+            self.size = x.numel()
+        else:
+            a = np.ascontiguousarray(x, dtype)
+            self.keep = a
+            self.ptr = a.ctypes.data
+            self.size = a.size
+
+
+class M6ANetEngine:
+    def __init__(self, weights=None, pretrained_model=DEFAULT_PRETRAINED_MODEL, device=0):
+        self._L = _lib.load()
+        if weights is None:
+            weights = load_weights(pretrained_model)
+        w = np.ascontiguousarray(weights, np.float32)
+        if w.size != N_WEIGHT_FLOATS:
+            raise ValueError("weights must have %d floats" % N_WEIGHT_FLOATS)
+        if isinstance(device, str):
+            device = int(device.split(":")[1]) if ":" in device else 0
+        self.device = int(device)
+        h = C.c_void_p()
+        rc = self._L.m6a_create(C.byref(h), w.ctypes.data, w.size, self.device)
+        if rc != 0:
+            raise _lib.M6AError(rc, self._L.m6a_last_error(None).decode())
+        self._h = h
+
+    # -- plumbing ---------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.m6a_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise _lib.M6AError(rc, self._L.m6a_last_error(self._h).decode())
+
+    def set_stream(self, stream_handle):
+        self._chk(self._L.m6a_set_stream(self._h, C.c_void_p(stream_handle or 0)))
+
+    def use_torch_stream(self):
+        import torch
+        self.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def set_job_offset(self, first_site):
+        """The sites given to calculate_site_proba/infer are sites [first_site, ...) of a larger
+        job (multi-GPU shards): flush groups and RNG restarts follow the job's batch indices."""
+        self._chk(self._L.m6a_set_job_offset(self._h, int(first_site)))
+
+    def sync(self):
+        self._chk(self._L.m6a_sync(self._h))
+
+    def profile(self, on=True):
+        self._chk(self._L.m6a_profile_enable(self._h, 1 if on else 0))
+
+    def profile_read(self, kind):
+        ms, n = C.c_double(), C.c_int64()
+        self._chk(self._L.m6a_profile_read(self._h, kind, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    @property
+    def last_pool_variant(self):
+        return self._L.m6a_last_pool_variant(self._h).decode()
+
+    def _out(self, like_dev, n, np_dtype, torch_name):
+        if like_dev:
+            import torch
+            return torch.empty(n, dtype=getattr(torch, torch_name), device="cuda:%d" % self.device)
+        return np.empty(n, np_dtype)
+
+    # -- the path ---------------------------------------------------------------------------
+    def get_read_probability(self, X, site_kmers, off, out=None):
+        aX, aK, aO = _Arg(X, np.float32, "float32"), _Arg(site_kmers, np.uint8, "uint8"), _Arg(off, np.int64, "int64")
+        S = aO.size - 1
+        R = aX.size // 9
+        if aK.size != 3 * S:
+            raise ValueError("site_kmers must be [n_sites, 3]")
+        rp = out if out is not None else self._out(aX.is_dev, R, np.float32, "float32")
+        aP = _Arg(rp, np.float32, "float32")
+        if aP.size != R:
+            raise ValueError("read_prob must have one float per read")
+        self._chk(self._L.m6a_encode_reads(self._h, aX.ptr, aK.ptr, aO.ptr, S, aP.ptr))
+        return rp
+
+    def calculate_site_proba(self, read_probs, off, n_iters, n_samples=N_SAMPLES,
+                             read_proba_threshold=DEFAULT_READ_THRESHOLD, seed=0, batch_size=16,
+                             save_per_batch=2):
+        """Returns (site_probs float32 [S], mod_ratios float64 [S])."""
+        aP, aO = _Arg(read_probs, np.float32, "float32"), _Arg(off, np.int64, "int64")
+        S = aO.size - 1
+        site = self._out(aP.is_dev, S, np.float32, "float32")
+        mod = self._out(aP.is_dev, S, np.float64, "float64")
+        aS, aM = _Arg(site, np.float32, "float32"), _Arg(mod, np.float64, "float64")
+        self._chk(self._L.m6a_site_pool(self._h, aP.ptr, aO.ptr, S, int(n_iters), int(n_samples),
+                                        float(np.float32(read_proba_threshold)), int(seed) & 0xffffffff,
+                                        _lib.RNG_NUMPY, int(batch_size), int(save_per_batch), aS.ptr, aM.ptr))
+        return site, mod
+
+    def infer(self, X, site_kmers, off, n_iters, n_samples=N_SAMPLES,
+              read_proba_threshold=DEFAULT_READ_THRESHOLD, seed=0, batch_size=16, save_per_batch=2,
+              want_read_probs=True, out=None):
+        """Returns (read_probs or None, site_probs, mod_ratios).  `out` = preallocated
+        (read_probs|None, site_probs, mod_ratios) to reuse buffers across calls."""
+        aX, aK, aO = _Arg(X, np.float32, "float32"), _Arg(site_kmers, np.uint8, "uint8"), _Arg(off, np.int64, "int64")
+        S = aO.size - 1
+        R = aX.size // 9
+        if out is not None:
+            rp, site, mod = out
+        else:
+            rp = self._out(aX.is_dev, R, np.float32, "float32") if want_read_probs else None
+            site = self._out(aX.is_dev, S, np.float32, "float32")
+            mod = self._out(aX.is_dev, S, np.float64, "float64")
+        aP = _Arg(rp, np.float32, "float32") if rp is not None else None
+        aS, aM = _Arg(site, np.float32, "float32"), _Arg(mod, np.float64, "float64")
+        self._chk(self._L.m6a_infer(self._h, aX.ptr, aK.ptr, aO.ptr, S, int(n_iters), int(n_samples),
+                                    float(np.float32(read_proba_threshold)), int(seed) & 0xffffffff,
+                                    _lib.RNG_NUMPY, int(batch_size), int(save_per_batch),
+                                    aP.ptr if aP else None, aS.ptr, aM.ptr))
+        return rp, site, mod
+
+    def forward(self, X, kmer, bag=N_SAMPLES):
+        """Site probability of fixed-size bags: X [B, bag, 9], kmer [B, 3] -> [B]."""
+        aX, aK = _Arg(X, np.float32, "float32"), _Arg(kmer, np.uint8, "uint8")
+        B = aK.size // 3
+        if aX.size != B * bag * 9:
+            raise ValueError("X must be [B, bag, 9]")
+        site = self._out(aX.is_dev, B, np.float32, "float32")
+        aS = _Arg(site, np.float32, "float32")
+        self._chk(self._L.m6a_bag_forward(self._h, aX.ptr, aK.ptr, B, int(bag), aS.ptr))
+        return site
+
+
+def flush_groups(n_sites, batch_size=16, save_per_batch=2):
+    """Site offsets of the reference's flush groups (inference_utils.py:33,47)."""
+    L = _lib.load()
+    nb = (n_sites + batch_size - 1) // batch_size
+    g = np.zeros(nb + 2, np.int64)
+    G = L.m6a_flush_groups(n_sites, batch_size, save_per_batch, g.ctypes.data, g.size)
+    if G < 0:
+        raise _lib.M6AError(int(G), "m6a_flush_groups")
+    return g[:G + 1].copy()
+
+
+def shard_plan(off, n_shards, batch_size=16, save_per_batch=2):
+    """Flush-group-aligned contiguous site shards balanced by read count -> int64 [n_shards+1]."""
+    L = _lib.load()
+    off = np.ascontiguousarray(off, np.int64)
+    out = np.zeros(n_shards + 1, np.int64)
+    rc = L.m6a_shard_plan(off.ctypes.data, off.size - 1, batch_size, save_per_batch, n_shards, out.ctypes.data)
+    if rc != 0:
+        raise _lib.M6AError(rc, "m6a_shard_plan")
+    return out

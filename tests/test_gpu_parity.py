@@ -1,0 +1,299 @@
+"""GPU parity tests: the HIP path (through the C ABI, via m6anet_amd.engine) against the CPU
+oracle and the golden vectors captured from the reference.
+
+Tolerances (stated per assertion):
+  * read probabilities: rtol=1e-5, atol=1e-8 -- the reference's own bar for
+    data.indiv_proba.csv (m6anet/tests/test_inference.py:32, np.allclose defaults);
+  * site probabilities from identical read probabilities: 1e-6 abs (indices, product order and
+    product values are exact replays; only the float32 summation tree of the mean differs from
+    NumPy's pairwise order); north_star asks for 1e-5;
+  * mod_ratio, flush groups, which sites get which draws: exact.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from m6anet_amd import synthetic                      # noqa: E402
+from m6anet_amd.constants import DEFAULT_READ_THRESHOLD  # noqa: E402
+
+THR = np.float32(DEFAULT_READ_THRESHOLD)
+SITE_ATOL = 1e-6
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import m6a_oracle
+    m6a_oracle.build()
+    return m6a_oracle
+
+
+@pytest.fixture(scope="module")
+def engines(weights):
+    from m6anet_amd.engine import M6ANetEngine
+    return {name: M6ANetEngine(weights=w) for name, w in weights.items()}
+
+
+@pytest.fixture(scope="module")
+def eng(engines):
+    return engines["hct116"]
+
+
+def rand_sites(seed, n_reads_per_site):
+    g = np.random.Generator(np.random.PCG64(seed))
+    n = np.asarray(n_reads_per_site, np.int64)
+    off = np.concatenate([[0], np.cumsum(n)]).astype(np.int64)
+    X = np.clip(g.standard_normal((int(off[-1]), 9)), -6, 6).astype(np.float32)
+    km = g.integers(0, 66, size=(len(n), 3)).astype(np.uint8)
+    return X, km, off
+
+
+def rand_probs(seed, off):
+    g = np.random.Generator(np.random.PCG64(seed))
+    # skewed like real read probabilities: mostly small, some large
+    return (g.random(int(off[-1]), dtype=np.float32) ** 4).astype(np.float32)
+
+
+# ------------------------------------------------------------------ encoder -----------------
+def test_encoder_golden_all_models(golden, engines):
+    b = golden("bundled_inputs.npz")
+    want = golden("bundled_readprob.npz")
+    for name, e in engines.items():
+        got = e.get_read_probability(b["X"], b["site_kmers"], b["off"])
+        assert np.allclose(got, want[name], rtol=1e-5, atol=1e-8), name
+
+
+@pytest.mark.parametrize("bags", [
+    [1], [20], [31], [32], [33], [1, 1, 1, 1, 1], [20] * 7, [0, 5, 0, 0, 7, 0], [3] * 100,
+    [1] * 200 + [40] + [1] * 50, [662, 20, 21, 500, 33], list(range(1, 70)),
+])
+def test_encoder_vs_oracle_shapes(eng, orc, weights, bags):
+    X, km, off = rand_sites(len(bags) * 7 + 1, bags)
+    got = eng.get_read_probability(X, km, off)
+    want = orc.encode_reads(weights["hct116"], X, km, off)
+    assert got.shape == want.shape
+    assert np.allclose(got, want, rtol=1e-5, atol=1e-8)
+
+
+def test_encoder_ragged_large_vs_oracle(engines, orc, weights):
+    g = np.random.Generator(np.random.PCG64(5))
+    bags = g.integers(20, 300, size=3000)
+    X, km, off = rand_sites(11, bags)
+    for name in ("hek293t_glori", "arabidopsis"):
+        got = engines[name].get_read_probability(X, km, off)
+        want = orc.encode_reads(weights[name], X, km, off, n_threads=8)
+        assert np.allclose(got, want, rtol=1e-5, atol=1e-8), name
+
+
+def test_encoder_extreme_inputs(eng, orc, weights):
+    X, km, off = rand_sites(3, [64] * 4)
+    X[:64] = 6.0
+    X[64:128] = -6.0
+    X[128:192] = 0.0
+    got = eng.get_read_probability(X, km, off)
+    want = orc.encode_reads(weights["hct116"], X, km, off)
+    assert np.all(np.isfinite(got))
+    assert np.allclose(got, want, rtol=1e-5, atol=1e-8)
+
+
+def test_encoder_empty(eng):
+    out = eng.get_read_probability(np.zeros((0, 9), np.float32), np.zeros((0, 3), np.uint8), np.zeros(1, np.int64))
+    assert out.shape == (0,)
+    out = eng.get_read_probability(np.zeros((0, 9), np.float32), np.zeros((3, 3), np.uint8), np.zeros(4, np.int64))
+    assert out.shape == (0,)
+
+
+def test_bag_forward_golden(eng, golden):
+    g = golden("bag_forward.npz")
+    got = eng.forward(g["X"], g["kmer"], bag=20)
+    assert np.allclose(got, g["site_prob"], rtol=1e-5, atol=1e-7)
+
+
+# ------------------------------------------------------------------ site pooling -------------
+CASES = [(5, 16, 2, 0), (100, 16, 2, 0), (1000, 16, 2, 0), (50, 8, 3, 0), (20, 13, 2, 7), (30, 51, 2, 0)]
+
+
+@pytest.mark.parametrize("T,bs,spb,seed", CASES)
+def test_pool_bundled_golden(eng, golden, T, bs, spb, seed):
+    """Ragged real bags (20..662 reads): the scan kernel against full reference runs."""
+    b = golden("bundled_inputs.npz")
+    p = golden("bundled_readprob.npz")["hct116"]
+    g = golden("bundled_site.npz")
+    key = f"T{T}_bs{bs}_spb{spb}_seed{seed}"
+    site, mod = eng.calculate_site_proba(p, b["off"], T, 20, THR, seed, bs, spb)
+    assert eng.last_pool_variant == "scan"
+    assert np.abs(site - g[key + "_site"]).max() <= SITE_ATOL
+    assert np.array_equal(mod, g[key + "_mod"])
+
+
+@pytest.mark.parametrize("T", [100, 1000])
+def test_pool_synthetic_golden(eng, golden, T):
+    g = golden("synthetic_small.npz")
+    for tag, variant in (("uniform20", "table"), ("ragged", "scan")):
+        site, mod = eng.calculate_site_proba(g[f"{tag}_readprob"], g[f"{tag}_off"], T, 20, THR)
+        assert eng.last_pool_variant == variant
+        assert np.abs(site - g[f"{tag}_site_T{T}"]).max() <= SITE_ATOL, tag
+        assert np.array_equal(mod, g[f"{tag}_mod"]), tag
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 19, 20, 21, 31, 32])
+@pytest.mark.parametrize("T", [1, 63, 64, 65, 200])
+def test_pool_uniform_table_vs_oracle(eng, orc, n, T):
+    S = 131
+    off = np.arange(S + 1, dtype=np.int64) * n
+    p = rand_probs(n * 1000 + T, off)
+    site, mod = eng.calculate_site_proba(p, off, T, 20, THR, seed=3)
+    assert eng.last_pool_variant == "table"
+    want_site, want_mod = orc.site_pool(p, off, T, THR, seed=3)
+    assert np.abs(site - want_site).max() <= SITE_ATOL
+    assert np.array_equal(mod, want_mod)
+
+
+@pytest.mark.parametrize("bags", [
+    [33] * 40, [64] * 35, [65] * 33, [1000] * 3, [1024, 1025, 1500, 20], [20, 21] * 30,
+    [1, 2, 1, 20, 1, 40], list(range(20, 84)), [2048, 20, 4097],
+])
+def test_pool_scan_vs_oracle(eng, orc, bags):
+    off = np.concatenate([[0], np.cumsum(bags)]).astype(np.int64)
+    p = rand_probs(len(bags), off)
+    for T in (7, 100):
+        site, mod = eng.calculate_site_proba(p, off, T, 20, THR, seed=11)
+        assert eng.last_pool_variant == "scan"
+        want_site, want_mod = orc.site_pool(p, off, T, THR, seed=11)
+        assert np.abs(site - want_site).max() <= SITE_ATOL
+        assert np.array_equal(mod, want_mod)
+
+
+@pytest.mark.parametrize("K", [1, 5, 19, 21, 64])
+def test_pool_other_sample_counts(eng, orc, K):
+    bags = [20, 25, 30, 100, 20, 33] * 6
+    off = np.concatenate([[0], np.cumsum(bags)]).astype(np.int64)
+    p = rand_probs(K, off)
+    site, mod = eng.calculate_site_proba(p, off, 50, K, THR, seed=5)
+    want_site, want_mod = orc.site_pool(p, off, 50, THR, seed=5, n_samples=K)
+    assert np.abs(site - want_site).max() <= SITE_ATOL
+    assert np.array_equal(mod, want_mod)
+
+
+@pytest.mark.parametrize("bs,spb", [(16, 2), (1, 2), (7, 3), (64, 2), (16, 1), (5, 5)])
+def test_pool_group_geometry(eng, orc, bs, spb):
+    S = 203
+    for n in (20, None):
+        bags = [20] * S if n else list(np.random.Generator(np.random.PCG64(S)).integers(20, 60, size=S))
+        off = np.concatenate([[0], np.cumsum(bags)]).astype(np.int64)
+        p = rand_probs(bs * 10 + spb, off)
+        site, mod = eng.calculate_site_proba(p, off, 30, 20, THR, seed=9, batch_size=bs, save_per_batch=spb)
+        want_site, _ = orc.site_pool(p, off, 30, THR, seed=9, batch_size=bs, save_per_batch=spb)
+        assert np.abs(site - want_site).max() <= SITE_ATOL, (bs, spb, n)
+
+
+def test_pool_seeds_differ_and_repeat(eng):
+    off = np.arange(101, dtype=np.int64) * 20
+    p = rand_probs(1, off)
+    a, _ = eng.calculate_site_proba(p, off, 100, seed=0)
+    b, _ = eng.calculate_site_proba(p, off, 100, seed=1)
+    c, _ = eng.calculate_site_proba(p, off, 100, seed=0)
+    assert np.array_equal(a, c)
+    assert not np.array_equal(a, b)
+
+
+def test_bad_arguments(eng):
+    from m6anet_amd._lib import M6AError
+    off = np.arange(3, dtype=np.int64) * 20
+    p = np.zeros(40, np.float32)
+    with pytest.raises(M6AError):
+        eng.calculate_site_proba(p, off, 0)
+    with pytest.raises(M6AError):
+        eng.calculate_site_proba(p, off, 10, n_samples=65)
+    with pytest.raises(M6AError):
+        eng.calculate_site_proba(p, off, 10, batch_size=0)
+    with pytest.raises(M6AError):
+        eng.calculate_site_proba(p, np.array([0, 30, 20], np.int64), 10)
+
+
+# ------------------------------------------------------------------ end to end -----------------
+def test_infer_end_to_end_vs_oracle(eng, orc, weights):
+    d = synthetic.make_sites(20000, 20, seed=99)
+    rp, site, mod = eng.infer(d["X"], d["site_kmers"], d["off"], 1000)
+    p = orc.encode_reads(weights["hct116"], d["X"], d["site_kmers"], d["off"], n_threads=8)
+    assert np.allclose(rp, p, rtol=1e-5, atol=1e-8)
+    want_site, want_mod = orc.site_pool(rp, d["off"], 1000, THR, n_threads=8)
+    assert np.abs(site - want_site).max() <= SITE_ATOL
+    assert np.array_equal(mod, want_mod)
+    # and against the oracle's own read probabilities: north_star's 1e-5
+    o_site, _ = orc.site_pool(p, d["off"], 1000, THR, n_threads=8)
+    assert np.abs(site - o_site).max() <= 1e-5
+
+
+def test_infer_ragged_end_to_end_vs_oracle(engines, orc, weights):
+    d = synthetic.make_sites(600, (50, 500), seed=5)
+    rp, site, mod = engines["hek293t_glori"].infer(d["X"], d["site_kmers"], d["off"], 1000)
+    p = orc.encode_reads(weights["hek293t_glori"], d["X"], d["site_kmers"], d["off"], n_threads=8)
+    assert np.allclose(rp, p, rtol=1e-5, atol=1e-8)
+    want_site, want_mod = orc.site_pool(rp, d["off"], 1000, THR, n_threads=8)
+    assert np.abs(site - want_site).max() <= SITE_ATOL
+    assert np.array_equal(mod, want_mod)
+
+
+def test_device_tensors_match_host_path(eng):
+    import torch
+    d = synthetic.make_sites(5000, 20, seed=3)
+    rp_h, site_h, mod_h = eng.infer(d["X"], d["site_kmers"], d["off"], 100)
+    dev = torch.device("cuda:0")
+    X = torch.from_numpy(d["X"]).to(dev)
+    km = torch.from_numpy(d["site_kmers"]).to(dev)
+    off = torch.from_numpy(d["off"]).to(dev)
+    eng.use_torch_stream()
+    try:
+        rp_d, site_d, mod_d = eng.infer(X, km, off, 100)
+        eng.sync()
+        assert np.array_equal(rp_d.cpu().numpy(), rp_h)
+        assert np.array_equal(site_d.cpu().numpy(), site_h)
+        assert np.array_equal(mod_d.cpu().numpy(), mod_h)
+        _, site_n, _ = eng.infer(X, km, off, 100, want_read_probs=False)
+        eng.sync()
+        assert np.array_equal(site_n.cpu().numpy(), site_h)
+    finally:
+        eng.set_stream(None)
+
+
+# ------------------------------------------------------------------ full size ------------------
+def test_full_size_properties(eng, orc, weights):
+    """BASELINE.json configs[2] size (1M sites x 20 reads, T=1000): size-independent checks.
+    Flush groups are independent, so the oracle can check randomly chosen groups exactly."""
+    import torch
+    S, T = 1_000_000, 1000
+    d = synthetic.make_sites(S, 20, seed=20250328)
+    dev = torch.device("cuda:0")
+    X = torch.from_numpy(d["X"]).to(dev)
+    km = torch.from_numpy(d["site_kmers"]).to(dev)
+    off = torch.from_numpy(d["off"]).to(dev)
+    eng.use_torch_stream()
+    try:
+        rp, site, mod = eng.infer(X, km, off, T)
+        eng.sync()
+        rp2, site2, mod2 = eng.infer(X, km, off, T)
+        eng.sync()
+    finally:
+        eng.set_stream(None)
+    rp, site, mod = rp.cpu().numpy(), site.cpu().numpy(), mod.cpu().numpy()
+    # determinism
+    assert np.array_equal(site, site2.cpu().numpy()) and np.array_equal(rp, rp2.cpu().numpy())
+    assert np.all(np.isfinite(site)) and site.min() >= 0 and site.max() <= 1
+    # exact oracle check on a sample of flush groups (group g>=1 = sites 16+32(g-1) .. +32)
+    g = np.random.Generator(np.random.PCG64(1))
+    for grp in [0, 1, 2] + list(g.integers(3, (S - 16) // 32, size=40)):
+        a, b = (0, 16) if grp == 0 else (16 + 32 * (grp - 1), 16 + 32 * grp)
+        sl = slice(a * 20, b * 20)
+        p = orc.encode_reads(weights["hct116"], d["X"][sl], d["site_kmers"][a:b], d["off"][a:b + 1] - a * 20)
+        assert np.allclose(rp[sl], p, rtol=1e-5, atol=1e-8)
+        # a group replayed alone (batch_size = its size, so it is one flush group) sees the same stream
+        w_site, w_mod = orc.site_pool(rp[sl], d["off"][a:b + 1] - a * 20, T, THR, batch_size=b - a, save_per_batch=2)
+        assert np.abs(site[a:b] - w_site).max() <= SITE_ATOL
+        assert np.array_equal(mod[a:b], w_mod)
+    # Monte-Carlo mean vs the closed form E = 1 - mean_i(1-p_i)... per site: 1 - (mean(1-p))^20
+    q = (1.0 - rp.astype(np.float64)).reshape(S, 20).mean(axis=1)
+    closed = 1.0 - q ** 20
+    assert np.abs(site - closed).mean() < 0.01
+    # last site is written (the reference would drop the final batch when #batches is even)
+    assert site[-1] > 0
