@@ -26,6 +26,22 @@ class M6AError(RuntimeError):
         self.code = code
 
 
+def _preload_hip_runtime():
+    """One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64.so.7 and refuses to
+    see the GPU if another copy (e.g. /opt/rocm's) was mapped first.  When torch is installed,
+    map ITS runtime before libm6a_hip.so so both bind to the same one, whichever is imported
+    first.  (torch itself is not imported here.)"""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec and spec.submodule_search_locations:
+        rt = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(rt):
+            C.CDLL(rt, mode=C.RTLD_GLOBAL)
+
+
 def load():
     """Loads the in-tree HIP library.  Raises if it has not been built (python -m m6anet_amd.build)."""
     global _lib
@@ -34,6 +50,7 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise ImportError("libm6a_hip.so is not built: run `python -m m6anet_amd.build` "
                           "(or __graft_entry__.build()); there is no CPU fallback")
+    _preload_hip_runtime()
     L = C.CDLL(LIB_PATH)
     vp, i64, i32, u32, f32, sz = C.c_void_p, C.c_int64, C.c_int, C.c_uint32, C.c_float, C.c_size_t
     L.m6a_create.argtypes = [C.POINTER(vp), vp, sz, i32]
