@@ -62,6 +62,7 @@ struct m6a_ctx {
     struct { uint32_t seed; int n, T, K, jmax; bool valid; } tab_key = {0, 0, 0, 0, 0, false};
     struct { int64_t S, bs, spb, base, G, gmax; bool valid; } goff_key = {0, 0, 0, 0, 0, 0, false};
     int64_t job_offset = 0;
+    int64_t bag_min = 0, bag_max = 0, n_reads = 0;   // last query_bags()
     int *d_err = nullptr;
     unsigned long long *d_minmax = nullptr;
     unsigned long long *h_minmax = nullptr;   // pinned
@@ -256,6 +257,23 @@ void prof_end(m6a_ctx *c, int kind)
     p.used[kind]++;
 }
 
+// bag-size range (decides the pooling kernel) and total reads: one 24-byte read-back, which
+// blocks on the stream
+int query_bags(m6a_ctx *c, const int64_t *d_off, int64_t S)
+{
+    c->h_minmax[0] = ~0ull; c->h_minmax[1] = 0ull; c->h_minmax[2] = 0ull;
+    HIPCHK(c, hipMemcpyAsync(c->d_minmax, c->h_minmax, 24, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(bag_minmax_kernel, dim3((unsigned)std::min<int64_t>((S + 255) / 256, 512)), dim3(256), 0,
+                       c->stream, d_off, S, c->d_minmax);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(c->h_minmax, c->d_minmax, 24, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->bag_min = (int64_t)c->h_minmax[0];
+    c->bag_max = (int64_t)c->h_minmax[1];
+    c->n_reads = (int64_t)c->h_minmax[2];
+    return M6A_OK;
+}
+
 // ---- launches (all pointers are device pointers here) ------------------------------------------
 int launch_encode(m6a_ctx *c, const float *X, const uint8_t *km, const int64_t *off, int64_t S,
                   int64_t R, float *rp)
@@ -281,15 +299,7 @@ int launch_pool(m6a_ctx *c, const float *rp, const int64_t *off, int64_t S, int 
     if (S <= 0) return M6A_OK;
     int rc = ensure_groups(c, S, bs, spb);
     if (rc) return rc;
-    // bag-size range decides the kernel: one 16-byte read-back (blocks on the stream)
-    c->h_minmax[0] = ~0ull; c->h_minmax[1] = 0ull;
-    HIPCHK(c, hipMemcpyAsync(c->d_minmax, c->h_minmax, 16, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(bag_minmax_kernel, dim3((unsigned)std::min<int64_t>((S + 255) / 256, 1024)), dim3(256), 0,
-                       c->stream, off, S, c->d_minmax);
-    HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(c->h_minmax, c->d_minmax, 16, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    const int64_t nmin = (int64_t)c->h_minmax[0], nmax = (int64_t)c->h_minmax[1];
+    const int64_t nmin = c->bag_min, nmax = c->bag_max;      // from query_bags()
     if (nmin < 0 || nmax > 0x7fffffff) return fail(c, M6A_EINVAL, "off[] is not a non-decreasing CSR array");
 
     PoolArgs a;
@@ -302,8 +312,11 @@ int launch_pool(m6a_ctx *c, const float *rp, const int64_t *off, int64_t S, int 
         rc = ensure_table(c, seed, (int)nmin, T, K, (int)gmax);
         if (rc) return rc;
         a.tab = (const uint32_t *)c->tab.p; a.uniform_n = (int)nmin; a.jmax = (int)gmax;
-        const int64_t items = ((a.n_groups + 7) / 8) * a.jmax;
-        const unsigned blocks = (unsigned)std::min<int64_t>((items + 3) / 4, (int64_t)c->n_cu * 8);
+        // workgroups are bound to a position j: jmax x nbj of them, 5 resident per CU (LDS)
+        const int64_t gblocks = (a.n_groups + 7) / 8;
+        int64_t nbj = std::max<int64_t>(1, ((int64_t)c->n_cu * 5 + a.jmax - 1) / a.jmax);
+        nbj = std::min<int64_t>(nbj, (gblocks + 3) / 4);
+        const unsigned blocks = (unsigned)(nbj * a.jmax);
         c->pool_variant = "table";
         prof_begin(c, 1);
         hipLaunchKernelGGL(pool_table_kernel, dim3(blocks), dim3(256), 0, c->stream, a);
@@ -325,6 +338,13 @@ int launch_pool(m6a_ctx *c, const float *rp, const int64_t *off, int64_t S, int 
     }
     HIPCHK(c, hipGetLastError());
     return M6A_OK;
+}
+
+void host_bag_range(m6a_ctx *c, const int64_t *off, int64_t S)
+{
+    int64_t mn = INT64_MAX, mx = 0;
+    for (int64_t s = 0; s < S; s++) { const int64_t n = off[s + 1] - off[s]; mn = std::min(mn, n); mx = std::max(mx, n); }
+    c->bag_min = mn; c->bag_max = mx; c->n_reads = off[S];
 }
 
 int check_pool_args(m6a_ctx *c, int64_t S, int T, int K, int rng_mode, int64_t bs, int64_t spb)
@@ -411,8 +431,8 @@ int m6a_create(m6a_ctx **out, const float *weights, size_t n_floats, int device_
     c->b3 = weights[O_B3];
     CRCHK(hipMalloc((void **)&c->d_err, sizeof(int)));
     CRCHK(hipMemset(c->d_err, 0, sizeof(int)));
-    CRCHK(hipMalloc((void **)&c->d_minmax, 16));
-    CRCHK(hipHostMalloc((void **)&c->h_minmax, 16, hipHostMallocDefault));
+    CRCHK(hipMalloc((void **)&c->d_minmax, 24));
+    CRCHK(hipHostMalloc((void **)&c->h_minmax, 24, hipHostMallocDefault));
     CRCHK(hipHostMalloc((void **)&c->h_err, sizeof(int), hipHostMallocDefault));
     *c->h_err = 0;
 #undef CRCHK
@@ -509,7 +529,11 @@ int m6a_site_pool(m6a_ctx *c, const float *rp, const int64_t *off, int64_t S, in
     const bool dev = is_device_ptr(rp);
     if (dev != is_device_ptr(off) || dev != is_device_ptr(site) || dev != is_device_ptr(mod))
         return fail(c, M6A_EINVAL, "read_prob, off, site_prob, mod_ratio must be all host or all device pointers");
-    if (dev) return launch_pool(c, rp, off, S, T, K, thr, seed, bs, spb, site, mod);
+    if (dev) {
+        rc = query_bags(c, off, S);
+        if (rc) return rc;
+        return launch_pool(c, rp, off, S, T, K, thr, seed, bs, spb, site, mod);
+    }
     if (off[0] != 0) return fail(c, M6A_EINVAL, "off[0] must be 0");
     for (int64_t s = 0; s < S; s++) if (off[s + 1] < off[s]) return fail(c, M6A_EINVAL, "off[] must be non-decreasing");
     const int64_t R = off[S];
@@ -519,6 +543,7 @@ int m6a_site_pool(m6a_ctx *c, const float *rp, const int64_t *off, int64_t S, in
     HIPCHK(c, c->sMod.ensure((size_t)S * 8));
     HIPCHK(c, hipMemcpyAsync(c->sP.p, rp, (size_t)R * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->sOff.p, off, (size_t)(S + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    host_bag_range(c, off, S);
     rc = launch_pool(c, (const float *)c->sP.p, (const int64_t *)c->sOff.p, S, T, K, thr, seed, bs, spb,
                      (float *)c->sSite.p, (double *)c->sMod.p);
     if (rc) return rc;
@@ -540,9 +565,9 @@ int m6a_infer(m6a_ctx *c, const float *X, const uint8_t *km, const int64_t *off,
         dev != is_device_ptr(mod) || (rp && dev != is_device_ptr(rp)))
         return fail(c, M6A_EINVAL, "all data pointers must be host pointers or all device pointers");
     if (dev) {
-        int64_t R = 0;
-        HIPCHK(c, hipMemcpyAsync(&R, off + S, 8, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        rc = query_bags(c, off, S);
+        if (rc) return rc;
+        const int64_t R = c->n_reads;
         float *p = rp;
         if (!p) { HIPCHK(c, c->rp_scratch.ensure((size_t)std::max<int64_t>(R, 1) * 4)); p = (float *)c->rp_scratch.p; }
         rc = launch_encode(c, X, km, off, S, R, p);
@@ -563,6 +588,7 @@ int m6a_infer(m6a_ctx *c, const float *X, const uint8_t *km, const int64_t *off,
     HIPCHK(c, hipMemcpyAsync(c->sOff.p, off, (size_t)(S + 1) * 8, hipMemcpyHostToDevice, c->stream));
     rc = launch_encode(c, (const float *)c->sX.p, (const uint8_t *)c->sK.p, (const int64_t *)c->sOff.p, S, R, (float *)c->sP.p);
     if (rc) return rc;
+    host_bag_range(c, off, S);
     rc = launch_pool(c, (const float *)c->sP.p, (const int64_t *)c->sOff.p, S, T, K, thr, seed, bs, spb,
                      (float *)c->sSite.p, (double *)c->sMod.p);
     if (rc) return rc;

@@ -32,6 +32,15 @@ __device__ __forceinline__ int wave_sum_i32(int v)
     return v;
 }
 
+// ReLU as one integer max: negative floats (and -0.0) have the sign bit set, i.e. are negative
+// as int32, so max(bits, 0) zeroes them and leaves positive values untouched.  fmaxf() costs two
+// VALU ops here (a canonicalising v_max first), and the encoder issues 96 of them per tile.
+__device__ __forceinline__ float relu_bits(float x)
+{
+    const int b = __builtin_bit_cast(int, x);
+    return __builtin_bit_cast(float, b > 0 ? b : 0);
+}
+
 // Orders this wave's LDS traffic: LDS ops of one wave execute in issue order, so a compiler
 // fence (no s_barrier) is all a single-wave producer/consumer needs.
 __device__ __forceinline__ void wave_lds_fence()
@@ -58,6 +67,17 @@ __device__ __forceinline__ void wave_lds_fence()
 //   1.0 and carries b2 through W2aug[:,150]; units 151..159 are zero padding.
 // Lane halves load different features: h=0 lanes x0..x7, h=1 lanes x8, e0..e5, 1.
 // =====================================================================================
+// Input pipeline: the features of tile t+1 are fetched while tile t is on the matrix pipe.  The
+// site lookup is a dependent chain (CSR offsets -> k-mer ids -> embedding rows); its three links
+// are issued between the five 24-MFMA groups of the current tile, so no link ever waits in front
+// of an MFMA.  A 32-read tile that starts in site `a` normally ends by site a+2 (bags >= 16
+// reads); off[a+1..a+3] are fetched up front (wave-uniform) and lanes pick their site by
+// comparison.  Smaller bags take the (rare) per-lane walk.
+struct EncTile {
+    float f[8];        // this lane's 8 B-operand features of the tile
+    int64_t s_last;    // site of the tile's last read (wave-uniform)
+};
+
 __global__ __launch_bounds__(256, 2) void enc_kernel(EncArgs a)
 {
     __shared__ float s_emb[132];
@@ -81,8 +101,8 @@ __global__ __launch_bounds__(256, 2) void enc_kernel(EncArgs a)
 #pragma unroll
     for (int i = 0; i < 16; i++) w3[i] = a.wfrag[(120 + i) * 64 + lane];
 
-    // site cursor for the wave's first read: largest s with off[s] <= r (upper_bound - 1)
-    int64_t s_cur;
+    // site of the wave's first read: largest s with off[s] <= r (upper_bound - 1)
+    int64_t s_base;
     {
         const int64_t r = tile0 * 32;
         int64_t lo = 0, hi = a.n_sites;          // invariant: off[lo] <= r < off[hi]
@@ -90,55 +110,114 @@ __global__ __launch_bounds__(256, 2) void enc_kernel(EncArgs a)
             int64_t mid = (lo + hi) >> 1;
             if (a.off[mid] <= r) lo = mid; else hi = mid;
         }
-        s_cur = lo;
+        s_base = lo;
+    }
+    const int64_t last_site = a.n_sites - 1;
+
+    // ---- the three links of the input chain for one tile -------------------------------------
+    // link 0: issue the x loads and the three CSR offsets after the base site
+    auto link0 = [&](int64_t tile, int64_t base, float (&x)[8], int64_t (&o)[3], int64_t &rc) {
+        const int64_t r = tile * 32 + col;
+        rc = r < a.n_reads ? r : a.n_reads - 1;
+        const float *xp = a.X + rc * 9;
+        if (half == 0) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) x[i] = xp[i];
+        } else {
+            x[0] = xp[8];
+        }
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            const int64_t si = base + 1 + i;
+            o[i] = a.off[si <= a.n_sites ? si : a.n_sites];
+        }
+    };
+    // link 1: pick the lane's site, issue its k-mer id loads
+    auto link1 = [&](int64_t base, const int64_t (&o)[3], int64_t rc, int64_t &s, int (&km)[3]) {
+        s = base + (rc >= o[0] ? 1 : 0) + (rc >= o[1] ? 1 : 0);
+        if (__any(rc >= o[2])) {                 // bags smaller than 16 reads: walk
+            s = base;
+            while (a.off[s + 1] <= rc) ++s;
+        }
+        s = s < last_site ? s : last_site;
+        const uint8_t *kp = a.site_kmers + s * 3;
+        km[0] = kp[0]; km[1] = kp[1]; km[2] = kp[2];
+    };
+    // link 2: embedding rows from LDS
+    auto link2 = [&](const int (&km)[3], float (&x)[8]) {
+        if (half == 1) {
+            x[1] = s_emb[2 * km[0]]; x[2] = s_emb[2 * km[0] + 1];
+            x[3] = s_emb[2 * km[1]]; x[4] = s_emb[2 * km[1] + 1];
+            x[5] = s_emb[2 * km[2]]; x[6] = s_emb[2 * km[2] + 1];
+            x[7] = 1.0f;
+        }
+    };
+
+    // prologue: first tile, unpipelined
+    float f[8];
+    {
+        int64_t o[3], rc, s;
+        int km[3];
+        link0(tile0, s_base, f, o, rc);
+        link1(s_base, o, rc, s, km);
+        link2(km, f);
+        s_base = __shfl(s, 31, 64);
     }
 
     for (int64_t tile = tile0; tile < tile1; ++tile) {
-        const int64_t r = tile * 32 + col;
-        const int64_t rc = r < a.n_reads ? r : a.n_reads - 1;
-        float f[8];
-        // every lane walks the cursor (cheap, keeps it wave-uniform for the next tile)
-        int64_t s = s_cur;
-        while (a.off[s + 1] <= rc) ++s;
-        s_cur = __shfl(s, 31, 64);   // site of the tile's last read; next tile starts there
-        if (half == 0) {
-            const float *x = a.X + rc * 9;
+        const bool more = tile + 1 < tile1;        // wave-uniform
+        float fn[8];
+        int64_t o[3], rcn = 0, sn = 0;
+        int km[3] = {0, 0, 0};
 #pragma unroll
-            for (int i = 0; i < 8; i++) f[i] = x[i];
-        } else {
-            f[0] = a.X[rc * 9 + 8];
-            const uint8_t *km = a.site_kmers + s * 3;
-            const int k0 = km[0], k1 = km[1], k2 = km[2];
-            f[1] = s_emb[2 * k0]; f[2] = s_emb[2 * k0 + 1];
-            f[3] = s_emb[2 * k1]; f[4] = s_emb[2 * k1 + 1];
-            f[5] = s_emb[2 * k2]; f[6] = s_emb[2 * k2 + 1];
-            f[7] = 1.0f;
-        }
+        for (int i = 0; i < 8; i++) fn[i] = 0.0f;
+        if (more) link0(tile + 1, s_base, fn, o, rcn);
 
-        f32x16 acc2;
+        // Layer 1 of unit-tile m+1 is issued ahead of layer 2 of unit-tile m (ping-pong
+        // accumulators).  ReLU is applied to a finished tile as one batch of 16 v_max_i32 and
+        // the 16 layer-2 MFMAs that consume it then issue back to back: a VALU op wedged between
+        // two MFMAs on the same accumulator costs ~6% of the matrix pipe (tools/mfma_chain_bench).
+        f32x16 acc2, h1a, h1b;
 #pragma unroll
-        for (int q = 0; q < 16; q++) acc2[q] = 0.0f;
+        for (int q = 0; q < 16; q++) { acc2[q] = 0.0f; h1a[q] = 0.0f; }
+#pragma unroll
+        for (int st = 0; st < 8; st++)
+            h1a = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[st], f[st], h1a, 0, 0, 0);
 #pragma unroll
         for (int m = 0; m < 5; m++) {
-            f32x16 acc1;
+            f32x16 &cur = (m & 1) ? h1b : h1a;
+            f32x16 &nxt = (m & 1) ? h1a : h1b;
+            if (m < 4) {
 #pragma unroll
-            for (int q = 0; q < 16; q++) acc1[q] = 0.0f;
+                for (int q = 0; q < 16; q++) nxt[q] = 0.0f;
 #pragma unroll
-            for (int st = 0; st < 8; st++)
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[m * 8 + st], f[st], acc1, 0, 0, 0);
-#pragma unroll
-            for (int q = 0; q < 16; q++) {
-                const float hq = fmaxf(acc1[q], 0.0f);
-                acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(w2[m * 16 + q], hq, acc2, 0, 0, 0);
+                for (int st = 0; st < 8; st++)
+                    nxt = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[(m + 1) * 8 + st], f[st], nxt, 0, 0, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);
+            if (m == 1 && more) link1(s_base, o, rcn, sn, km);
+            if (m == 3 && more) link2(km, fn);
+#pragma unroll
+            for (int q = 0; q < 16; q++) cur[q] = relu_bits(cur[q]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 16; q++)
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(w2[m * 16 + q], cur[q], acc2, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         float z = 0.0f;
 #pragma unroll
-        for (int q = 0; q < 16; q++) z = fmaf(fmaxf(acc2[q], 0.0f), w3[q], z);
+        for (int q = 0; q < 16; q++) z = fmaf(relu_bits(acc2[q]), w3[q], z);
         z += __shfl_xor(z, 32, 64);
         z += a.b3;
         const float p = 1.0f / (1.0f + expf(-z));
+        const int64_t r = tile * 32 + col;
         if (half == 0 && r < a.n_reads) a.read_prob[r] = p;
+        if (more) {
+            s_base = __shfl(sn, 31, 64);
+#pragma unroll
+            for (int i = 0; i < 8; i++) f[i] = fn[i];
+        }
     }
 }
 
@@ -278,86 +357,116 @@ template __global__ void pool_scan_kernel<0>(PoolArgs);
 // Same arithmetic as pool_scan_kernel; because every site consumes the stream identically,
 // the accepted indices of "the j-th site of a flush group" are the same in every group:
 // tab[j][round][plane][lane] packs, for iteration t = 64*round + lane, byte offsets 8*idx of
-// its 20 draws (5 dwords).  One wavefront takes position j of 8 consecutive groups: the 8
-// bags sit in LDS as 4 arrays of float2 (two sites per 8-byte entry, 160 B per array, one
-// array per 256 B bank row), so each ds_read_b64 gathers for two sites, conflict-free, and
-// one v_pk_mul_f32 advances both products.
+// its 20 draws (5 dwords).
+//
+// A workgroup is bound to one position j (blockIdx % jmax -- with the observed block -> XCD
+// round-robin each XCD's L2 then serves only jmax/8 rows) and keeps a 16-round chunk of row j
+// in LDS (20 KB; the whole row when T <= 1024).  Each wavefront takes position j of 8
+// consecutive groups: the 8 bags sit in LDS as 4 arrays of float2 (two sites per 8-byte entry,
+// 160 B per array, each array inside one 256 B bank row), so every ds_read_b64 gathers for two
+// sites, conflict-free, and v_pk_mul_f32 advances both products.  Inner loop = LDS + VALU only.
 // =====================================================================================
-__global__ __launch_bounds__(256) void pool_table_kernel(PoolArgs a)
+#define M6A_TAB_RC 16                       // rounds per LDS chunk
+__global__ __launch_bounds__(256, 6) void pool_table_kernel(PoolArgs a)
 {
-    __shared__ __attribute__((aligned(16))) float s_bag[4][4 * 64];   // [wave][pair*64 + 2*i + e]
+    __shared__ __attribute__((aligned(16))) uint32_t s_idx[M6A_TAB_RC * 5 * 64];
+    // bag arrays: pair p of wave w lives at byte p*2112 + w*256 (+ 8*idx + 4*e).  The odd 2112 B
+    // pair stride is deliberate: no difference of two pair bases fits ds_read2_b64's offset field
+    // (<= 2040 B) or is a multiple of ds_read2st64_b64's 512 B unit, so the four gathers of one
+    // draw stay four ds_read_b64 (256 B/clk, 64-bank addressing: the 20 entries of a bag never
+    // collide).  Fused into ds_read2_b64 they run at half rate and bank modulo 32 dwords, where
+    // entries i and i+16 collide -- measured 2.4 conflict cycles per gather.
+    __shared__ __attribute__((aligned(256))) float s_bag[4 * 528];
     const int lane = threadIdx.x & 63;
     const int wib = threadIdx.x >> 6;
-    float *bag = s_bag[wib];
+    float *bag = s_bag + wib * 64;             // + pair * 528 floats
+    const char *bagb = (const char *)bag;
     const int n = a.uniform_n;
     const int rounds = (a.T + 63) >> 6;
+    const int n_chunks = (rounds + M6A_TAB_RC - 1) / M6A_TAB_RC;
+    const int j = (int)(blockIdx.x % (unsigned)a.jmax);
+    const int64_t c = blockIdx.x / (unsigned)a.jmax;
+    const int64_t nbj = gridDim.x / (unsigned)a.jmax;          // workgroups per position
     const int64_t gblocks = (a.n_groups + 7) >> 3;
-    const int64_t n_items = gblocks * a.jmax;
-    const int64_t n_waves = (int64_t)gridDim.x * 4;
+    const int64_t stride = nbj * 4;
+    const int64_t n_iter = (gblocks + stride - 1) / stride;
+    const uint32_t *row = a.tab + (int64_t)j * rounds * 5 * 64;
 
-    for (int64_t item = (int64_t)blockIdx.x * 4 + wib; item < n_items; item += n_waves) {
-        const int j = (int)(item % a.jmax);
-        const int64_t g0 = (item / a.jmax) * 8;
+    if (n_chunks == 1) {
+        for (int i = threadIdx.x; i < rounds * 5 * 64; i += 256) s_idx[i] = row[i];
+        __syncthreads();
+    }
+    for (int64_t it = 0; it < n_iter; ++it) {
+        const int64_t gb = c * 4 + wib + it * stride;
+        const bool active = gb < gblocks;
         int64_t site[8];
-#pragma unroll
-        for (int q = 0; q < 8; q++) {
-            const int64_t g = g0 + q;
-            site[q] = -1;
-            if (g < a.n_groups) {
-                const int64_t s = a.goff[g] + j;
-                if (s < a.goff[g + 1]) site[q] = s;
-            }
-        }
-        // bags + mod_ratio
-#pragma unroll
-        for (int q = 0; q < 8; q++) {
-            float v = 0.0f;
-            bool ge = false;
-            if (site[q] >= 0 && lane < n) {
-                v = a.read_prob[a.off[site[q]] + lane];
-                ge = v >= a.thr;
-            }
-            const int cge = __popcll(__ballot(ge));
-            if (lane < 32) bag[(q >> 1) * 64 + 2 * lane + (q & 1)] = 1.0f - v;
-            if (lane == 0 && site[q] >= 0) a.mod_ratio[site[q]] = (double)cge / (double)n;
-        }
-        wave_lds_fence();
-
         float sum[8];
 #pragma unroll
-        for (int q = 0; q < 8; q++) sum[q] = 0.0f;
-        const uint32_t *tj = a.tab + (int64_t)j * rounds * 5 * 64 + lane;
-        const char *bagb = (const char *)bag;
-        for (int rd = 0; rd < rounds; ++rd) {
-            uint32_t ix[5];
+        for (int q = 0; q < 8; q++) { site[q] = -1; sum[q] = 0.0f; }
+        if (active) {
 #pragma unroll
-            for (int pl = 0; pl < 5; pl++) ix[pl] = tj[(rd * 5 + pl) * 64];
-            float2 prod[4];
+            for (int q = 0; q < 8; q++) {
+                const int64_t g = gb * 8 + q;
+                if (g < a.n_groups) {
+                    const int64_t s = a.goff[g] + j;
+                    if (s < a.goff[g + 1]) site[q] = s;
+                }
+                float v = 0.0f;
+                bool ge = false;
+                if (site[q] >= 0 && lane < n) {
+                    v = a.read_prob[a.off[site[q]] + lane];
+                    ge = v >= a.thr;
+                }
+                const int cge = __popcll(__ballot(ge));
+                if (lane < 32) bag[(q >> 1) * 528 + 2 * lane + (q & 1)] = 1.0f - v;
+                if (lane == 0 && site[q] >= 0) a.mod_ratio[site[q]] = (double)cge / (double)n;
+            }
+            wave_lds_fence();
+        }
+        for (int ch = 0; ch < n_chunks; ++ch) {
+            const int rd0 = ch * M6A_TAB_RC;
+            const int nr = rounds - rd0 < M6A_TAB_RC ? rounds - rd0 : M6A_TAB_RC;
+            if (n_chunks > 1) {
+                __syncthreads();
+                for (int i = threadIdx.x; i < nr * 5 * 64; i += 256) s_idx[i] = row[rd0 * 5 * 64 + i];
+                __syncthreads();
+            }
+            if (!active) continue;
+            for (int rd = 0; rd < nr; ++rd) {
+                float2 prod[4];
 #pragma unroll
-            for (int pr = 0; pr < 4; pr++) prod[pr] = make_float2(1.0f, 1.0f);
+                for (int pr = 0; pr < 4; pr++) prod[pr] = make_float2(1.0f, 1.0f);
+                const uint32_t *ixp = s_idx + rd * 5 * 64 + lane;
+#pragma unroll 1
+                for (int pl = 0; pl < 5; pl++) {
+                    const uint32_t ixw = ixp[pl * 64];
 #pragma unroll
-            for (int k = 0; k < 20; k++) {
-                const uint32_t o = (ix[k >> 2] >> (8 * (k & 3))) & 0xffu;
+                    for (int bb = 0; bb < 4; bb++) {
+                        const uint32_t o = (ixw >> (8 * bb)) & 0xffu;
+#pragma unroll
+                        for (int pr = 0; pr < 4; pr++) {
+                            const float2 v = *(const float2 *)(bagb + pr * 2112 + o);
+                            prod[pr].x *= v.x;
+                            prod[pr].y *= v.y;
+                        }
+                    }
+                }
+                const bool live = (rd0 + rd) * 64 + lane < a.T;
 #pragma unroll
                 for (int pr = 0; pr < 4; pr++) {
-                    const float2 v = *(const float2 *)(bagb + pr * 256 + o);
-                    prod[pr].x *= v.x;
-                    prod[pr].y *= v.y;
+                    sum[2 * pr] += live ? 1.0f - prod[pr].x : 0.0f;
+                    sum[2 * pr + 1] += live ? 1.0f - prod[pr].y : 0.0f;
                 }
             }
-            const bool live = rd * 64 + lane < a.T;
+        }
+        if (active) {
 #pragma unroll
-            for (int pr = 0; pr < 4; pr++) {
-                sum[2 * pr] += live ? 1.0f - prod[pr].x : 0.0f;
-                sum[2 * pr + 1] += live ? 1.0f - prod[pr].y : 0.0f;
+            for (int q = 0; q < 8; q++) {
+                const float tot = wave_sum_f32(sum[q]);
+                if (lane == 0 && site[q] >= 0) a.site_prob[site[q]] = tot / (float)a.T;
             }
+            wave_lds_fence();
         }
-#pragma unroll
-        for (int q = 0; q < 8; q++) {
-            const float tot = wave_sum_f32(sum[q]);
-            if (lane == 0 && site[q] >= 0) a.site_prob[site[q]] = tot / (float)a.T;
-        }
-        wave_lds_fence();
     }
 }
 
@@ -377,9 +486,11 @@ __global__ void iota_off_kernel(int64_t *off, int64_t n_plus_1, int64_t step)
     if (i < n_plus_1) off[i] = i * step;
 }
 
-// min / max bag size over all sites -> out[0], out[1] (initialised by the host to INT64_MAX, 0)
-__global__ void bag_minmax_kernel(const int64_t *off, int64_t n_sites, unsigned long long *out)
+// min / max bag size over all sites -> out[0], out[1] (initialised by the host to UINT64_MAX, 0);
+// out[2] = off[n_sites] (total reads).  One atomic pair per workgroup.
+__global__ __launch_bounds__(256) void bag_minmax_kernel(const int64_t *off, int64_t n_sites, unsigned long long *out)
 {
+    __shared__ int64_t s_mn[4], s_mx[4];
     int64_t mn = INT64_MAX, mx = 0;
     for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < n_sites;
          s += (int64_t)gridDim.x * blockDim.x) {
@@ -393,8 +504,12 @@ __global__ void bag_minmax_kernel(const int64_t *off, int64_t n_sites, unsigned 
         mn = omn < mn ? omn : mn;
         mx = omx > mx ? omx : mx;
     }
-    if ((threadIdx.x & 63) == 0) {
+    if ((threadIdx.x & 63) == 0) { s_mn[threadIdx.x >> 6] = mn; s_mx[threadIdx.x >> 6] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; w++) { mn = s_mn[w] < mn ? s_mn[w] : mn; mx = s_mx[w] > mx ? s_mx[w] : mx; }
         atomicMin(&out[0], (unsigned long long)mn);
         atomicMax(&out[1], (unsigned long long)mx);
+        if (blockIdx.x == 0) out[2] = (unsigned long long)off[n_sites];
     }
 }

@@ -253,6 +253,7 @@ int64_t m6a_or_flush_groups(int64_t n_sites, int64_t batch_size, int64_t save_pe
 typedef struct {
     const float *p; const int64_t *off; const int64_t *goff; int64_t n_groups;
     int n_iters, n_samples; uint32_t seed; float *site; int64_t *next; pthread_mutex_t *mu;
+    int64_t chunk;
 } pool_job;
 
 static void *pool_worker(void *arg)
@@ -263,10 +264,10 @@ static void *pool_worker(void *arg)
     for (;;) {
         pthread_mutex_lock(j->mu);
         int64_t g0 = *j->next;
-        *j->next = g0 + 64;
+        *j->next = g0 + j->chunk;
         pthread_mutex_unlock(j->mu);
         if (g0 >= j->n_groups) break;
-        int64_t g1 = g0 + 64 < j->n_groups ? g0 + 64 : j->n_groups;
+        int64_t g1 = g0 + j->chunk < j->n_groups ? g0 + j->chunk : j->n_groups;
         for (int64_t g = g0; g < g1; g++) {
             /* every flush group's Pool worker starts from the parent's never-advanced state
              * (inference_utils.py:102-104 forks after inference.py:86 seeded): reseed. */
@@ -292,7 +293,10 @@ int m6a_or_site_pool(const float *read_prob, const int64_t *off, int64_t n_sites
     int64_t G = m6a_or_flush_groups(n_sites, batch_size, save_per_batch, goff);
     int64_t next = 0;
     pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER;
-    pool_job job = { read_prob, off, goff, G, n_iters, n_samples, seed, site_prob, &next, &mu };
+    int64_t chunk = G / ((int64_t)(n_threads > 0 ? n_threads : 1) * 16);
+    if (chunk < 1) chunk = 1;
+    if (chunk > 64) chunk = 64;
+    pool_job job = { read_prob, off, goff, G, n_iters, n_samples, seed, site_prob, &next, &mu, chunk };
     if (n_threads <= 1) {
         pool_worker(&job);
     } else {
