@@ -28,6 +28,21 @@ PEAK_F32_TFLOPS = 157.3        # MI355X_MICROARCH.md: f32 MFMA = f32 vector peak
 PEAK_HBM_GBPS = 8000.0
 
 
+def measured_traffic(S, n):
+    """HBM bytes per enc_kernel launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE, separate runs; profiles/*_enc_traffic.json), when they were taken on this workload."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(REPO, "profiles", "*_enc_traffic.json"))):
+        try:
+            d = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        if d.get("workload") == {"sites": S, "reads_per_site": n}:
+            best = d
+    return best
+
+
 def cpu_baseline(d, T, thr, weights, budget_s=15.0):
     """The oracle (a port of the reference's algorithm) on this host's cores, bounded sample."""
     from oracle import m6a_oracle as orc
@@ -66,7 +81,7 @@ def main():
     args = ap.parse_args()
 
     import torch
-    from m6anet_amd import synthetic
+    from m6anet_amd import dist as mdist, synthetic
     from m6anet_amd.constants import DEFAULT_READ_THRESHOLD
     from m6anet_amd.engine import M6ANetEngine, load_weights, shard_plan
 
@@ -103,22 +118,12 @@ def main():
     rp = torch.empty(R, dtype=torch.float32, device=dev)
     site = torch.empty(Sr, dtype=torch.float32, device=dev)
     mod = torch.empty(Sr, dtype=torch.float64, device=dev)
-    gather_site = gather_mod = None
-    if world > 1:
-        smax = int(max(np.diff(cuts)))
-        pad_site = torch.zeros(smax, dtype=torch.float32, device=dev)
-        pad_mod = torch.zeros(smax, dtype=torch.float64, device=dev)
-        if rank == 0:
-            gather_site = [torch.empty(smax, dtype=torch.float32, device=dev) for _ in range(world)]
-            gather_mod = [torch.empty(smax, dtype=torch.float64, device=dev) for _ in range(world)]
+    gbufs = {}
 
     def step():
         eng.infer(X, km, off, T, 20, thr, 0, 16, 2, out=(rp, site, mod))
-        if world > 1:
-            pad_site[:Sr].copy_(site)
-            pad_mod[:Sr].copy_(mod)
-            dist.gather(pad_site, gather_site, dst=0)
-            dist.gather(pad_mod, gather_mod, dst=0)
+        if world > 1:           # the job's one exchange: site_prob + mod_ratio to rank 0 (RCCL)
+            mdist.gather_sites(site, mod, cuts, dst=0, buffers=gbufs)
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -145,12 +150,12 @@ def main():
         dt = float(tmax.item())
 
     if rank == 0:
-        total_sites = world * S if world > 1 else Sr
         total_sites = int(cuts[-1])
         enc_avg_ms = enc_ms / max(enc_n, 1)
         pool_avg_ms = pool_ms / max(pool_n, 1)
         enc_tflops = ENC_FLOP_PER_READ * R / (enc_avg_ms * 1e-3) / 1e12
         enc_gbps = ENC_BYTES_PER_READ * R / (enc_avg_ms * 1e-3) / 1e9
+        tr = measured_traffic(S, n) if world == 1 else None
         out = {
             "metric": "DRACH sites/sec at num_iterations=%d" % T,
             "value": total_sites * args.steps / dt,
@@ -166,7 +171,10 @@ def main():
                        "pool_kernel": eng.last_pool_variant, "sharding": "site shards, 1 RCCL gather/step" if world > 1 else "none"},
             "roofline": {"kernel": "enc_kernel (read encoder)", "bound": "mfma", "achieved": enc_tflops,
                          "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": enc_tflops / PEAK_F32_TFLOPS,
-                         "traffic": None, "avg_launch_ms": enc_avg_ms, "launches": enc_n,
+                         "traffic": tr["traffic_bytes_per_launch"] if tr else None,
+                         "traffic_source": tr["source"] if tr else None,
+                         "algorithmic_bytes_per_launch": ENC_BYTES_PER_READ * R,
+                         "avg_launch_ms": enc_avg_ms, "launches": enc_n,
                          "algorithmic_flop_per_read": ENC_FLOP_PER_READ, "reads_per_launch": R,
                          "hbm_view": {"achieved": enc_gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                                       "frac": enc_gbps / PEAK_HBM_GBPS, "algorithmic_bytes_per_read": ENC_BYTES_PER_READ}},

@@ -234,13 +234,16 @@ float m6a_or_site_proba(m6a_or_mt *st, const float *p, int64_t n, int n_iters, i
 /* inference_utils.py:33,47: batches of `batch_size` sites; batch `it` closes a flush group
  * when (it+1) % save_per_batch != 0.  Batches after the last flush are never written by
  * the reference; here they form a final group so every site gets a value. */
-int64_t m6a_or_flush_groups(int64_t n_sites, int64_t batch_size, int64_t save_per_batch,
-                            int64_t *group_off)
+int64_t m6a_or_flush_groups_at(int64_t n_sites, int64_t batch_size, int64_t save_per_batch,
+                               int64_t first_site, int64_t *group_off)
 {
+    /* the sites are sites [first_site, first_site+n_sites) of a larger job: batch indices are
+     * global (first_site is a multiple of batch_size that starts a group), offsets local */
     int64_t n_batches = (n_sites + batch_size - 1) / batch_size, g = 0, start_b = 0;
+    const int64_t it0 = first_site / batch_size;
     group_off[0] = 0;
     for (int64_t it = 0; it < n_batches; it++) {
-        if ((it + 1) % save_per_batch) {
+        if ((it0 + it + 1) % save_per_batch) {
             int64_t end = (it + 1) * batch_size;
             group_off[++g] = end < n_sites ? end : n_sites;
             start_b = it + 1;
@@ -248,6 +251,12 @@ int64_t m6a_or_flush_groups(int64_t n_sites, int64_t batch_size, int64_t save_pe
     }
     if (start_b < n_batches) group_off[++g] = n_sites;
     return g;
+}
+
+int64_t m6a_or_flush_groups(int64_t n_sites, int64_t batch_size, int64_t save_per_batch,
+                            int64_t *group_off)
+{
+    return m6a_or_flush_groups_at(n_sites, batch_size, save_per_batch, 0, group_off);
 }
 
 typedef struct {
@@ -286,11 +295,20 @@ int m6a_or_site_pool(const float *read_prob, const int64_t *off, int64_t n_sites
                      int n_samples, float thr, uint32_t seed, int64_t batch_size,
                      int64_t save_per_batch, int n_threads, float *site_prob, double *mod_ratio)
 {
+    return m6a_or_site_pool_at(read_prob, off, n_sites, n_iters, n_samples, thr, seed, batch_size,
+                               save_per_batch, 0, n_threads, site_prob, mod_ratio);
+}
+
+int m6a_or_site_pool_at(const float *read_prob, const int64_t *off, int64_t n_sites, int n_iters,
+                        int n_samples, float thr, uint32_t seed, int64_t batch_size,
+                        int64_t save_per_batch, int64_t first_site, int n_threads,
+                        float *site_prob, double *mod_ratio)
+{
     if (n_sites <= 0) return 0;
     int64_t n_batches = (n_sites + batch_size - 1) / batch_size;
     int64_t *goff = (int64_t *)malloc((size_t)(n_batches + 2) * sizeof(int64_t));
     if (!goff) return -1;
-    int64_t G = m6a_or_flush_groups(n_sites, batch_size, save_per_batch, goff);
+    int64_t G = m6a_or_flush_groups_at(n_sites, batch_size, save_per_batch, first_site, goff);
     int64_t next = 0;
     pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER;
     int64_t chunk = G / ((int64_t)(n_threads > 0 ? n_threads : 1) * 16);

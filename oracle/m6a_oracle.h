@@ -52,12 +52,22 @@ float m6a_or_site_proba(m6a_or_mt *st, const float *p, int64_t n, int n_iters, i
 int64_t m6a_or_flush_groups(int64_t n_sites, int64_t batch_size, int64_t save_per_batch,
                             int64_t *group_off);
 
+/* same for a shard of a larger job: the sites are [first_site, first_site+n_sites) of the job;
+ * first_site must be a multiple of batch_size that starts a flush group */
+int64_t m6a_or_flush_groups_at(int64_t n_sites, int64_t batch_size, int64_t save_per_batch,
+                               int64_t first_site, int64_t *group_off);
+
 /* a10-a13 numerics for a whole job: reseed per flush group, sites sequential inside a group
  * (inference_utils.py:47-54,90-104 at n_processes=1), mod_ratio (inference_utils.py:53).
  * n_threads>1 runs flush groups concurrently (they are independent); results identical. */
 int m6a_or_site_pool(const float *read_prob, const int64_t *off, int64_t n_sites, int n_iters,
                      int n_samples, float thr, uint32_t seed, int64_t batch_size,
                      int64_t save_per_batch, int n_threads, float *site_prob, double *mod_ratio);
+
+int m6a_or_site_pool_at(const float *read_prob, const int64_t *off, int64_t n_sites, int n_iters,
+                        int n_samples, float thr, uint32_t seed, int64_t batch_size,
+                        int64_t save_per_batch, int64_t first_site, int n_threads,
+                        float *site_prob, double *mod_ratio);
 
 /* a8: SigmoidProdPooling.forward on fixed-size bags: 1 - prod(1-p) per bag of `bag` reads
  * (m6anet/model/model_blocks/pooling_blocks.py:127-129). */

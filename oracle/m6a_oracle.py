@@ -41,6 +41,9 @@ def lib():
         L.m6a_or_site_pool.argtypes = [f32p, i64p, C.c_int64, C.c_int, C.c_int, C.c_float, C.c_uint32,
                                        C.c_int64, C.c_int64, C.c_int, f32p, f64p]
         L.m6a_or_site_pool.restype = C.c_int
+        L.m6a_or_site_pool_at.argtypes = [f32p, i64p, C.c_int64, C.c_int, C.c_int, C.c_float, C.c_uint32,
+                                          C.c_int64, C.c_int64, C.c_int64, C.c_int, f32p, f64p]
+        L.m6a_or_site_pool_at.restype = C.c_int
         L.m6a_or_bag_noisy_or.argtypes = [f32p, C.c_int64, C.c_int, f32p]
         _lib = L
     return _lib
@@ -97,15 +100,15 @@ def flush_groups(n_sites, batch_size, save_per_batch):
 
 
 def site_pool(read_prob, off, n_iters, thr, seed=0, batch_size=16, save_per_batch=2, n_samples=20,
-              n_threads=1):
+              n_threads=1, first_site=0):
     read_prob = np.ascontiguousarray(read_prob, np.float32)
     off = np.ascontiguousarray(off, np.int64)
     S = len(off) - 1
     site = np.empty(S, np.float32)
     mod = np.empty(S, np.float64)
-    rc = lib().m6a_or_site_pool(_p(read_prob, C.c_float), _p(off, C.c_int64), S, n_iters, n_samples,
-                                np.float32(thr), seed, batch_size, save_per_batch, n_threads,
-                                _p(site, C.c_float), _p(mod, C.c_double))
+    rc = lib().m6a_or_site_pool_at(_p(read_prob, C.c_float), _p(off, C.c_int64), S, n_iters, n_samples,
+                                   np.float32(thr), seed, batch_size, save_per_batch, first_site, n_threads,
+                                   _p(site, C.c_float), _p(mod, C.c_double))
     assert rc == 0
     return site, mod
 

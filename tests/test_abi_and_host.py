@@ -1,0 +1,106 @@
+"""CPU-only checks of the boundary and the host logic (no GPU compute calls)."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from m6anet_amd import _lib, constants, engine, synthetic
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    h = open(os.path.join(REPO, "include", "m6a.h")).read()
+    h = re.sub(r"/\*.*?\*/", "", h, flags=re.S)
+    return sorted(set(re.findall(r"\b(m6a_[a-z_0-9]+)\s*\(", h)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = _lib.load()
+    declared = header_symbols()
+    assert declared, "no declarations parsed from include/m6a.h"
+    for name in declared:
+        assert hasattr(L, name), "libm6a_hip.so does not export %s" % name
+    assert sorted(_lib.SYMBOLS) == declared            # the binding knows exactly the header's surface
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    exported = sorted(set(re.findall(r" T (m6a_[a-z_0-9]+)", out)))
+    assert exported == declared, (exported, declared)
+
+
+def test_version_and_errors_without_gpu():
+    L = _lib.load()
+    assert b"gfx950" in L.m6a_version()
+    h = C.c_void_p()
+    w = np.zeros(7997, np.float32)
+    assert L.m6a_create(C.byref(h), w.ctypes.data, 10, 0) == -1          # M6A_EINVAL: wrong blob size
+    assert b"7997" in L.m6a_last_error(None)
+    import torch
+    if not torch.cuda.is_available():
+        rc = L.m6a_create(C.byref(h), w.ctypes.data, 7997, 0)
+        assert rc == -5 and not h.value                                  # M6A_ENODEV, loud, no fallback
+        with pytest.raises(_lib.M6AError):
+            engine.M6ANetEngine(weights=w)
+
+
+def test_vocabulary_matches_reference_capture():
+    want = open(os.path.join(REPO, "tests", "golden", "vocab66.txt")).read().split()
+    assert constants.ALL_KMERS == want
+    assert len(constants.ALL_7MERS) == 288 and len(constants.M6A_KMERS) == 18
+    assert constants.kmer7_to_ids("AGGACTT") == [constants.KMER_TO_INT[k] for k in ("AGGAC", "GGACT", "GACTT")]
+
+
+def test_flush_groups_helper_matches_reference_loop():
+    def ref(S, bs, spb):      # the loop shape of m6anet/utils/inference_utils.py:33,47
+        nb, out, start = (S + bs - 1) // bs, [0], 0
+        for it in range(nb):
+            if (it + 1) % spb:
+                out.append(min((it + 1) * bs, S))
+                start = it + 1
+        if start < nb:
+            out.append(S)
+        return out
+    for S, bs, spb in [(101, 16, 2), (101, 51, 2), (101, 13, 2), (101, 8, 3), (40, 16, 1), (5, 16, 2), (1, 1, 2),
+                       (1000, 7, 5), (64, 16, 2), (0, 16, 2)]:
+        assert engine.flush_groups(S, bs, spb).tolist() == ref(S, bs, spb), (S, bs, spb)
+
+
+@pytest.mark.parametrize("n_shards", [1, 2, 3, 8])
+def test_shard_plan_is_group_aligned_and_balanced(n_shards):
+    g = np.random.Generator(np.random.PCG64(n_shards))
+    for bags in (np.full(5000, 20), g.integers(20, 400, size=3000)):
+        off = np.concatenate([[0], np.cumsum(bags)]).astype(np.int64)
+        cuts = engine.shard_plan(off, n_shards)
+        groups = set(engine.flush_groups(len(bags)).tolist())
+        assert cuts[0] == 0 and cuts[-1] == len(bags) and np.all(np.diff(cuts) >= 0)
+        assert all(int(c) in groups for c in cuts)
+        reads = np.diff(off[cuts])
+        assert reads.max() - reads.min() <= 2 * 32 * bags.max()       # within a couple of groups of even
+
+
+def test_weights_blobs_and_state_dict_order():
+    for name, (blob, thr, norm) in constants.PRETRAINED_CONFIGS.items():
+        w = engine.load_weights(name)
+        assert w.shape == (7997,) and np.all(np.isfinite(w))
+        assert os.path.exists(constants.asset_path(norm))
+    sd = {k: np.arange(n, dtype=np.float32) for k, n in [
+        ("read_level_encoder.1.embedding_layer.weight", 132), ("read_level_encoder.3.layers.0.weight", 2250),
+        ("read_level_encoder.3.layers.0.bias", 150), ("read_level_encoder.3.layers.1.weight", 150),
+        ("read_level_encoder.3.layers.1.bias", 150), ("read_level_encoder.3.layers.1.running_mean", 150),
+        ("read_level_encoder.3.layers.1.running_var", 150), ("read_level_encoder.4.layers.0.weight", 4800),
+        ("read_level_encoder.4.layers.0.bias", 32), ("pooling_filter.probability_layer.0.weight", 32),
+        ("pooling_filter.probability_layer.0.bias", 1)]}
+    w = engine.weights_from_state_dict(sd)
+    assert w.size == 7997 and w[132] == 0 and w[131] == 131 and w[-1] == 0
+    with pytest.raises(ValueError):
+        engine.load_weights("nope")
+
+
+def test_synthetic_generator_is_deterministic():
+    a = synthetic.make_sites(300, (50, 500), seed=7)
+    b = synthetic.make_sites(300, (50, 500), seed=7)
+    assert all(np.array_equal(a[k], b[k]) for k in a)
+    assert a["X"].dtype == np.float32 and np.abs(a["X"]).max() <= 6.0
+    assert a["site_kmers"].max() < 66 and a["off"][0] == 0 and np.diff(a["off"]).min() >= 50

@@ -1,0 +1,62 @@
+"""N>1 path on CPU: world_size-2 gloo.  Each rank owns a flush-group-aligned shard of one job,
+computes it with the job-offset semantics (the CPU oracle stands in for the HIP engine, which
+needs a GPU), and one gather brings everything to rank 0 -- which must equal the unsharded job
+bit for bit.  Exercises m6anet_amd.dist (plan, padded ragged gather) and the first_site rule."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, bag, out_path):
+    sys.path.insert(0, REPO)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    from m6anet_amd import dist as mdist, synthetic
+    from m6anet_amd.engine import load_weights
+    from oracle import m6a_oracle as orc
+    r, w = mdist.init_from_env("gloo")
+    assert (r, w) == (rank, world)
+    d = synthetic.make_sites(1500, bag, seed=4)          # every rank sees the same job description
+    weights = load_weights()
+    thr = np.float32(0.033379376)
+    cuts = mdist.shard_plan(d["off"], world)
+    a, b = mdist.my_shard(cuts, rank)
+    off = d["off"][a:b + 1] - d["off"][a]
+    X = d["X"][d["off"][a]:d["off"][b]]
+    p = orc.encode_reads(weights, X, d["site_kmers"][a:b], off)
+    site, mod = orc.site_pool(p, off, 50, thr, first_site=a)
+    bufs = {}
+    for _ in range(2):                                   # twice: staging buffers are reused
+        site_all, mod_all = mdist.gather_sites(torch.from_numpy(site), torch.from_numpy(mod), cuts, dst=0, buffers=bufs)
+    if rank == 0:
+        p_full = orc.encode_reads(weights, d["X"], d["site_kmers"], d["off"])
+        f_site, f_mod = orc.site_pool(p_full, d["off"], 50, thr)
+        ok = np.array_equal(site_all.numpy(), f_site) and np.array_equal(mod_all.numpy(), f_mod)
+        np.save(out_path, np.array([int(ok), len(site_all), int(cuts[1])]))
+    else:
+        assert site_all is None and mod_all is None
+    import torch.distributed as dist
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("bag", [20, (20, 120)])
+def test_two_rank_shards_equal_the_whole_job(tmp_path, bag):
+    out = str(tmp_path / "res.npy")
+    mp.spawn(_worker, args=(2, _free_port(), bag, out), nprocs=2, join=True)
+    ok, n, cut = np.load(out)
+    assert ok == 1 and n == 1500 and 0 < cut < 1500

@@ -257,6 +257,35 @@ def test_device_tensors_match_host_path(eng):
         eng.set_stream(None)
 
 
+def test_job_offset_shards_equal_whole_job(eng):
+    """Multi-GPU rule on one GPU: shards cut by shard_plan and run with set_job_offset reproduce the
+    unsharded job bit for bit (uniform bags -> table kernel, ragged -> scan kernel)."""
+    from m6anet_amd.engine import shard_plan
+    from m6anet_amd._lib import M6AError
+    for bag in (20, (20, 90)):
+        d = synthetic.make_sites(3000, bag, seed=8)
+        rp, site, mod = eng.infer(d["X"], d["site_kmers"], d["off"], 64)
+        cuts = shard_plan(d["off"], 3)
+        parts = []
+        try:
+            for r in range(3):
+                a, b = int(cuts[r]), int(cuts[r + 1])
+                eng.set_job_offset(a)
+                off = d["off"][a:b + 1] - d["off"][a]
+                X = d["X"][d["off"][a]:d["off"][b]]
+                parts.append(eng.infer(X, d["site_kmers"][a:b], off, 64))
+            eng.set_job_offset(16)      # inside a group for the default geometry? 16 starts group 1: fine
+            eng.infer(d["X"][:20 * 0 + d["off"][32]], d["site_kmers"][:32], d["off"][:33], 8)
+            eng.set_job_offset(32)      # batch 2 continues the group {1,2}: must be refused
+            with pytest.raises(M6AError):
+                eng.infer(d["X"][:d["off"][32]], d["site_kmers"][:32], d["off"][:33], 8)
+        finally:
+            eng.set_job_offset(0)
+        assert np.array_equal(np.concatenate([p[0] for p in parts]), rp)
+        assert np.array_equal(np.concatenate([p[1] for p in parts]), site)
+        assert np.array_equal(np.concatenate([p[2] for p in parts]), mod)
+
+
 # ------------------------------------------------------------------ full size ------------------
 def test_full_size_properties(eng, orc, weights):
     """BASELINE.json configs[2] size (1M sites x 20 reads, T=1000): size-independent checks.
