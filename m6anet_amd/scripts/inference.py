@@ -1,0 +1,74 @@
+"""`inference` sub-command: same flags, defaults and output files as `m6anet inference`
+(m6anet/scripts/inference.py:20-106), running the hot path on an MI355X through libm6a_hip.so."""
+import os
+import pathlib
+import warnings
+from argparse import ArgumentDefaultsHelpFormatter, ArgumentParser
+
+from ..constants import (DEFAULT_MIN_READS, DEFAULT_PRETRAINED_MODEL, DEFAULT_PRETRAINED_MODELS,
+                         DEFAULT_READ_THRESHOLD, PRETRAINED_CONFIGS)
+from ..data_utils import load_sites
+from ..engine import M6ANetEngine, load_weights, weights_from_state_dict
+from ..inference_utils import INDIV_HEADER, SITE_HEADER, run_inference
+
+
+def argparser():
+    parser = ArgumentParser(formatter_class=ArgumentDefaultsHelpFormatter, add_help=False)
+    parser.add_argument("--input_dir", nargs="*", required=True,
+                        help="directories containing data.info and data.json.")
+    parser.add_argument("--out_dir", required=True, help="directory to output inference results.")
+    parser.add_argument("--pretrained_model", default=DEFAULT_PRETRAINED_MODEL, type=str,
+                        help="pre-trained model available at m6anet. Options include {}.".format(DEFAULT_PRETRAINED_MODELS))
+    parser.add_argument("--model_config", default=None,
+                        help="accepted for compatibility; only the m6anet.toml topology is supported.")
+    parser.add_argument("--model_state_dict", default=None,
+                        help="path to model weights: a reference .pt checkpoint (needs torch) or a flat .bin blob.")
+    parser.add_argument("--norm_path", default=PRETRAINED_CONFIGS[DEFAULT_PRETRAINED_MODEL][2],
+                        help="path to normalization factors file (.npz of this package or the reference's .joblib)")
+    parser.add_argument("--batch_size", default=16, type=int, help="batch size for inference.")
+    parser.add_argument("--save_per_batch", default=2, type=int,
+                        help="saving inference results every save_per_batch multiples.")
+    parser.add_argument("--n_processes", default=25, type=int,
+                        help="accepted for compatibility; results are those of the reference at n_processes=1.")
+    parser.add_argument("--num_iterations", default=1000, type=int, help="number of sampling run.")
+    parser.add_argument("--device", default="cuda:0", type=str,
+                        help="GPU to run on (cuda:N / hip:N). There is no CPU path.")
+    parser.add_argument("--seed", default=0, type=int, help="random seed for sampling.")
+    parser.add_argument("--read_proba_threshold", default=DEFAULT_READ_THRESHOLD, type=float,
+                        help="default probability threshold for a read to be considered modified.")
+    return parser
+
+
+def _device_index(device):
+    d = str(device).lower()
+    if d.startswith("cpu"):
+        raise ValueError("--device cpu: this build runs the hot path on an MI355X only (no CPU fallback)")
+    return int(d.split(":")[1]) if ":" in d else 0
+
+
+def main(args):
+    if args.model_state_dict is not None:
+        warnings.warn("--model_state_dict is specified, overwriting default model weights")
+        if str(args.model_state_dict).endswith(".bin"):
+            import numpy as np
+            weights = np.fromfile(args.model_state_dict, np.float32)
+        else:
+            import torch
+            weights = weights_from_state_dict(torch.load(args.model_state_dict, map_location="cpu"))
+    else:
+        if args.pretrained_model not in DEFAULT_PRETRAINED_MODELS:
+            raise ValueError("Invalid pretrained model {}, must be one of {}".format(
+                args.pretrained_model, DEFAULT_PRETRAINED_MODELS))
+        weights = load_weights(args.pretrained_model)
+        args.read_proba_threshold = PRETRAINED_CONFIGS[args.pretrained_model][1]
+        args.norm_path = PRETRAINED_CONFIGS[args.pretrained_model][2]
+
+    engine = M6ANetEngine(weights=weights, device=_device_index(args.device))
+    pathlib.Path(args.out_dir).mkdir(parents=True, exist_ok=True)
+    with open(os.path.join(args.out_dir, "data.site_proba.csv"), "w", encoding="utf-8") as f:
+        f.write(SITE_HEADER)
+    with open(os.path.join(args.out_dir, "data.indiv_proba.csv"), "w", encoding="utf-8") as g:
+        g.write(INDIV_HEADER)
+    batch = load_sites(args.input_dir, DEFAULT_MIN_READS, args.norm_path)
+    run_inference(engine, batch, args)
+    engine.close()

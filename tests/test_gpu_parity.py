@@ -326,3 +326,65 @@ def test_full_size_properties(eng, orc, weights):
     assert np.abs(site - closed).mean() < 0.01
     # last site is written (the reference would drop the final batch when #batches is even)
     assert site[-1] > 0
+
+
+# ------------------------------------------------------------------ CLI, config #1 --------------
+def _run_cli(tmp_path, extra):
+    import os
+    from m6anet_amd.__main__ import main
+    out = str(tmp_path / "out")
+    data = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_tests_data")
+    main(["inference", "--input_dir", data, "--out_dir", out, "--n_processes", "1"] + extra)
+    return out
+
+
+def test_cli_config1_matches_reference_csvs(tmp_path, golden):
+    """BASELINE.json configs[0]: bundled data -> inference at num_iterations=5 -- here on the GPU --
+    against the exact CSVs the reference wrote (tests/golden/config1_*.csv)."""
+    import gzip
+    import os
+    import pandas as pd
+    out = _run_cli(tmp_path, ["--num_iterations", "5"])
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    site = pd.read_csv(os.path.join(out, "data.site_proba.csv"))
+    ref_site = pd.read_csv(os.path.join(gold, "config1_site_proba.csv"))
+    assert list(site.columns) == list(ref_site.columns) and len(site) == len(ref_site) == 101
+    for col in ("transcript_id", "transcript_position", "n_reads", "kmer"):      # bit-exact ids / k-mers
+        assert (site[col] == ref_site[col]).all(), col
+    assert np.array_equal(site["mod_ratio"], ref_site["mod_ratio"])
+    assert np.abs(site["probability_modified"] - ref_site["probability_modified"]).max() <= 1e-5
+    ours = open(os.path.join(out, "data.indiv_proba.csv")).read().splitlines()
+    ref = gzip.open(os.path.join(gold, "config1_indiv_proba.csv.gz"), "rt").read().splitlines()
+    assert len(ours) == len(ref) and ours[0] == ref[0]
+    pa = np.array([float(r.rsplit(",", 1)[1]) for r in ours[1:]])
+    pb = np.array([float(r.rsplit(",", 1)[1]) for r in ref[1:]])
+    assert [r.rsplit(",", 1)[0] for r in ours[1:]] == [r.rsplit(",", 1)[0] for r in ref[1:]]   # read_index exact
+    assert np.allclose(pa, pb, rtol=1e-5, atol=1e-8)
+
+
+def test_cli_reference_test_suite_bar(tmp_path):
+    """The reference's own integration test (m6anet/tests/test_inference.py:10-37) re-stated on its
+    own golden files: ids exact, read probabilities allclose, mod_ratio allclose, site probabilities
+    atol=1e-2 at num_iterations=10000."""
+    import os
+    import pandas as pd
+    out = _run_cli(tmp_path, ["--num_iterations", "10000"])
+    data = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_tests_data")
+    key_i = ["transcript_id", "transcript_position", "read_index"]
+    key_s = ["transcript_id", "transcript_position"]
+    ti = pd.read_csv(os.path.join(out, "data.indiv_proba.csv")).sort_values(key_i).reset_index(drop=True)
+    ts = pd.read_csv(os.path.join(out, "data.site_proba.csv")).sort_values(key_s).reset_index(drop=True)
+    gi = pd.read_csv(os.path.join(data, "data.indiv_proba.csv.gz")).sort_values(key_i).reset_index(drop=True)
+    gs = pd.read_csv(os.path.join(data, "data.site_proba.csv.gz")).sort_values(key_s).reset_index(drop=True)
+    for k in key_i:
+        assert np.all(gi[k] == ti[k])
+    assert np.allclose(gi["probability_modified"], ti["probability_modified"])
+    for k in key_s:
+        assert np.all(gs[k] == ts[k])
+    assert np.allclose(gs["mod_ratio"], ts["mod_ratio"])
+    assert np.allclose(gs["probability_modified"], ts["probability_modified"], atol=1e-2)
+
+
+def test_cli_rejects_cpu_device(tmp_path):
+    with pytest.raises(ValueError):
+        _run_cli(tmp_path, ["--device", "cpu"])
