@@ -125,7 +125,10 @@ int m6a_shard_plan(const int64_t *off, int64_t n_sites, int64_t batch_size, int6
  * kind: 0 = read encoder, 1 = site pooling.  m6a_profile_read synchronises the stream. */
 int m6a_profile_enable(m6a_ctx *ctx, int on);
 int m6a_profile_read(m6a_ctx *ctx, int kind, double *total_ms, int64_t *n_launches);
-/* name of the pooling kernel variant used by the last pool/infer call ("table" | "scan") */
+/* Tuning knob for ragged bags: 0 = choose by available parallelism (default), 1 = one wavefront
+ * per flush group, 2 = counting pass + one wavefront per site.  Results are identical. */
+int m6a_set_scan_driver(m6a_ctx *ctx, int mode);
+/* pooling kernel variant used by the last pool/infer call: "table" | "scan-group" | "scan-site" */
 const char *m6a_last_pool_variant(const m6a_ctx *ctx);
 
 const char *m6a_version(void);

@@ -57,12 +57,13 @@ struct m6a_ctx {
     float *d_wfrag = nullptr, *d_emb = nullptr;
     float b3 = 0.f;
     // sampling state (device) + what it was built for
-    DevBuf raw, tab, goff, rp_scratch, off_scratch;
+    DevBuf raw, tab, goff, rp_scratch, off_scratch, start_pos;
     uint32_t raw_seed = 0; int64_t raw_len = 0;
     struct { uint32_t seed; int n, T, K, jmax; bool valid; } tab_key = {0, 0, 0, 0, 0, false};
     struct { int64_t S, bs, spb, base, G, gmax; bool valid; } goff_key = {0, 0, 0, 0, 0, 0, false};
     int64_t job_offset = 0;
     int64_t bag_min = 0, bag_max = 0, n_reads = 0;   // last query_bags()
+    int scan_driver = 0;                              // 0 auto, 1 per group, 2 counting pass + per site
     int *d_err = nullptr;
     unsigned long long *d_minmax = nullptr;
     unsigned long long *h_minmax = nullptr;   // pinned
@@ -305,7 +306,7 @@ int launch_pool(m6a_ctx *c, const float *rp, const int64_t *off, int64_t S, int 
     PoolArgs a;
     memset(&a, 0, sizeof a);
     a.read_prob = rp; a.off = off; a.goff = (const int64_t *)c->goff.p; a.site_prob = site; a.mod_ratio = mod;
-    a.err = c->d_err; a.n_groups = c->goff_key.G; a.T = T; a.K = K; a.thr = thr;
+    a.err = c->d_err; a.n_groups = c->goff_key.G; a.n_sites = S; a.T = T; a.K = K; a.thr = thr;
     const int64_t gmax = c->goff_key.gmax;
 
     if (nmin == nmax && nmin >= 1 && nmin <= M6A_TABLE_MAX_N && K == 20 && gmax <= 4096) {
@@ -324,16 +325,34 @@ int launch_pool(m6a_ctx *c, const float *rp, const int64_t *off, int64_t S, int 
     } else {
         // expected words per accepted draw <= 2; slack covers the rejection-count spread
         const int64_t A = (int64_t)T * K;
-        const int64_t need = gmax * (2 * A + A / 16) + 8192;
+        const int64_t need = gmax * (2 * A + A / 16) + 8192;     // incl. the kernels' 2 x 1024-word read-ahead
         rc = ensure_raw(c, seed, need);
         if (rc) return rc;
         a.raw = (const uint32_t *)c->raw.p; a.raw_len = c->raw_len;
-        const size_t lds = (size_t)4 * (M6A_BAG_LDS + 64 * (K + 1) + 128) * sizeof(float);
-        const unsigned blocks = (unsigned)std::min<int64_t>((a.n_groups + 3) / 4, (int64_t)c->n_cu * 4);
-        c->pool_variant = "scan";
+        HIPCHK(c, c->start_pos.ensure((size_t)S * sizeof(uint32_t)));
+        a.start_pos = (uint32_t *)c->start_pos.p;
+        // LDS bag sized to the largest bag of this call (bags beyond M6A_BAG_LDS gather from global)
+        a.bag_cap = (int)std::min<int64_t>(M6A_BAG_LDS, std::max<int64_t>(64, (nmax + 63) / 64 * 64));
+        const size_t lds = (size_t)4 * (a.bag_cap + (64 * K) * 5 / 4 + 32) * sizeof(float);
+        const int64_t wg_per_cu = std::max<int64_t>(1, std::min<int64_t>(8, (160 * 1024) / (int64_t)lds));
+        const int64_t wave_slots = (int64_t)c->n_cu * wg_per_cu * 4;
+        // enough flush groups to fill the chip several times over: walk each group's sites in
+        // sequence (the stream is scanned once); otherwise buy 32x the parallelism with a counting
+        // pass that finds every site's start position first
+        const bool by_group = c->scan_driver ? c->scan_driver == 1 : a.n_groups >= 3 * wave_slots;
+        c->pool_variant = by_group ? "scan-group" : "scan-site";
         prof_begin(c, 1);
-        if (K == 20) hipLaunchKernelGGL(pool_scan_kernel<20>, dim3(blocks), dim3(256), lds, c->stream, a);
-        else hipLaunchKernelGGL(pool_scan_kernel<0>, dim3(blocks), dim3(256), lds, c->stream, a);
+        if (by_group) {
+            const unsigned blocks = (unsigned)std::min<int64_t>((a.n_groups + 3) / 4, wave_slots / 4);
+            if (K == 20) hipLaunchKernelGGL(pool_scan_group_kernel<20>, dim3(blocks), dim3(256), lds, c->stream, a);
+            else hipLaunchKernelGGL(pool_scan_group_kernel<0>, dim3(blocks), dim3(256), lds, c->stream, a);
+        } else {
+            hipLaunchKernelGGL(pool_scan_start_kernel, dim3((unsigned)std::min<int64_t>((a.n_groups + 3) / 4, (int64_t)c->n_cu * 8)),
+                               dim3(256), 0, c->stream, a);
+            const unsigned blocks = (unsigned)std::min<int64_t>((S + 3) / 4, wave_slots / 4);
+            if (K == 20) hipLaunchKernelGGL(pool_scan_site_kernel<20>, dim3(blocks), dim3(256), lds, c->stream, a);
+            else hipLaunchKernelGGL(pool_scan_site_kernel<0>, dim3(blocks), dim3(256), lds, c->stream, a);
+        }
         prof_end(c, 1);
     }
     HIPCHK(c, hipGetLastError());
@@ -449,7 +468,7 @@ void m6a_destroy(m6a_ctx *c)
         for (auto e : c->prof.start[k]) (void)hipEventDestroy(e);
         for (auto e : c->prof.stop[k]) (void)hipEventDestroy(e);
     }
-    for (DevBuf *b : {&c->raw, &c->tab, &c->goff, &c->rp_scratch, &c->off_scratch, &c->sX, &c->sK, &c->sOff,
+    for (DevBuf *b : {&c->raw, &c->tab, &c->goff, &c->rp_scratch, &c->off_scratch, &c->start_pos, &c->sX, &c->sK, &c->sOff,
                       &c->sP, &c->sSite, &c->sMod}) b->release();
     if (c->d_wfrag) (void)hipFree(c->d_wfrag);
     if (c->d_emb) (void)hipFree(c->d_emb);
@@ -473,6 +492,14 @@ int m6a_set_job_offset(m6a_ctx *c, int64_t first_site)
     if (!c) return M6A_EINVAL;
     if (first_site < 0) return fail(c, M6A_EINVAL, "job offset must be >= 0");
     c->job_offset = first_site;
+    return M6A_OK;
+}
+
+int m6a_set_scan_driver(m6a_ctx *c, int mode)
+{
+    if (!c) return M6A_EINVAL;
+    if (mode < 0 || mode > 2) return fail(c, M6A_EINVAL, "scan driver must be 0 (auto), 1 (group) or 2 (site)");
+    c->scan_driver = mode;
     return M6A_OK;
 }
 

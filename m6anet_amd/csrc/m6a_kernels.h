@@ -27,14 +27,17 @@ struct PoolArgs {
     const uint32_t *tab;          // ... or accepted-index table (table)
     float *site_prob;             // [S]
     double *mod_ratio;            // [S]
+    uint32_t *start_pos;          // [S] first stream word of each site (scan)
     int *err;
-    int64_t n_groups, raw_len;
-    int T, K, uniform_n, jmax;
+    int64_t n_groups, n_sites, raw_len;
+    int T, K, uniform_n, jmax, bag_cap;
     float thr;
 };
 
 __global__ void enc_kernel(EncArgs a);
-template <int KT> __global__ void pool_scan_kernel(PoolArgs a);
+__global__ void pool_scan_start_kernel(PoolArgs a);
+template <int KT> __global__ void pool_scan_group_kernel(PoolArgs a);
+template <int KT> __global__ void pool_scan_site_kernel(PoolArgs a);
 __global__ void pool_table_kernel(PoolArgs a);
 __global__ void bag_noisy_or_kernel(const float *read_prob, int64_t n_bags, int bag, float *site_prob);
 __global__ void iota_off_kernel(int64_t *off, int64_t n_plus_1, int64_t step);

@@ -2,9 +2,11 @@
 //
 //   enc_kernel         read encoder: [x(9) | emb(6) | 1] -> 150 (BN folded) -> ReLU -> 32 -> ReLU
 //                      -> 1 -> sigmoid, all in registers on v_mfma_f32_32x32x2_f32 (exact f32).
-//   pool_scan_kernel   site pooling, exact NumPy-stream replay, any bag sizes: one wavefront
-//                      per flush group walks the shared MT19937 word stream (masked rejection),
-//                      compacts accepted draws through LDS and multiplies 20-term products.
+//   pool_scan_start_kernel + pool_scan_kernel
+//                      site pooling, exact NumPy-stream replay, any bag sizes: a counting pass per
+//                      flush group finds where each site starts in the shared MT19937 word stream
+//                      (masked rejection); then one wavefront per site compacts its accepted draws
+//                      through LDS and multiplies the 20-term products.
 //   pool_table_kernel  same result when every bag has the same size n <= 32: the accepted
 //                      index sequence is then identical in every flush group, so it is a
 //                      precomputed table and the kernel is a pure LDS gather, 8 sites per pass.
@@ -232,125 +234,300 @@ __global__ __launch_bounds__(256, 2) void enc_kernel(EncArgs a)
 // groups read the SAME word stream `raw` (generated once on the host) from position 0, and the
 // sites of a group consume it back to back.
 //
-// One wavefront per flush group.  Per step 64 consecutive words are tested; accepted lanes get
-// their rank by ballot + mbcnt, gather 1-p from the LDS bag and drop it at slot -> slot +
-// slot/K (row stride K+1: conflict-free both for the rank-ordered write and for the
-// per-iteration read back).  Every 64 completed iterations the lanes multiply their K values
-// left to right (float32, same order as np.prod) and accumulate 1 - prod.
+// scan_site() replays one site from a given stream position.  Per step 64 consecutive words are
+// masked and range-tested; accepted lanes get their rank by ballot + mbcnt, gather 1-p from the
+// LDS bag and store it at ring slot cnt+rank.  The ring holds two windows of 32 iterations
+// (CH = 32*K slots each); a slot lives at dword slot + slot/4, which makes the stride between
+// iterations K*5/4 (25 for K = 20: odd, so the per-iteration read-back is bank-conflict-free, and
+// with K % 4 == 0 every read offset is a compile-time immediate) at no division.  When a window
+// fills, lanes 0..31 multiply their K values left to right (float32, the order of np.prod) and
+// add 1-prod.  The step that completes the site finds the lane holding the last accepted draw;
+// the next site starts at the following word, exactly like the sequential NumPy loop.
+//
+// Where a site starts depends on how many words every earlier site of its group rejected.  Two
+// drivers, chosen on the host by how much parallelism the call has:
+//   pool_scan_group_kernel  one wavefront per flush group, sites in sequence (no extra pass);
+//   pool_scan_start_kernel + pool_scan_site_kernel
+//                           a counting-only pass per group (per-lane counters, 1024 words per
+//                           step) records start_pos[site]; then one wavefront per SITE.
 // =====================================================================================
+__device__ __forceinline__ uint32_t pow2_mask(uint32_t rng)
+{
+    uint32_t mask = rng;
+    mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+    return mask;
+}
+
+// dword address of ring slot `s` (see above)
+__device__ __forceinline__ int ring_addr(int s) { return s + (s >> 2); }
+
 template <int KT>
-__global__ __launch_bounds__(256) void pool_scan_kernel(PoolArgs a)
+__device__ __forceinline__ float window_product(const float *ring, int wbase, int lane, int K)
+{
+    float prod = 1.0f;
+    if (KT && (KT % 4 == 0)) {
+        const float *row = ring + (wbase + lane * KT) * 5 / 4;      // wbase, lane*KT multiples of 4
+#pragma unroll
+        for (int k = 0; k < KT; k++) prod *= row[k + (k >> 2)];
+    } else {
+        const int base = wbase + lane * K;
+        for (int k = 0; k < K; k++) prod *= ring[ring_addr(base + k)];
+    }
+    return prod;
+}
+
+// Replays one site.  `pos` = its first stream word on entry, the word after its last accepted
+// draw on return.  Returns false if the stream proved too short (err flag set).
+template <int KT>
+__device__ __forceinline__ bool scan_site(const PoolArgs &a, int64_t s, uint32_t &pos, float *bag, float *ring,
+                                          int lane, int K)
+{
+    const int bag_cap = a.bag_cap;
+    const int CH = 32 * K;                       // slots per window
+    const int A = a.T * K;                       // accepted draws per site
+    // site-level values are wave-uniform: say so, and rng/mask/branches below become scalar
+    const int64_t r0 = ((int64_t)__builtin_amdgcn_readfirstlane((int)(a.off[s] >> 32)) << 32) |
+                       (uint32_t)__builtin_amdgcn_readfirstlane((int)a.off[s]);
+    const int n = __builtin_amdgcn_readfirstlane((int)(a.off[s + 1] - r0));
+    int cge = 0;
+    for (int i = lane; i < n; i += 64) {
+        const float v = a.read_prob[r0 + i];
+        cge += (v >= a.thr) ? 1 : 0;
+        if (i < bag_cap) bag[i] = 1.0f - v;
+    }
+    cge = wave_sum_i32(cge);
+    if (lane == 0) a.mod_ratio[s] = n > 0 ? (double)cge / (double)n : __builtin_nan("");
+    if (n <= 0) { if (lane == 0) a.site_prob[s] = __builtin_nanf(""); return true; }
+    wave_lds_fence();
+
+    const uint32_t rng = (uint32_t)(n - 1);
+    if (rng == 0) {                              // bag of one read: randint draws no words
+        float prod = 1.0f;
+        const float a0 = bag[0];
+        for (int k = 0; k < K; k++) prod *= a0;
+        if (lane == 0) a.site_prob[s] = 1.0f - prod;
+        wave_lds_fence();
+        return true;
+    }
+    const uint32_t mask = pow2_mask(rng);
+    const bool in_lds = n <= bag_cap;            // wave-uniform: no per-lane test on the fast path
+    float sum = 0.0f;
+    int acc = 0, cnt = 0, wbase = 0;
+    if ((uint64_t)pos + 512 > (uint64_t)a.raw_len) { if (lane == 0) atomicExch(a.err, 1); return false; }
+    uint32_t w[4], wn[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) w[i] = a.raw[pos + 64 * i + lane];
+
+    // one accepted word -> ring: gather 1-p, store at slot base+rank (two-window ring, wrapped)
+    auto put = [&](uint32_t v, int base_plus_rank) {
+        float val;
+        if (in_lds) val = bag[v];
+        else val = v < (uint32_t)bag_cap ? bag[v] : 1.0f - a.read_prob[r0 + v];
+        uint32_t slot = (uint32_t)base_plus_rank;                    // < 2*CH + 256
+        slot = min(slot, slot - (uint32_t)(2 * CH));                 // wrap
+        ring[ring_addr((int)slot)] = val;
+    };
+    auto close_window = [&]() {
+        wave_lds_fence();
+        if (lane < 32) sum += 1.0f - window_product<KT>(ring, wbase, lane, K);
+        wbase = CH - wbase;                      // other window
+        cnt -= CH;
+        wave_lds_fence();
+    };
+
+    // ---- whole 256-word blocks, branch-free inside: the gather index is clamped so every lane
+    // may gather, rejected lanes store to a trash slot (one v_cndmask instead of a branch), all
+    // four gathers are in flight together, one window check per block (the ring absorbs the
+    // <= 255 overflow slots as long as CH >= 256, i.e. K >= 8).  Bags beyond the LDS bag take
+    // the tail path.
+    const int trash = ring_addr(2 * CH) + 1;
+    if (K >= 8 && in_lds) {
+        for (;;) {
+            if ((uint64_t)pos + 512 > (uint64_t)a.raw_len) { if (lane == 0) atomicExch(a.err, 1); return false; }
+            uint32_t v[4];
+            unsigned long long bal[4];
+            int c[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                v[i] = w[i] & mask;
+                bal[i] = __ballot(v[i] <= rng);
+                c[i] = __popcll(bal[i]);
+            }
+            const int cb = c[0] + c[1] + c[2] + c[3];
+            if (acc + cb >= A) break;            // the site's last draw is in this block: exact tail below
+#pragma unroll
+            for (int i = 0; i < 4; i++) wn[i] = a.raw[pos + 256 + 64 * i + lane];   // next block in flight
+            int base = wbase + cnt;
+            float val[4];
+            int addr[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                val[i] = bag[min(v[i], rng)];
+                const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal[i] >> 32),
+                                 __builtin_amdgcn_mbcnt_lo((uint32_t)bal[i], 0));
+                uint32_t slot = (uint32_t)(base + rank);
+                slot = min(slot, slot - (uint32_t)(2 * CH));
+                addr[i] = v[i] <= rng ? ring_addr((int)slot) : trash;
+                base += c[i];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) ring[addr[i]] = val[i];
+            cnt += cb;
+            acc += cb;
+            if (cnt >= CH) close_window();
+            pos += 256;
+#pragma unroll
+            for (int i = 0; i < 4; i++) w[i] = wn[i];
+        }
+    }
+    // ---- exact tail (and the whole site when K < 8): 64 words at a time until the A-th draw
+    bool done = false;
+    while (!done) {
+        if ((uint64_t)pos + 512 > (uint64_t)a.raw_len) { if (lane == 0) atomicExch(a.err, 1); return false; }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            if (done) break;
+            const uint32_t v = w[i] & mask;
+            bool ok = v <= rng;
+            const unsigned long long bal = __ballot(ok);
+            int c = __popcll(bal);
+            const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32),
+                             __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0));
+            const int remaining = A - acc;
+            if (c >= remaining) {                // this step completes the site
+                ok = ok && rank < remaining;
+                const unsigned long long lastb = __ballot(ok && rank == remaining - 1);
+                pos += 64 * i + (uint32_t)__builtin_ctzll(lastb) + 1;
+                c = remaining;
+                done = true;
+            }
+            if (ok) put(v, wbase + cnt + rank);
+            cnt += c;
+            acc += c;
+            if (cnt >= CH) close_window();
+        }
+        if (!done) {
+            pos += 256;
+#pragma unroll
+            for (int i = 0; i < 4; i++) w[i] = a.raw[pos + 64 * i + lane];
+        }
+    }
+    wave_lds_fence();
+    const int t_rem = cnt / K;                   // iterations left in the current window (< 32)
+    if (lane < t_rem) sum += 1.0f - window_product<KT>(ring, wbase, lane, K);
+    sum = wave_sum_f32(sum);
+    if (lane == 0) a.site_prob[s] = sum / (float)a.T;
+    wave_lds_fence();
+    return true;
+}
+
+// LDS per wavefront: the bag, then the ring (2 windows of 32*K slots at 5/4 dwords per slot)
+__device__ __forceinline__ int scan_wave_floats(int bag_cap, int K) { return bag_cap + (64 * K) * 5 / 4 + 32; }
+
+template <int KT>
+__global__ __launch_bounds__(256) void pool_scan_group_kernel(PoolArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int K = KT ? KT : a.K;
-    const int lane = threadIdx.x & 63;
-    const int wib = threadIdx.x >> 6;
-    const int per_wave = M6A_BAG_LDS + 64 * (K + 1) + 128;
-    float *bag = smem + wib * per_wave;
-    float *buf = bag + M6A_BAG_LDS;
-    const int CH = 64 * K;
-    const int A = a.T * K;                       // accepted draws per site
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    float *bag = smem + wib * scan_wave_floats(a.bag_cap, K);
+    float *ring = bag + a.bag_cap;
     const int64_t n_waves = (int64_t)gridDim.x * 4;
-
     for (int64_t g = (int64_t)blockIdx.x * 4 + wib; g < a.n_groups; g += n_waves) {
-        uint32_t pos = 0;                        // next unread word of the group's stream
+        uint32_t pos = 0;
         const int64_t s_end = a.goff[g + 1];
-        for (int64_t s = a.goff[g]; s < s_end; ++s) {
-            const int64_t r0 = a.off[s];
-            const int n = (int)(a.off[s + 1] - r0);
-            int cge = 0;
-            for (int i = lane; i < n; i += 64) {
-                const float v = a.read_prob[r0 + i];
-                cge += (v >= a.thr) ? 1 : 0;
-                if (i < M6A_BAG_LDS) bag[i] = 1.0f - v;
-            }
-            cge = wave_sum_i32(cge);
-            if (lane == 0) a.mod_ratio[s] = n > 0 ? (double)cge / (double)n : __builtin_nan("");
-            if (n <= 0) { if (lane == 0) a.site_prob[s] = __builtin_nanf(""); continue; }
-            wave_lds_fence();
-
-            const uint32_t rng = (uint32_t)(n - 1);
-            float sum = 0.0f;
-            if (rng == 0) {                      // bag of one read: randint draws no words
-                float prod = 1.0f;
-                const float a0 = bag[0];
-                for (int k = 0; k < K; k++) prod *= a0;
-                if (lane == 0) a.site_prob[s] = 1.0f - prod;
-                wave_lds_fence();
-                continue;
-            }
-            uint32_t mask = rng;
-            mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
-
-            int acc = 0, cnt = 0;
-            bool done = false;
-            while (!done) {
-                if ((uint64_t)pos + 256 > (uint64_t)a.raw_len) {      // stream too short: report
-                    if (lane == 0) atomicExch(a.err, 1);
-                    done = true;
-                    break;
-                }
-                uint32_t w[4];
-#pragma unroll
-                for (int i = 0; i < 4; i++) w[i] = a.raw[pos + 64 * i + lane];
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    if (done) break;
-                    const uint32_t v = w[i] & mask;
-                    bool ok = v <= rng;
-                    const unsigned long long bal = __ballot(ok);
-                    int c = __popcll(bal);
-                    const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32),
-                                     __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0));
-                    const int remaining = A - acc;
-                    if (c >= remaining) {        // this step completes the site
-                        ok = ok && rank < remaining;
-                        const unsigned long long lastb = __ballot(ok && rank == remaining - 1);
-                        pos += 64 * i + (uint32_t)__builtin_ctzll(lastb) + 1;
-                        c = remaining;
-                        done = true;
-                    }
-                    if (ok) {
-                        const float val = v < M6A_BAG_LDS ? bag[v] : 1.0f - a.read_prob[r0 + v];
-                        const int slot = cnt + rank;
-                        buf[slot + slot / K] = val;
-                    }
-                    cnt += c;
-                    acc += c;
-                    if (cnt >= CH) {
-                        wave_lds_fence();
-                        float prod = 1.0f;
-                        const float *row = buf + lane * (K + 1);
-                        for (int k = 0; k < K; k++) prod *= row[k];
-                        sum += 1.0f - prod;
-                        const int m = cnt - CH;  // < 64 overflow slots move to the front
-                        float tmp = 0.0f;
-                        if (lane < m) { const int sl = CH + lane; tmp = buf[sl + sl / K]; }
-                        wave_lds_fence();
-                        if (lane < m) buf[lane + lane / K] = tmp;
-                        cnt = m;
-                        wave_lds_fence();
-                    }
-                }
-                if (!done) pos += 256;
-            }
-            wave_lds_fence();
-            const int t_rem = cnt / K;           // iterations left in the buffer (< 64)
-            if (lane < t_rem) {
-                float prod = 1.0f;
-                const float *row = buf + lane * (K + 1);
-                for (int k = 0; k < K; k++) prod *= row[k];
-                sum += 1.0f - prod;
-            }
-            sum = wave_sum_f32(sum);
-            if (lane == 0) a.site_prob[s] = sum / (float)a.T;
-            wave_lds_fence();
-        }
+        for (int64_t s = a.goff[g]; s < s_end; ++s)
+            if (!scan_site<KT>(a, s, pos, bag, ring, lane, K)) return;
     }
 }
 
-template __global__ void pool_scan_kernel<20>(PoolArgs);
-template __global__ void pool_scan_kernel<0>(PoolArgs);
+template <int KT>
+__global__ __launch_bounds__(256) void pool_scan_site_kernel(PoolArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int K = KT ? KT : a.K;
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    float *bag = smem + wib * scan_wave_floats(a.bag_cap, K);
+    float *ring = bag + a.bag_cap;
+    const int64_t n_waves = (int64_t)gridDim.x * 4;
+    for (int64_t s = (int64_t)blockIdx.x * 4 + wib; s < a.n_sites; s += n_waves) {
+        uint32_t pos = a.start_pos[s];
+        if (!scan_site<KT>(a, s, pos, bag, ring, lane, K)) return;
+    }
+}
+
+template __global__ void pool_scan_group_kernel<20>(PoolArgs);
+template __global__ void pool_scan_group_kernel<0>(PoolArgs);
+template __global__ void pool_scan_site_kernel<20>(PoolArgs);
+template __global__ void pool_scan_site_kernel<0>(PoolArgs);
+
+// Counting-only pass: start_pos[s] for every site.  Per step 16 x 64 words; every lane keeps its
+// own acceptance count (and / compare / add), nothing is reduced across lanes until A words have
+// been scanned (a site needs at least A words), after that one wave total per step, and only the
+// step in which the site's last draw falls is re-walked with ballots to get the exact word.
+#define M6A_SCAN_A_LOADS 16
+__global__ __launch_bounds__(256) void pool_scan_start_kernel(PoolArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const int A = a.T * a.K;
+    const uint32_t STEP = 64 * M6A_SCAN_A_LOADS;
+    const int64_t n_waves = (int64_t)gridDim.x * 4;
+    for (int64_t g = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); g < a.n_groups; g += n_waves) {
+        uint32_t pos = 0;
+        const int64_t s_end = a.goff[g + 1];
+        for (int64_t s = a.goff[g]; s < s_end; ++s) {
+            if (lane == 0) a.start_pos[s] = pos;
+            const int64_t n = a.off[s + 1] - a.off[s];
+            if (n <= 1) continue;                        // randint(0,1) draws no words
+            const uint32_t rng = (uint32_t)(n - 1);
+            const uint32_t mask = pow2_mask(rng);
+            if ((uint64_t)pos + 2 * STEP > (uint64_t)a.raw_len) { if (lane == 0) atomicExch(a.err, 1); return; }
+            uint32_t w[M6A_SCAN_A_LOADS], wn[M6A_SCAN_A_LOADS];
+#pragma unroll
+            for (int i = 0; i < M6A_SCAN_A_LOADS; i++) w[i] = a.raw[pos + 64 * i + lane];
+            int acc = 0;             // wave total of accepted words in steps already folded in
+            int carry = 0;           // per-lane count of steps not folded in yet
+            uint32_t scanned = 0;
+            for (;;) {
+                if ((uint64_t)pos + 2 * STEP > (uint64_t)a.raw_len) { if (lane == 0) atomicExch(a.err, 1); return; }
+#pragma unroll
+                for (int i = 0; i < M6A_SCAN_A_LOADS; i++) wn[i] = a.raw[pos + STEP + 64 * i + lane];
+                int cl = 0;
+#pragma unroll
+                for (int i = 0; i < M6A_SCAN_A_LOADS; i++) cl += ((w[i] & mask) <= rng) ? 1 : 0;
+                scanned += STEP;
+                if (scanned < (uint32_t)A) {             // uniform: cannot be the last step yet
+                    carry += cl;
+                } else {
+                    if (scanned - STEP < (uint32_t)A) { acc += wave_sum_i32(carry); carry = 0; }   // first total
+                    const int tot = wave_sum_i32(cl);
+                    if (acc + tot >= A) {
+                        // the site's last accepted draw is in this step: walk its loads in stream order
+#pragma unroll
+                        for (int i = 0; i < M6A_SCAN_A_LOADS; i++) {
+                            const bool ok = (w[i] & mask) <= rng;
+                            const unsigned long long bal = __ballot(ok);
+                            const int c = __popcll(bal);
+                            if (acc + c >= A) {
+                                const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32),
+                                                 __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0));
+                                const unsigned long long lastb = __ballot(ok && rank == A - acc - 1);
+                                pos += 64 * i + (uint32_t)__builtin_ctzll(lastb) + 1;
+                                break;
+                            }
+                            acc += c;
+                        }
+                        break;
+                    }
+                    acc += tot;
+                }
+                pos += STEP;
+#pragma unroll
+                for (int i = 0; i < M6A_SCAN_A_LOADS; i++) w[i] = wn[i];
+            }
+        }
+    }
+}
 
 // =====================================================================================
 // Site pooling, uniform bags (every site has the same n <= 32 reads), K = 20.

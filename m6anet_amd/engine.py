@@ -119,6 +119,10 @@ class M6ANetEngine:
         job (multi-GPU shards): flush groups and RNG restarts follow the job's batch indices."""
         self._chk(self._L.m6a_set_job_offset(self._h, int(first_site)))
 
+    def set_scan_driver(self, mode):
+        """0 auto, 1 one wavefront per flush group, 2 counting pass + one wavefront per site."""
+        self._chk(self._L.m6a_set_scan_driver(self._h, int(mode)))
+
     def sync(self):
         self._chk(self._L.m6a_sync(self._h))
 

@@ -121,7 +121,7 @@ def test_pool_bundled_golden(eng, golden, T, bs, spb, seed):
     g = golden("bundled_site.npz")
     key = f"T{T}_bs{bs}_spb{spb}_seed{seed}"
     site, mod = eng.calculate_site_proba(p, b["off"], T, 20, THR, seed, bs, spb)
-    assert eng.last_pool_variant == "scan"
+    assert eng.last_pool_variant.startswith("scan")
     assert np.abs(site - g[key + "_site"]).max() <= SITE_ATOL
     assert np.array_equal(mod, g[key + "_mod"])
 
@@ -131,7 +131,7 @@ def test_pool_synthetic_golden(eng, golden, T):
     g = golden("synthetic_small.npz")
     for tag, variant in (("uniform20", "table"), ("ragged", "scan")):
         site, mod = eng.calculate_site_proba(g[f"{tag}_readprob"], g[f"{tag}_off"], T, 20, THR)
-        assert eng.last_pool_variant == variant
+        assert eng.last_pool_variant.startswith(variant)
         assert np.abs(site - g[f"{tag}_site_T{T}"]).max() <= SITE_ATOL, tag
         assert np.array_equal(mod, g[f"{tag}_mod"]), tag
 
@@ -156,12 +156,17 @@ def test_pool_uniform_table_vs_oracle(eng, orc, n, T):
 def test_pool_scan_vs_oracle(eng, orc, bags):
     off = np.concatenate([[0], np.cumsum(bags)]).astype(np.int64)
     p = rand_probs(len(bags), off)
-    for T in (7, 100):
-        site, mod = eng.calculate_site_proba(p, off, T, 20, THR, seed=11)
-        assert eng.last_pool_variant == "scan"
-        want_site, want_mod = orc.site_pool(p, off, T, THR, seed=11)
-        assert np.abs(site - want_site).max() <= SITE_ATOL
-        assert np.array_equal(mod, want_mod)
+    try:
+        for T in (7, 100):
+            want_site, want_mod = orc.site_pool(p, off, T, THR, seed=11)
+            for driver, name in ((1, "scan-group"), (2, "scan-site"), (0, None)):
+                eng.set_scan_driver(driver)
+                site, mod = eng.calculate_site_proba(p, off, T, 20, THR, seed=11)
+                assert eng.last_pool_variant == (name or eng.last_pool_variant) and eng.last_pool_variant.startswith("scan")
+                assert np.abs(site - want_site).max() <= SITE_ATOL, (T, driver)
+                assert np.array_equal(mod, want_mod)
+    finally:
+        eng.set_scan_driver(0)
 
 
 @pytest.mark.parametrize("K", [1, 5, 19, 21, 64])
@@ -169,10 +174,15 @@ def test_pool_other_sample_counts(eng, orc, K):
     bags = [20, 25, 30, 100, 20, 33] * 6
     off = np.concatenate([[0], np.cumsum(bags)]).astype(np.int64)
     p = rand_probs(K, off)
-    site, mod = eng.calculate_site_proba(p, off, 50, K, THR, seed=5)
     want_site, want_mod = orc.site_pool(p, off, 50, THR, seed=5, n_samples=K)
-    assert np.abs(site - want_site).max() <= SITE_ATOL
-    assert np.array_equal(mod, want_mod)
+    try:
+        for driver in (1, 2):
+            eng.set_scan_driver(driver)
+            site, mod = eng.calculate_site_proba(p, off, 50, K, THR, seed=5)
+            assert np.abs(site - want_site).max() <= SITE_ATOL, driver
+            assert np.array_equal(mod, want_mod)
+    finally:
+        eng.set_scan_driver(0)
 
 
 @pytest.mark.parametrize("bs,spb", [(16, 2), (1, 2), (7, 3), (64, 2), (16, 1), (5, 5)])
@@ -225,9 +235,14 @@ def test_infer_end_to_end_vs_oracle(eng, orc, weights):
     assert np.abs(site - o_site).max() <= 1e-5
 
 
-def test_infer_ragged_end_to_end_vs_oracle(engines, orc, weights):
+@pytest.mark.parametrize("driver", [1, 2])
+def test_infer_ragged_end_to_end_vs_oracle(engines, orc, weights, driver):
     d = synthetic.make_sites(600, (50, 500), seed=5)
-    rp, site, mod = engines["hek293t_glori"].infer(d["X"], d["site_kmers"], d["off"], 1000)
+    engines["hek293t_glori"].set_scan_driver(driver)
+    try:
+        rp, site, mod = engines["hek293t_glori"].infer(d["X"], d["site_kmers"], d["off"], 1000)
+    finally:
+        engines["hek293t_glori"].set_scan_driver(0)
     p = orc.encode_reads(weights["hek293t_glori"], d["X"], d["site_kmers"], d["off"], n_threads=8)
     assert np.allclose(rp, p, rtol=1e-5, atol=1e-8)
     want_site, want_mod = orc.site_pool(rp, d["off"], 1000, THR, n_threads=8)

@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Side measurements for DESIGN.md (not the bench line): ragged bags (BASELINE configs[4] shape)
+through the scan kernel, configs[1] (100k sites, T=100), and the PCIe-inclusive host-pointer rate."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+from m6anet_amd import synthetic  # noqa: E402
+from m6anet_amd.engine import M6ANetEngine, load_weights  # noqa: E402
+
+
+def timed(eng, X, km, off, T, reps=5):
+    eng.infer(X, km, off, T)
+    eng.sync()
+    eng.profile(True)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        eng.infer(X, km, off, T)
+    eng.sync()
+    dt = (time.perf_counter() - t0) / reps
+    e, en = eng.profile_read(0)
+    p, pn = eng.profile_read(1)
+    eng.profile(False)
+    return dt, e / max(en, 1), p / max(pn, 1)
+
+
+def main():
+    dev = torch.device("cuda:0")
+    out = {}
+    for tag, model, S, bag, T in [("config1_100k_T100", "HCT116_RNA002", 100_000, 20, 100),
+                                  ("config4_ragged_200k_T1000", "HEK293T_RNA004", 200_000, (50, 500), 1000),
+                                  ("uniform33_200k_T1000_scan", "HCT116_RNA002", 200_000, 33, 1000)]:
+        eng = M6ANetEngine(weights=load_weights(model))
+        d = synthetic.make_sites(S, bag, seed=1)
+        X, km, off = (torch.from_numpy(d[k]).to(dev) for k in ("X", "site_kmers", "off"))
+        eng.use_torch_stream()
+        dt, e_ms, p_ms = timed(eng, X, km, off, T)
+        R = int(d["off"][-1])
+        out[tag] = {"sites": S, "reads": R, "T": T, "pool": eng.last_pool_variant, "ms_per_call": dt * 1e3,
+                    "sites_per_s": S / dt, "enc_ms": e_ms, "pool_ms": p_ms,
+                    "enc_TFLOPs": 14164 * R / (e_ms * 1e-3) / 1e12, "pool_Gdraws_per_s": S * T * 20 / (p_ms * 1e-3) / 1e9}
+        if tag.startswith("config1"):
+            eng.set_stream(None)
+            t0 = time.perf_counter()
+            for _ in range(3):
+                eng.infer(d["X"], d["site_kmers"], d["off"], T)
+            out[tag]["host_pointer_sites_per_s"] = S * 3 / (time.perf_counter() - t0)
+        eng.close()
+    # PCIe-inclusive rate of the bench workload (host numpy arrays in, host arrays out)
+    eng = M6ANetEngine(weights=load_weights())
+    d = synthetic.make_sites(1_000_000, 20, seed=2)
+    eng.infer(d["X"], d["site_kmers"], d["off"], 1000)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        eng.infer(d["X"], d["site_kmers"], d["off"], 1000)
+    out["bench_workload_host_pointers"] = {"sites_per_s": 3e6 / (time.perf_counter() - t0),
+                                           "note": "pageable numpy buffers, hipMemcpyAsync staging, synchronous call"}
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
