@@ -125,6 +125,11 @@ int m6a_shard_plan(const int64_t *off, int64_t n_sites, int64_t batch_size, int6
  * kind: 0 = read encoder, 1 = site pooling.  m6a_profile_read synchronises the stream. */
 int m6a_profile_enable(m6a_ctx *ctx, int on);
 int m6a_profile_read(m6a_ctx *ctx, int kind, double *total_ms, int64_t *n_launches);
+/* Tuning knob for the read encoder: 0 = auto (default), 1 = general kernel (16 K-slots, any bags),
+ * 2 = 12-slot kernel (per-site constants folded; requires every bag >= 16 reads -- a call that
+ * violates this reports M6A_EINVAL at the next sync).  Results agree to float32 rounding. */
+int m6a_set_encoder_variant(m6a_ctx *ctx, int mode);
+const char *m6a_last_encoder_variant(const m6a_ctx *ctx);   /* "general16" | "csite12" */
 /* Tuning knob for ragged bags: 0 = choose by available parallelism (default), 1 = one wavefront
  * per flush group, 2 = counting pass + one wavefront per site.  Results are identical. */
 int m6a_set_scan_driver(m6a_ctx *ctx, int mode);

@@ -54,7 +54,7 @@ struct m6a_ctx {
     hipStream_t stream = nullptr;
     std::string err;
     // model
-    float *d_wfrag = nullptr, *d_emb = nullptr;
+    float *d_wfrag = nullptr, *d_wfrag2 = nullptr, *d_w1e = nullptr, *d_emb = nullptr;
     float b3 = 0.f;
     // sampling state (device) + what it was built for
     DevBuf raw, tab, goff, rp_scratch, off_scratch, start_pos;
@@ -63,6 +63,8 @@ struct m6a_ctx {
     struct { int64_t S, bs, spb, base, G, gmax; bool valid; } goff_key = {0, 0, 0, 0, 0, 0, false};
     int64_t job_offset = 0;
     int64_t bag_min = 0, bag_max = 0, n_reads = 0;   // last query_bags()
+    int enc_variant = 0;                              // 0 auto, 1 general 16-slot, 2 12-slot (bags >= 16)
+    const char *enc_variant_used = "none";
     int scan_driver = 0;                              // 0 auto, 1 per group, 2 counting pass + per site
     int *d_err = nullptr;
     unsigned long long *d_minmax = nullptr;
@@ -111,7 +113,7 @@ bool is_device_ptr(const void *p)
 enum { O_E = 0, O_W1 = 132, O_B1 = 2382, O_G = 2532, O_BE = 2682, O_MU = 2832, O_VAR = 2982,
        O_W2 = 3132, O_B2 = 7932, O_W3 = 7964, O_B3 = 7996 };
 
-void build_fragments(const float *w, std::vector<float> &frag)
+void build_fragments(const float *w, std::vector<float> &frag, std::vector<float> &frag2, std::vector<float> &w1e)
 {
     // W1aug[160][16]: columns 0..14 = alpha*W1, column 15 = alpha*b1 + (beta - mean*alpha)
     // (torch eval BatchNorm1d: y*alpha + beta - mean*alpha, alpha = gamma/sqrt(var+eps), blocks.py:250);
@@ -143,6 +145,22 @@ void build_fragments(const float *w, std::vector<float> &frag)
         for (int q = 0; q < 16; q++)
             frag[(120 + q) * 64 + lane] = w[O_W3 + (q & 3) + 8 * (q >> 2) + 4 * half];
     }
+    // 12-slot kernel: x-slot fragments W1'[u][2st+half] (st<4), W1'[u][8]; and the per-unit rows the
+    // per-site c vectors are folded from: W1'[u][9..14], b1'[u]  (w1 column 15 is the folded bias)
+    frag2.assign(M6A_WFRAG2_FLOATS, 0.f);
+    w1e.assign(M6A_W1E_FLOATS, 0.f);
+    for (int lane = 0; lane < 64; lane++) {
+        const int col = lane & 31, half = lane >> 5;
+        for (int m = 0; m < 5; m++) {
+            for (int st = 0; st < 4; st++) frag2[(m * 4 + st) * 64 + lane] = w1[(32 * m + col) * 16 + 2 * st + half];
+            frag2[(20 + m) * 64 + lane] = w1[(32 * m + col) * 16 + 8];
+        }
+    }
+    for (int m = 0; m < 5; m++)
+        for (int col = 0; col < 32; col++) {
+            for (int e = 0; e < 6; e++) w1e[(m * 7 + e) * 32 + col] = w1[(32 * m + col) * 16 + 9 + e];
+            w1e[(m * 7 + 6) * 32 + col] = w1[(32 * m + col) * 16 + 15];
+        }
 }
 
 // ---- flush groups (inference_utils.py:33,47) --------------------------------------------------
@@ -258,6 +276,8 @@ void prof_end(m6a_ctx *c, int kind)
     p.used[kind]++;
 }
 
+void host_bag_range(m6a_ctx *c, const int64_t *off, int64_t S);
+
 // bag-size range (decides the pooling kernel) and total reads: one 24-byte read-back, which
 // blocks on the stream
 int query_bags(m6a_ctx *c, const int64_t *d_off, int64_t S)
@@ -276,19 +296,26 @@ int query_bags(m6a_ctx *c, const int64_t *d_off, int64_t S)
 }
 
 // ---- launches (all pointers are device pointers here) ------------------------------------------
+// c->bag_min must describe `off` (query_bags / host_bag_range ran for this call)
 int launch_encode(m6a_ctx *c, const float *X, const uint8_t *km, const int64_t *off, int64_t S,
                   int64_t R, float *rp)
 {
     if (R <= 0 || S <= 0) return M6A_OK;
     EncArgs a;
     a.X = X; a.site_kmers = km; a.off = off; a.wfrag = c->d_wfrag; a.emb = c->d_emb; a.read_prob = rp;
+    a.wfrag2 = c->d_wfrag2; a.w1e_tab = c->d_w1e; a.err = c->d_err;
     a.n_sites = S; a.n_reads = R; a.n_tiles = (R + 31) / 32; a.b3 = c->b3;
     const int64_t max_waves = (int64_t)c->n_cu * 8;        // 2 blocks/CU x 4 waves
     a.tiles_per_wave = (a.n_tiles + max_waves - 1) / max_waves;
     const int64_t waves = (a.n_tiles + a.tiles_per_wave - 1) / a.tiles_per_wave;
     const unsigned blocks = (unsigned)((waves + 3) / 4);
+    // every bag >= 16 reads: a 32-read tile spans <= 3 sites -> 12-slot layer 1 (110 MFMAs per tile);
+    // otherwise the general 16-slot kernel (120)
+    const bool csite = c->enc_variant ? c->enc_variant == 2 : c->bag_min >= M6A_CSITE_MIN_BAG;
+    c->enc_variant_used = csite ? "csite12" : "general16";
     prof_begin(c, 0);
-    hipLaunchKernelGGL(enc_kernel, dim3(blocks), dim3(256), 0, c->stream, a);
+    if (csite) hipLaunchKernelGGL(enc_csite_kernel, dim3(blocks), dim3(256), 0, c->stream, a);
+    else hipLaunchKernelGGL(enc_kernel, dim3(blocks), dim3(256), 0, c->stream, a);
     prof_end(c, 0);
     HIPCHK(c, hipGetLastError());
     return M6A_OK;
@@ -381,7 +408,12 @@ int check_pool_args(m6a_ctx *c, int64_t S, int T, int K, int rng_mode, int64_t b
 int deferred_error(m6a_ctx *c)
 {
     // stream is idle here
-    if (*c->h_err) { *c->h_err = 0; return fail(c, M6A_ESTREAM, "MT19937 stream too short for a flush group"); }
+    if (*c->h_err) {
+        const int e = *c->h_err;
+        *c->h_err = 0;
+        if (e == 2) return fail(c, M6A_EINVAL, "encoder: a 32-read tile spans more than 3 sites (bag < 16 reads) in the 12-slot kernel");
+        return fail(c, M6A_ESTREAM, "MT19937 stream too short for a flush group");
+    }
     return M6A_OK;
 }
 
@@ -441,9 +473,13 @@ int m6a_create(m6a_ctx **out, const float *weights, size_t n_floats, int device_
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     CRCHK(hipStreamCreate(&c->own_stream));
     c->stream = c->own_stream;
-    std::vector<float> frag;
-    build_fragments(weights, frag);
+    std::vector<float> frag, frag2, w1e;
+    build_fragments(weights, frag, frag2, w1e);
     CRCHK(hipMalloc((void **)&c->d_wfrag, frag.size() * sizeof(float)));
+    CRCHK(hipMalloc((void **)&c->d_wfrag2, frag2.size() * sizeof(float)));
+    CRCHK(hipMalloc((void **)&c->d_w1e, w1e.size() * sizeof(float)));
+    CRCHK(hipMemcpy(c->d_wfrag2, frag2.data(), frag2.size() * sizeof(float), hipMemcpyHostToDevice));
+    CRCHK(hipMemcpy(c->d_w1e, w1e.data(), w1e.size() * sizeof(float), hipMemcpyHostToDevice));
     CRCHK(hipMalloc((void **)&c->d_emb, 132 * sizeof(float)));
     CRCHK(hipMemcpy(c->d_wfrag, frag.data(), frag.size() * sizeof(float), hipMemcpyHostToDevice));
     CRCHK(hipMemcpy(c->d_emb, weights + O_E, 132 * sizeof(float), hipMemcpyHostToDevice));
@@ -471,6 +507,8 @@ void m6a_destroy(m6a_ctx *c)
     for (DevBuf *b : {&c->raw, &c->tab, &c->goff, &c->rp_scratch, &c->off_scratch, &c->start_pos, &c->sX, &c->sK, &c->sOff,
                       &c->sP, &c->sSite, &c->sMod}) b->release();
     if (c->d_wfrag) (void)hipFree(c->d_wfrag);
+    if (c->d_wfrag2) (void)hipFree(c->d_wfrag2);
+    if (c->d_w1e) (void)hipFree(c->d_w1e);
     if (c->d_emb) (void)hipFree(c->d_emb);
     if (c->d_err) (void)hipFree(c->d_err);
     if (c->d_minmax) (void)hipFree(c->d_minmax);
@@ -494,6 +532,16 @@ int m6a_set_job_offset(m6a_ctx *c, int64_t first_site)
     c->job_offset = first_site;
     return M6A_OK;
 }
+
+int m6a_set_encoder_variant(m6a_ctx *c, int mode)
+{
+    if (!c) return M6A_EINVAL;
+    if (mode < 0 || mode > 2) return fail(c, M6A_EINVAL, "encoder variant must be 0 (auto), 1 (16-slot) or 2 (12-slot)");
+    c->enc_variant = mode;
+    return M6A_OK;
+}
+
+const char *m6a_last_encoder_variant(const m6a_ctx *c) { return c ? c->enc_variant_used : "none"; }
 
 int m6a_set_scan_driver(m6a_ctx *c, int mode)
 {
@@ -532,17 +580,16 @@ int m6a_encode_reads(m6a_ctx *c, const float *X, const uint8_t *km, const int64_
         HIPCHK(c, hipMemcpyAsync(c->sX.p, X, (size_t)R * 9 * 4, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(c->sK.p, km, (size_t)S * 3, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(c->sOff.p, off, (size_t)(S + 1) * 8, hipMemcpyHostToDevice, c->stream));
+        host_bag_range(c, off, S);
         int rc = launch_encode(c, (const float *)c->sX.p, (const uint8_t *)c->sK.p, (const int64_t *)c->sOff.p, S, R, (float *)c->sP.p);
         if (rc) return rc;
         HIPCHK(c, hipMemcpyAsync(rp, c->sP.p, (size_t)R * 4, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        return M6A_OK;
+        return sync_and_check(c);
     }
-    // device pointers: R = off[S] is needed for the grid; 8-byte read-back
-    int64_t R = 0;
-    HIPCHK(c, hipMemcpyAsync(&R, off + S, 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    return launch_encode(c, X, km, off, S, R, rp);
+    // device pointers: total reads (grid size) and smallest bag (kernel choice): one read-back
+    int rc = query_bags(c, off, S);
+    if (rc) return rc;
+    return launch_encode(c, X, km, off, S, c->n_reads, rp);
 }
 
 int m6a_site_pool(m6a_ctx *c, const float *rp, const int64_t *off, int64_t S, int T, int K, float thr,
@@ -613,9 +660,9 @@ int m6a_infer(m6a_ctx *c, const float *X, const uint8_t *km, const int64_t *off,
     HIPCHK(c, hipMemcpyAsync(c->sX.p, X, (size_t)R * 9 * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->sK.p, km, (size_t)S * 3, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->sOff.p, off, (size_t)(S + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    host_bag_range(c, off, S);
     rc = launch_encode(c, (const float *)c->sX.p, (const uint8_t *)c->sK.p, (const int64_t *)c->sOff.p, S, R, (float *)c->sP.p);
     if (rc) return rc;
-    host_bag_range(c, off, S);
     rc = launch_pool(c, (const float *)c->sP.p, (const int64_t *)c->sOff.p, S, T, K, thr, seed, bs, spb,
                      (float *)c->sSite.p, (double *)c->sMod.p);
     if (rc) return rc;
@@ -651,6 +698,7 @@ int m6a_bag_forward(m6a_ctx *c, const float *X, const uint8_t *km, int64_t B, in
         HIPCHK(c, hipMemcpyAsync(c->sK.p, km, (size_t)B * 3, hipMemcpyHostToDevice, c->stream));
         dX = (const float *)c->sX.p; dK = (const uint8_t *)c->sK.p; dS = (float *)c->sSite.p;
     }
+    c->bag_min = c->bag_max = bag; c->n_reads = R;
     int rc = launch_encode(c, dX, dK, d_off, B, R, d_p);
     if (rc) return rc;
     hipLaunchKernelGGL(bag_noisy_or_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, c->stream, d_p, B, bag, dS);

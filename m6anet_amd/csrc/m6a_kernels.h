@@ -6,15 +6,21 @@
 
 #define M6A_BAG_LDS 1024          // reads of a bag kept in LDS by pool_scan_kernel (rest: global)
 #define M6A_WFRAG_FLOATS (136 * 64)   // 40 (W1) + 80 (W2) + 16 (W3) registers x 64 lanes
+#define M6A_WFRAG2_FLOATS (25 * 64)   // 20 (W1 x-slots) + 5 (W1[:,8]) registers x 64 lanes
+#define M6A_W1E_FLOATS (35 * 32)
+#define M6A_CSITE_MIN_BAG 16          // enc_csite_kernel: a 32-read tile must span <= 3 sites
 #define M6A_TABLE_MAX_N 32        // pool_table_kernel: byte offsets 8*idx must fit a byte
 
 struct EncArgs {
     const float *X;               // [R][9]
     const uint8_t *site_kmers;    // [S][3]
     const int64_t *off;           // [S+1]
-    const float *wfrag;           // [136][64] lane-major MFMA weight fragments
+    const float *wfrag;           // [136][64] lane-major MFMA weight fragments (16-slot kernel; W2/W3 shared)
+    const float *wfrag2;          // [25][64]  layer-1 fragments of the 12-slot kernel
+    const float *w1e_tab;         // [35][32]  W1'[:, 9..14] and b1' per unit, for the per-site c vectors
     const float *emb;             // [66][2]
     float *read_prob;             // [R]
+    int *err;
     int64_t n_sites, n_reads, n_tiles, tiles_per_wave;
     float b3;
 };
@@ -35,6 +41,7 @@ struct PoolArgs {
 };
 
 __global__ void enc_kernel(EncArgs a);
+__global__ void enc_csite_kernel(EncArgs a);
 __global__ void pool_scan_start_kernel(PoolArgs a);
 template <int KT> __global__ void pool_scan_group_kernel(PoolArgs a);
 template <int KT> __global__ void pool_scan_site_kernel(PoolArgs a);

@@ -43,6 +43,14 @@ __device__ __forceinline__ float relu_bits(float x)
     return __builtin_bit_cast(float, b > 0 ? b : 0);
 }
 
+// A value the program knows to be wave-uniform, made provably so: addresses built from it use
+// scalar loads (s_load, counted by lgkmcnt) instead of vector loads (in-order vmcnt queue).
+__device__ __forceinline__ int64_t uniform_i64(int64_t v)
+{
+    return ((int64_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
+           (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+
 // Orders this wave's LDS traffic: LDS ops of one wave execute in issue order, so a compiler
 // fence (no s_barrier) is all a single-wave producer/consumer needs.
 __device__ __forceinline__ void wave_lds_fence()
@@ -117,25 +125,20 @@ __global__ __launch_bounds__(256, 2) void enc_kernel(EncArgs a)
     const int64_t last_site = a.n_sites - 1;
 
     // ---- the three links of the input chain for one tile -------------------------------------
-    // link 0: issue the x loads and the three CSR offsets after the base site
-    auto link0 = [&](int64_t tile, int64_t base, float (&x)[8], int64_t (&o)[3], int64_t &rc) {
-        const int64_t r = tile * 32 + col;
-        rc = r < a.n_reads ? r : a.n_reads - 1;
-        const float *xp = a.X + rc * 9;
-        if (half == 0) {
-#pragma unroll
-            for (int i = 0; i < 8; i++) x[i] = xp[i];
-        } else {
-            x[0] = xp[8];
-        }
+    // link 0: the three CSR offsets after the base site (base is wave-uniform)
+    auto link0 = [&](int64_t base, int64_t (&o)[3]) {
 #pragma unroll
         for (int i = 0; i < 3; i++) {
             const int64_t si = base + 1 + i;
             o[i] = a.off[si <= a.n_sites ? si : a.n_sites];
         }
     };
-    // link 1: pick the lane's site, issue its k-mer id loads
-    auto link1 = [&](int64_t base, const int64_t (&o)[3], int64_t rc, int64_t &s, int (&km)[3]) {
+    // link 1: pick the lane's site, issue its k-mer id loads, THEN the x loads: vector loads retire
+    // in order, so the k-mer ids (needed two links from now) must not queue behind the x stream
+    // (needed only by the next tile)
+    auto link1 = [&](int64_t tile, int64_t base, const int64_t (&o)[3], int64_t &s, int (&km)[3], float (&x)[8]) {
+        const int64_t r = tile * 32 + col;
+        const int64_t rc = r < a.n_reads ? r : a.n_reads - 1;
         s = base + (rc >= o[0] ? 1 : 0) + (rc >= o[1] ? 1 : 0);
         if (__any(rc >= o[2])) {                 // bags smaller than 16 reads: walk
             s = base;
@@ -144,6 +147,13 @@ __global__ __launch_bounds__(256, 2) void enc_kernel(EncArgs a)
         s = s < last_site ? s : last_site;
         const uint8_t *kp = a.site_kmers + s * 3;
         km[0] = kp[0]; km[1] = kp[1]; km[2] = kp[2];
+        // every lane issues the same 8 loads (no divergent branch, so nothing has to be merged and
+        // waited for here): half 0 reads x0..x7; half 1 reads x8 into x[0] and re-reads x1..x7,
+        // which link 2 overwrites
+        const float *xp = a.X + rc * 9;
+        x[0] = xp[half ? 8 : 0];
+#pragma unroll
+        for (int i = 1; i < 8; i++) x[i] = xp[i];
     };
     // link 2: embedding rows from LDS
     auto link2 = [&](const int (&km)[3], float (&x)[8]) {
@@ -157,23 +167,23 @@ __global__ __launch_bounds__(256, 2) void enc_kernel(EncArgs a)
 
     // prologue: first tile, unpipelined
     float f[8];
+    s_base = uniform_i64(s_base);
     {
-        int64_t o[3], rc, s;
+        int64_t o[3], s;
         int km[3];
-        link0(tile0, s_base, f, o, rc);
-        link1(s_base, o, rc, s, km);
+        link0(s_base, o);
+        link1(tile0, s_base, o, s, km, f);
         link2(km, f);
-        s_base = __shfl(s, 31, 64);
+        s_base = uniform_i64(__shfl(s, 31, 64));
     }
 
     for (int64_t tile = tile0; tile < tile1; ++tile) {
-        const bool more = tile + 1 < tile1;        // wave-uniform
+        // the chain always runs (for the last tile it refetches that tile): no guard, no merge
+        const int64_t tn = tile + 1 < tile1 ? tile + 1 : tile;
         float fn[8];
-        int64_t o[3], rcn = 0, sn = 0;
-        int km[3] = {0, 0, 0};
-#pragma unroll
-        for (int i = 0; i < 8; i++) fn[i] = 0.0f;
-        if (more) link0(tile + 1, s_base, fn, o, rcn);
+        int64_t o[3], sn;
+        int km[3];
+        link0(s_base, o);
 
         // Layer 1 of unit-tile m+1 is issued ahead of layer 2 of unit-tile m (ping-pong
         // accumulators).  ReLU is applied to a finished tile as one batch of 16 v_max_i32 and
@@ -197,8 +207,8 @@ __global__ __launch_bounds__(256, 2) void enc_kernel(EncArgs a)
                     nxt = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[(m + 1) * 8 + st], f[st], nxt, 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (m == 1 && more) link1(s_base, o, rcn, sn, km);
-            if (m == 3 && more) link2(km, fn);
+            if (m == 0) link1(tn, s_base, o, sn, km, fn);
+            if (m == 2) link2(km, fn);
 #pragma unroll
             for (int q = 0; q < 16; q++) cur[q] = relu_bits(cur[q]);
             __builtin_amdgcn_sched_barrier(0);
@@ -215,11 +225,192 @@ __global__ __launch_bounds__(256, 2) void enc_kernel(EncArgs a)
         const float p = 1.0f / (1.0f + expf(-z));
         const int64_t r = tile * 32 + col;
         if (half == 0 && r < a.n_reads) a.read_prob[r] = p;
-        if (more) {
-            s_base = __shfl(sn, 31, 64);
+        if (tn != tile) s_base = uniform_i64(__shfl(sn, 31, 64));
 #pragma unroll
-            for (int i = 0; i < 8; i++) f[i] = fn[i];
+        for (int i = 0; i < 8; i++) f[i] = fn[i];
+    }
+}
+
+// =====================================================================================
+// Read encoder, 12-slot variant (calls whose bags all have >= 16 reads).
+//
+// Six of the 16 inputs (the three k-mer embeddings) and the bias are constant per SITE, and a
+// 32-read tile that starts in site `a` ends by site a+2 when bags have >= 16 reads.  Layer 1 is
+// therefore run with K = 12 slots instead of 16:
+//     slots 0..8   the nine signal features, against W1'[:, 0..8];
+//     slots 9..11  one-hot "read belongs to site a / a+1 / a+2", against the per-site vectors
+//                  c_s[u] = b1'[u] + sum_e W1'[u][9+e] * emb_e(s)          (exact same terms),
+// i.e. 6 K-steps per unit tile instead of 8: 110 MFMAs per tile instead of 120.  The c vectors
+// (A operands of the indicator steps) are rebuilt for every tile on the VALU, in the shadow of the
+// matrix pipe: the 18 embedding floats of the three sites are fetched by lanes 0..17, broadcast
+// with v_readlane, and folded against W1'[:, 9..14] (kept in LDS, one row per lane) with 60 FMAs.
+// Lane halves: h=0 supplies slots x0,x2,x4,x6,x8,I(a+1); h=1 supplies x1,x3,x5,x7,I(a),I(a+2).
+// Everything else (layer 2, ReLU batching, ping-pong, epilogue, input prefetch chain) is as in
+// enc_kernel.  A tile that would need a fourth site raises the error flag (the host only
+// launches this kernel when the smallest bag has >= 16 reads).
+// =====================================================================================
+__global__ __launch_bounds__(256, 2) void enc_csite_kernel(EncArgs a)
+{
+    __shared__ float s_emb[132];
+    __shared__ float s_w1e[35 * 32];             // [m*7 + e][col]: W1'[32m+col][9+e] (e<6), b1'[32m+col] (e=6)
+    for (int i = threadIdx.x; i < 132; i += 256) s_emb[i] = a.emb[i];
+    for (int i = threadIdx.x; i < 35 * 32; i += 256) s_w1e[i] = a.w1e_tab[i];
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int col = lane & 31;
+    const int half = lane >> 5;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t tile0 = wave * a.tiles_per_wave;
+    if (tile0 >= a.n_tiles) return;
+    const int64_t tile1 = (tile0 + a.tiles_per_wave < a.n_tiles) ? tile0 + a.tiles_per_wave : a.n_tiles;
+
+    // static weight fragments: w1x[m*4+st] = W1'[32m+col][2st+half], w8[m] = W1'[32m+col][8]
+    float w1x[20], w8[5], w2[80], w3[16];
+#pragma unroll
+    for (int i = 0; i < 20; i++) w1x[i] = a.wfrag2[i * 64 + lane];
+#pragma unroll
+    for (int i = 0; i < 5; i++) w8[i] = a.wfrag2[(20 + i) * 64 + lane];
+#pragma unroll
+    for (int i = 0; i < 80; i++) w2[i] = a.wfrag[(40 + i) * 64 + lane];
+#pragma unroll
+    for (int i = 0; i < 16; i++) w3[i] = a.wfrag[(120 + i) * 64 + lane];
+
+    int64_t s_base;
+    {
+        const int64_t r = tile0 * 32;
+        int64_t lo = 0, hi = a.n_sites;          // invariant: off[lo] <= r < off[hi]
+        while (hi - lo > 1) {
+            int64_t mid = (lo + hi) >> 1;
+            if (a.off[mid] <= r) lo = mid; else hi = mid;
         }
+        s_base = lo;
+    }
+    const int64_t last_site = a.n_sites - 1;
+
+    // ---- input chain of one tile ----------------------------------------------------------------
+    // link0: the three CSR offsets after the base site -- scalar loads (base is uniform)
+    auto link0 = [&](int64_t base, int64_t (&o)[3]) {
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            const int64_t si = base + 1 + i;
+            o[i] = a.off[si <= a.n_sites ? si : a.n_sites];
+        }
+    };
+    // link1: the lane's site relative to base; lanes 0..17 fetch the k-mer id their embedding
+    // float belongs to (float q of site base + q/6 is E[kmer (q%6)/2][q&1]); THEN the x loads
+    // (4 per lane, + x8 on half 0) -- vector loads retire in order, the k-mer ids must not queue
+    // behind the x stream
+    auto link1 = [&](int64_t tile, int64_t base, const int64_t (&o)[3], int &rel, int &kid, float (&x)[5]) {
+        const int64_t r = tile * 32 + col;
+        const int64_t rc = r < a.n_reads ? r : a.n_reads - 1;
+        rel = (rc >= o[0] ? 1 : 0) + (rc >= o[1] ? 1 : 0);
+        if (__any(rc >= o[2])) atomicExch(a.err, 2);         // would need a 4th site: precondition broken
+        const int q = lane < 18 ? lane : 17;                 // every lane loads a valid byte: no merge
+        int64_t ks = base + q / 6;
+        ks = ks < last_site ? ks : last_site;
+        kid = (int)a.site_kmers[ks * 3 + (q % 6) / 2];
+        const float *xp = a.X + rc * 9 + half;
+#pragma unroll
+        for (int i = 0; i < 4; i++) x[i] = xp[2 * i];
+        x[4] = xp[half ? 6 : 8];                             // x8 on half 0 (half 1: a valid dummy)
+    };
+    // link2: the embedding float itself
+    auto link2 = [&](int kid, float &ev) { ev = s_emb[2 * kid + (lane & 1)]; };
+    // link3: c vectors -> A operands of the two indicator steps, indicator B operands
+    // (x8 is the value loaded for slot 4 on half 0; in place: a4/a5/x[4..5] of the running tile are
+    // dead once layer 1 of its last unit tile has issued)
+    auto link3 = [&](float ev, int rel, float x8, float (&x)[6], float (&a4)[5], float (&a5)[5]) {
+        float e[18];
+#pragma unroll
+        for (int q = 0; q < 18; q++)
+            e[q] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ev), q));
+        float eP[6];
+#pragma unroll
+        for (int q = 0; q < 6; q++) eP[q] = half ? e[q] : e[6 + q];          // h=1: site a, h=0: site a+1
+#pragma unroll
+        for (int m = 0; m < 5; m++) {
+            const float *wr = s_w1e + (m * 7) * 32 + col;
+            float cP = wr[6 * 32], cQ = wr[6 * 32];
+#pragma unroll
+            for (int q = 0; q < 6; q++) {
+                const float wq = wr[q * 32];
+                cP = fmaf(wq, eP[q], cP);
+                cQ = fmaf(wq, e[12 + q], cQ);                                 // site a+2
+            }
+            a4[m] = half ? cP : w8[m];           // step 4: h=0 x8, h=1 I(a)
+            a5[m] = half ? cQ : cP;              // step 5: h=0 I(a+1), h=1 I(a+2)
+        }
+        x[4] = half ? (rel == 0 ? 1.0f : 0.0f) : x8;
+        x[5] = (rel == (half ? 2 : 1)) ? 1.0f : 0.0f;
+    };
+
+    // prologue: first tile, unpipelined
+    float f[6], a4[5], a5[5];
+    s_base = uniform_i64(s_base);
+    {
+        int64_t o[3];
+        int rel, kid;
+        float ev, x5[5];
+        link0(s_base, o);
+        link1(tile0, s_base, o, rel, kid, x5);
+#pragma unroll
+        for (int i = 0; i < 4; i++) f[i] = x5[i];
+        link2(kid, ev);
+        link3(ev, rel, x5[4], f, a4, a5);
+        s_base += __builtin_amdgcn_readfirstlane(__shfl(rel, 31, 64));
+    }
+
+    for (int64_t tile = tile0; tile < tile1; ++tile) {
+        // the chain always runs (for the last tile it refetches that tile): no guard, no merge
+        const int64_t tn = tile + 1 < tile1 ? tile + 1 : tile;
+        float fn[5], evn;
+        int64_t o[3];
+        int reln, kidn;
+        link0(s_base, o);
+
+        auto layer1 = [&](int m, f32x16 &acc) {
+#pragma unroll
+            for (int q = 0; q < 16; q++) acc[q] = 0.0f;
+#pragma unroll
+            for (int st = 0; st < 4; st++)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w1x[m * 4 + st], f[st], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[m], f[4], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a5[m], f[5], acc, 0, 0, 0);
+        };
+
+        f32x16 acc2, h1a, h1b;
+#pragma unroll
+        for (int q = 0; q < 16; q++) acc2[q] = 0.0f;
+        layer1(0, h1a);
+#pragma unroll
+        for (int m = 0; m < 5; m++) {
+            f32x16 &cur = (m & 1) ? h1b : h1a;
+            f32x16 &nxt = (m & 1) ? h1a : h1b;
+            if (m < 4) layer1(m + 1, nxt);
+            __builtin_amdgcn_sched_barrier(0);
+            if (m == 0) link1(tn, s_base, o, reln, kidn, fn);
+            if (m == 1) link2(kidn, evn);
+            if (m == 3) link3(evn, reln, fn[4], f, a4, a5);             // layer1(4) has issued: in place
+#pragma unroll
+            for (int q = 0; q < 16; q++) cur[q] = relu_bits(cur[q]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 16; q++)
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(w2[m * 16 + q], cur[q], acc2, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        float z = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 16; q++) z = fmaf(relu_bits(acc2[q]), w3[q], z);
+        z += __shfl_xor(z, 32, 64);
+        z += a.b3;
+        const float p = 1.0f / (1.0f + expf(-z));
+        const int64_t r = tile * 32 + col;
+        if (half == 0 && r < a.n_reads) a.read_prob[r] = p;
+        if (tn != tile) s_base += __builtin_amdgcn_readfirstlane(__shfl(reln, 31, 64));
+#pragma unroll
+        for (int i = 0; i < 4; i++) f[i] = fn[i];
     }
 }
 

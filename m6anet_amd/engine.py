@@ -119,6 +119,14 @@ class M6ANetEngine:
         job (multi-GPU shards): flush groups and RNG restarts follow the job's batch indices."""
         self._chk(self._L.m6a_set_job_offset(self._h, int(first_site)))
 
+    def set_encoder_variant(self, mode):
+        """0 auto, 1 general 16-slot kernel, 2 12-slot kernel (needs every bag >= 16 reads)."""
+        self._chk(self._L.m6a_set_encoder_variant(self._h, int(mode)))
+
+    @property
+    def last_encoder_variant(self):
+        return self._L.m6a_last_encoder_variant(self._h).decode()
+
     def set_scan_driver(self, mode):
         """0 auto, 1 one wavefront per flush group, 2 counting pass + one wavefront per site."""
         self._chk(self._L.m6a_set_scan_driver(self._h, int(mode)))

@@ -96,6 +96,44 @@ def test_encoder_extreme_inputs(eng, orc, weights):
     assert np.allclose(got, want, rtol=1e-5, atol=1e-8)
 
 
+@pytest.mark.parametrize("variant,name", [(1, "general16"), (2, "csite12")])
+@pytest.mark.parametrize("bags", [[16] * 50, [20] * 333, [16, 17, 40, 16, 700, 16, 16, 33], list(range(16, 120)),
+                                  [32] * 9 + [31] * 9, [1000, 16, 16, 16, 2000]])
+def test_encoder_variants_vs_oracle(engines, orc, weights, variant, name, bags):
+    """Both layer-1 formulations (16 K-slots; 12 K-slots with per-site constants folded) on bags of
+    >= 16 reads, all four checkpoints' topology via two of them."""
+    X, km, off = rand_sites(sum(bags) % 97 + variant, bags)
+    for model in ("hct116", "hek293t_m6ace"):
+        e = engines[model]
+        e.set_encoder_variant(variant)
+        try:
+            got = e.get_read_probability(X, km, off)
+            assert e.last_encoder_variant == name
+        finally:
+            e.set_encoder_variant(0)
+        want = orc.encode_reads(weights[model], X, km, off)
+        assert np.allclose(got, want, rtol=1e-5, atol=1e-8), (model, name)
+
+
+def test_encoder_variant_selection_and_precondition(eng):
+    from m6anet_amd._lib import M6AError
+    X, km, off = rand_sites(1, [20] * 40)
+    eng.get_read_probability(X, km, off)
+    assert eng.last_encoder_variant == "csite12"
+    X, km, off = rand_sites(2, [20] * 40 + [15])
+    eng.get_read_probability(X, km, off)
+    assert eng.last_encoder_variant == "general16"            # one bag of 15 reads: general kernel
+    X, km, off = rand_sites(3, [3] * 200)
+    eng.set_encoder_variant(2)                                # forcing the 12-slot kernel on small bags
+    try:
+        with pytest.raises(M6AError):
+            eng.get_read_probability(X, km, off)              # is reported, not silently wrong
+    finally:
+        eng.set_encoder_variant(0)
+    got = eng.get_read_probability(X, km, off)                # and the context keeps working
+    assert np.all(np.isfinite(got))
+
+
 def test_encoder_empty(eng):
     out = eng.get_read_probability(np.zeros((0, 9), np.float32), np.zeros((0, 3), np.uint8), np.zeros(1, np.int64))
     assert out.shape == (0,)
