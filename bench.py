@@ -78,6 +78,7 @@ def main():
     ap.add_argument("--reads", type=int, default=20, help="reads per site")
     ap.add_argument("--iters", type=int, default=1000, help="num_iterations")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--enc-variant", type=int, default=0, help="0 auto, 1 general 16-slot, 2 12-slot encoder kernel")
     args = ap.parse_args()
 
     import torch
@@ -90,13 +91,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+    # M6A_BENCH_BACKEND=gloo is a debugging aid (ranks may then share a GPU, the gather is staged
+    # through host memory); the real multi-GPU run is RCCL: backend "nccl", one GPU per rank
+    backend = os.environ.get("M6A_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        mdist.init_from_env(backend, device_id=dev if backend == "nccl" else None)
 
     S, n, T = args.sites, args.reads, args.iters
     thr = np.float32(DEFAULT_READ_THRESHOLD)
@@ -113,6 +118,8 @@ def main():
     Sr, R = b - a, int(d["off"][-1])
 
     eng = M6ANetEngine(weights=weights, device=local_rank)
+    if args.enc_variant:
+        eng.set_encoder_variant(args.enc_variant)
     eng.use_torch_stream()
     eng.set_job_offset(a)
     rp = torch.empty(R, dtype=torch.float32, device=dev)
@@ -123,7 +130,11 @@ def main():
     def step():
         eng.infer(X, km, off, T, 20, thr, 0, 16, 2, out=(rp, site, mod))
         if world > 1:           # the job's one exchange: site_prob + mod_ratio to rank 0 (RCCL)
-            mdist.gather_sites(site, mod, cuts, dst=0, buffers=gbufs)
+            if backend == "nccl":
+                mdist.gather_sites(site, mod, cuts, dst=0, buffers=gbufs)
+            else:
+                eng.sync()
+                mdist.gather_sites(site.cpu(), mod.cpu(), cuts, dst=0, buffers=gbufs)
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -168,8 +179,8 @@ def main():
                                    "num_iterations=%d, numpy-stream replay (batch_size 16, save_per_batch 2, seed 0); "
                                    "BASELINE.json configs[2]%s" % (S, n, T, " x%d GPUs (configs[3] shape)" % world if world > 1 else ""),
                        "sites_per_gpu": S, "reads_per_site": n, "num_iterations": T,
-                       "pool_kernel": eng.last_pool_variant, "sharding": "site shards, 1 RCCL gather/step" if world > 1 else "none"},
-            "roofline": {"kernel": "enc_kernel (read encoder)", "bound": "mfma", "achieved": enc_tflops,
+                       "pool_kernel": eng.last_pool_variant, "encoder_kernel": eng.last_encoder_variant, "sharding": "site shards, 1 RCCL gather/step" if world > 1 else "none"},
+            "roofline": {"kernel": "read encoder (%s)" % eng.last_encoder_variant, "bound": "mfma", "achieved": enc_tflops,
                          "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": enc_tflops / PEAK_F32_TFLOPS,
                          "traffic": tr["traffic_bytes_per_launch"] if tr else None,
                          "traffic_source": tr["source"] if tr else None,
