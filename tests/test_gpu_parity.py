@@ -235,6 +235,30 @@ def test_pool_group_geometry(eng, orc, bs, spb):
         assert np.abs(site - want_site).max() <= SITE_ATOL, (bs, spb, n)
 
 
+@pytest.mark.parametrize("T", [1024, 1025, 1500, 3000, 10000])
+def test_pool_long_iterations(eng, orc, T):
+    """num_iterations beyond one 16-round LDS chunk of the index row (table kernel, T > 1024) and
+    long replays in the scan kernels; 10000 is what the reference's own test uses."""
+    S = 70 if T < 10000 else 40
+    for bags, variant in (([20] * S, "table"), ([20, 27, 33, 64, 100] * (S // 5), "scan")):
+        off = np.concatenate([[0], np.cumsum(bags)]).astype(np.int64)
+        p = rand_probs(T, off)
+        site, mod = eng.calculate_site_proba(p, off, T, 20, THR, seed=2)
+        assert eng.last_pool_variant.startswith(variant)
+        want_site, want_mod = orc.site_pool(p, off, T, THR, seed=2, n_threads=8)
+        assert np.abs(site - want_site).max() <= SITE_ATOL, (T, variant)
+        assert np.array_equal(mod, want_mod)
+
+
+def test_pool_many_small_groups_and_one_huge_group(eng, orc):
+    off = np.arange(0, 20 * 3001, 20, dtype=np.int64)
+    p = rand_probs(77, off)
+    for bs, spb in ((1, 2), (4096, 2), (3000, 1)):       # 1-site groups; one flush group holding every site
+        site, mod = eng.calculate_site_proba(p, off, 12, 20, THR, seed=4, batch_size=bs, save_per_batch=spb)
+        want_site, _ = orc.site_pool(p, off, 12, THR, seed=4, batch_size=bs, save_per_batch=spb, n_threads=8)
+        assert np.abs(site - want_site).max() <= SITE_ATOL, (bs, spb)
+
+
 def test_pool_seeds_differ_and_repeat(eng):
     off = np.arange(101, dtype=np.int64) * 20
     p = rand_probs(1, off)
