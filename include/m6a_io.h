@@ -1,0 +1,60 @@
+/*
+ * m6a_io.h -- C ABI of libm6a_io.so: the data formats either side of the hot path
+ * (SURVEY.md section 8(f) ranks 1-2).  Host-only C++ (no HIP): usable without a GPU.
+ *
+ *   m6a_io_load_sites   replaces NanopolishDS / NanopolishReplicateDS.__getitem__ + inference_collate
+ *                       for a whole job (m6anet/utils/data_utils.py:118-129,152-231,341-427,498-506):
+ *                       data.info + data.json -> the flat arrays include/m6a.h takes.
+ *   m6a_io_write_csv    replaces the row formatting of run_inference
+ *                       (m6anet/utils/inference_utils.py:59-67): data.site_proba.csv /
+ *                       data.indiv_proba.csv, byte-identical to the Python '%' formatting.
+ *
+ * Every function returns 0 or a negative code; m6a_io_last_error() has the text (thread-local).
+ */
+#ifndef M6A_IO_H
+#define M6A_IO_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct m6a_sites m6a_sites;
+
+enum { M6A_IO_OK = 0, M6A_IO_EINVAL = -1, M6A_IO_ENOMEM = -2, M6A_IO_EIO = -3, M6A_IO_EFORMAT = -4 };
+
+const char *m6a_io_last_error(void);
+
+/* input_dirs: n_dirs directories, each holding data.info + data.json (one = single sample, several
+ * = replicates: union of sites in order of first appearance, read counts summed, reads concatenated
+ * in directory order, read ids printed "<id>_<replicate>").  Sites with fewer than min_reads reads are
+ * dropped (data_utils.py:129).  Normalisation factors (data_utils.py:233-248): n_norm 5-mers
+ * (norm_kmers = n_norm x 5 chars, no terminators) with mean/std [n_norm][3] in float64; features are
+ * (x - mean) / std in float64, then float32.  n_norm = 0 disables normalisation.  n_threads <= 0:
+ * all hardware threads. */
+int m6a_io_load_sites(const char *const *input_dirs, int n_dirs, int min_reads,
+                      const char *norm_kmers, const double *norm_mean, const double *norm_std, int n_norm,
+                      int n_threads, m6a_sites **out);
+void m6a_io_free(m6a_sites *s);
+
+int64_t m6a_io_n_sites(const m6a_sites *s);
+int64_t m6a_io_n_reads(const m6a_sites *s);
+int m6a_io_n_replicates(const m6a_sites *s);
+const float *m6a_io_X(const m6a_sites *s);                 /* [R][9] */
+const uint8_t *m6a_io_site_kmers(const m6a_sites *s);      /* [S][3] vocabulary ids */
+const int64_t *m6a_io_off(const m6a_sites *s);             /* [S+1] */
+const int64_t *m6a_io_tx_pos(const m6a_sites *s);          /* [S] */
+const double *m6a_io_read_ids(const m6a_sites *s);         /* [R] numeric read index */
+const int32_t *m6a_io_read_rep(const m6a_sites *s);        /* [R] replicate of each read */
+const char *m6a_io_tx_id(const m6a_sites *s, int64_t site);    /* NUL-terminated */
+const char *m6a_io_kmer5(const m6a_sites *s, int64_t site);    /* centre 5-mer, NUL-terminated */
+
+/* Appends the rows of all sites to <out_dir>/data.site_proba.csv and data.indiv_proba.csv
+ * (headers are written when write_header != 0, truncating the files like
+ * m6anet/scripts/inference.py:94-97).  read_prob [R], site_prob [S], mod_ratio [S]. */
+int m6a_io_write_csv(const m6a_sites *s, const char *out_dir, const float *read_prob,
+                     const float *site_prob, const double *mod_ratio, int write_header, int n_threads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,107 @@
+"""ctypes binding of libm6a_io.so (include/m6a_io.h): native loader + CSV writers."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libm6a_io.so")
+SYMBOLS = ["m6a_io_last_error", "m6a_io_load_sites", "m6a_io_free", "m6a_io_n_sites", "m6a_io_n_reads",
+           "m6a_io_n_replicates", "m6a_io_X", "m6a_io_site_kmers", "m6a_io_off", "m6a_io_tx_pos",
+           "m6a_io_read_ids", "m6a_io_read_rep", "m6a_io_tx_id", "m6a_io_kmer5", "m6a_io_write_csv"]
+_lib = None
+
+
+class M6AIOError(RuntimeError):
+    pass
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("libm6a_io.so is not built: run `python -m m6anet_amd.build`")
+    L = C.CDLL(LIB_PATH)
+    vp, i64, i32 = C.c_void_p, C.c_int64, C.c_int
+    L.m6a_io_last_error.restype = C.c_char_p
+    L.m6a_io_load_sites.argtypes = [C.POINTER(C.c_char_p), i32, i32, C.c_char_p, vp, vp, i32, i32, C.POINTER(vp)]
+    L.m6a_io_free.argtypes = [vp]
+    L.m6a_io_free.restype = None
+    for name, rt in (("m6a_io_n_sites", i64), ("m6a_io_n_reads", i64), ("m6a_io_n_replicates", i32)):
+        getattr(L, name).argtypes = [vp]
+        getattr(L, name).restype = rt
+    for name in ("m6a_io_X", "m6a_io_site_kmers", "m6a_io_off", "m6a_io_tx_pos", "m6a_io_read_ids", "m6a_io_read_rep"):
+        getattr(L, name).argtypes = [vp]
+        getattr(L, name).restype = vp
+    for name in ("m6a_io_tx_id", "m6a_io_kmer5"):
+        getattr(L, name).argtypes = [vp, i64]
+        getattr(L, name).restype = C.c_char_p
+    L.m6a_io_write_csv.argtypes = [vp, C.c_char_p, vp, vp, vp, i32, i32]
+    _lib = L
+    return L
+
+
+def _chk(rc):
+    if rc != 0:
+        raise M6AIOError("m6a_io error %d: %s" % (rc, load().m6a_io_last_error().decode()))
+
+
+class NativeSites:
+    """Owns an m6a_sites handle; exposes its arrays as zero-copy numpy views."""
+
+    def __init__(self, input_dirs, min_reads, norm, n_threads=0):
+        L = load()
+        dirs = (C.c_char_p * len(input_dirs))(*[os.fsencode(d) for d in input_dirs])
+        if norm:
+            kmers = sorted(norm)
+            blob = "".join(kmers).encode()
+            mean = np.ascontiguousarray([norm[k][0] for k in kmers], np.float64)
+            std = np.ascontiguousarray([norm[k][1] for k in kmers], np.float64)
+            args = (blob, mean.ctypes.data, std.ctypes.data, len(kmers))
+        else:
+            args = (None, None, None, 0)
+        h = C.c_void_p()
+        _chk(L.m6a_io_load_sites(dirs, len(input_dirs), int(min_reads), *args, int(n_threads), C.byref(h)))
+        self._h, self._L = h, L
+        S, R = L.m6a_io_n_sites(h), L.m6a_io_n_reads(h)
+        self.n_replicates = L.m6a_io_n_replicates(h)
+
+        def view(fn, ctype, shape):
+            n = int(np.prod(shape))
+            arr = np.ctypeslib.as_array(C.cast(fn(h), C.POINTER(ctype)), shape=(n,)).reshape(shape)
+            arr.flags.writeable = False
+            return arr
+        self.X = view(L.m6a_io_X, C.c_float, (R, 9))
+        self.site_kmers = view(L.m6a_io_site_kmers, C.c_uint8, (S, 3))
+        self.off = view(L.m6a_io_off, C.c_int64, (S + 1,))
+        self.tx_pos = view(L.m6a_io_tx_pos, C.c_int64, (S,))
+        self.read_id_values = view(L.m6a_io_read_ids, C.c_double, (R,))
+        self.read_rep = view(L.m6a_io_read_rep, C.c_int32, (R,))
+
+    def tx_id(self, i):
+        return self._L.m6a_io_tx_id(self._h, i).decode()
+
+    def kmer5(self, i):
+        return self._L.m6a_io_kmer5(self._h, i).decode()
+
+    def write_csv(self, out_dir, read_prob, site_prob, mod_ratio, write_header=False, n_threads=0):
+        rp = np.ascontiguousarray(read_prob, np.float32)
+        sp = np.ascontiguousarray(site_prob, np.float32)
+        mr = np.ascontiguousarray(mod_ratio, np.float64)
+        assert rp.size == self.X.shape[0] and sp.size == self.tx_pos.size == mr.size
+        _chk(self._L.m6a_io_write_csv(self._h, os.fsencode(out_dir), rp.ctypes.data, sp.ctypes.data, mr.ctypes.data,
+                                      1 if write_header else 0, int(n_threads)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            for name in ("X", "site_kmers", "off", "tx_pos", "read_id_values", "read_rep"):
+                setattr(self, name, None)
+            self._L.m6a_io_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

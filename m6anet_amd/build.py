@@ -7,6 +7,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 INCLUDE = os.path.join(os.path.dirname(PKG), "include")
 LIB = os.path.join(PKG, "libm6a_hip.so")
+IO_LIB = os.path.join(PKG, "libm6a_io.so")
 SOURCES = ["m6a_kernels.hip", "m6a_api.hip"]
 DEPS = SOURCES + ["m6a_kernels.h", os.path.join(INCLUDE, "m6a.h")]
 
@@ -30,5 +31,20 @@ def build(force=False, verbose=False):
     return LIB
 
 
+def build_io(force=False, verbose=False):
+    """libm6a_io.so: host-only C++ (loader + CSV writers, include/m6a_io.h)."""
+    src = os.path.join(CSRC, "m6a_io.cpp")
+    hdr = os.path.join(INCLUDE, "m6a_io.h")
+    if not force and os.path.exists(IO_LIB) and os.path.getmtime(IO_LIB) >= max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        return IO_LIB
+    cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Wall", "-Wextra",
+           "-I" + INCLUDE, src, "-o", IO_LIB]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return IO_LIB
+
+
 if __name__ == "__main__":
+    print(build_io(force="--force" in sys.argv, verbose=True))
     print(build(force="--force" in sys.argv, verbose=True))

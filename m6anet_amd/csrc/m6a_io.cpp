@@ -1,0 +1,481 @@
+// m6a_io.cpp -- native loader for dataprep output and CSV writers (include/m6a_io.h).
+// Host-only C++17; parsing and formatting are spread over std::threads by site range.
+#include "m6a_io.h"
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <clocale>
+#include <cstdlib>
+#include <locale.h>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <set>
+#include <string>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[768];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+struct Mapped {
+    const char *p = nullptr;
+    size_t n = 0;
+    int fd = -1;
+    int open(const std::string &path)
+    {
+        fd = ::open(path.c_str(), O_RDONLY);
+        if (fd < 0) return fail(M6A_IO_EIO, "cannot open %s", path.c_str());
+        struct stat st;
+        if (fstat(fd, &st) != 0) return fail(M6A_IO_EIO, "cannot stat %s", path.c_str());
+        n = (size_t)st.st_size;
+        if (n) {
+            void *m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);   // one pass over the page tables, not a fault per page per thread
+            if (m == MAP_FAILED) return fail(M6A_IO_EIO, "cannot mmap %s", path.c_str());
+            p = (const char *)m;
+        }
+        return 0;
+    }
+    ~Mapped()
+    {
+        if (p) munmap((void *)p, n);
+        if (fd >= 0) ::close(fd);
+    }
+};
+
+// the 66-word vocabulary: sorted unique 5-mers of all N-DRACH-N 7-mers
+// (m6anet/utils/constants.py:29-36, m6anet/utils/data_utils.py:89-96)
+const std::map<std::string, int> &vocab()
+{
+    static const std::map<std::string, int> v = [] {
+        std::set<std::string> s;
+        const std::string N = "ACGT", D = "AGT", R = "GA", H = "ACT";
+        for (char a : N) for (char d : D) for (char r : R) for (char h : H) for (char b : N) {
+            const std::string k7 = {a, d, r, 'A', 'C', h, b};
+            for (int i = 0; i < 3; i++) s.insert(k7.substr(i, 5));
+        }
+        std::map<std::string, int> m;
+        int i = 0;
+        for (const auto &k : s) m[k] = i++;
+        return m;
+    }();
+    return v;
+}
+
+struct Part { int rep; int64_t start, end; };
+struct SiteRef {
+    std::string tx;
+    int64_t pos;
+    int64_t n_reads = 0;
+    std::vector<Part> parts;
+};
+
+int parse_info(const std::string &dir, int rep, std::vector<SiteRef> &sites,
+               std::unordered_map<std::string, size_t> &index)
+{
+    const std::string path = dir + "/data.info";
+    FILE *f = fopen(path.c_str(), "r");
+    if (!f) return fail(M6A_IO_EIO, "cannot open %s", path.c_str());
+    char line[4096];
+    bool first = true;
+    int rc = 0;
+    while (fgets(line, sizeof line, f)) {
+        if (first) {          // header: transcript_id,transcript_position,start,end,n_reads
+            first = false;
+            if (strncmp(line, "transcript_id,transcript_position,start,end,n_reads", 51) != 0) {
+                rc = fail(M6A_IO_EFORMAT, "%s: unexpected header", path.c_str());
+                break;
+            }
+            continue;
+        }
+        char *c1 = strchr(line, ',');
+        if (!c1) continue;
+        std::string tx(line, c1 - line);
+        long long pos, start, end, n;
+        if (sscanf(c1 + 1, "%lld,%lld,%lld,%lld", &pos, &start, &end, &n) != 4) {
+            rc = fail(M6A_IO_EFORMAT, "%s: bad row '%s'", path.c_str(), line);
+            break;
+        }
+        const std::string key = tx + ":" + std::to_string(pos);
+        auto it = index.find(key);
+        size_t i;
+        if (it == index.end()) {
+            i = sites.size();
+            index.emplace(key, i);
+            sites.push_back(SiteRef{tx, pos, 0, {}});
+        } else {
+            i = it->second;
+        }
+        sites[i].n_reads += n;
+        sites[i].parts.push_back(Part{rep, start, end});
+    }
+    fclose(f);
+    return rc;
+}
+
+// --- minimal JSON walker for one dataprep record: {"tx":{"pos":{"KMER":[[n,...],[n,...]]}}} -------
+struct Cursor {
+    const char *p, *e;
+    void ws() { while (p < e && (*p == ' ' || *p == '\n' || *p == '\r' || *p == '\t')) ++p; }
+    bool eat(char c) { ws(); if (p < e && *p == c) { ++p; return true; } return false; }
+    bool str(std::string &out)
+    {
+        ws();
+        if (p >= e || *p != '"') return false;
+        const char *q = ++p;
+        while (p < e && *p != '"') { if (*p == '\\') ++p; ++p; }
+        if (p >= e) return false;
+        out.assign(q, p - q);
+        ++p;
+        return true;
+    }
+    // Correctly rounded decimal -> double, like Python's float().  (libstdc++ 11's
+    // std::from_chars(double) switches locale under a global lock -- it serialises the worker
+    // threads -- so: Clinger's exact fast path for <= 15 significant digits and |exp10| <= 22,
+    // glibc strtod_l on a cached "C" locale for everything else.  Every number in a dataprep
+    // record is followed by ',' or ']', so strtod never runs off the mapping.)
+    bool num(double &v)
+    {
+        ws();
+        const char *q = p;
+        bool neg = false;
+        if (q < e && (*q == '-' || *q == '+')) { neg = *q == '-'; ++q; }
+        uint64_t mant = 0;
+        int nd = 0, frac = 0;
+        bool dot = false, any = false;
+        for (; q < e; ++q) {
+            const char ch = *q;
+            if (ch >= '0' && ch <= '9') {
+                any = true;
+                if (mant || ch != '0') {
+                    if (++nd > 15) break;                 // too many significant digits: slow path
+                    mant = mant * 10 + (uint64_t)(ch - '0');
+                }
+                if (dot) ++frac;
+            } else if (ch == '.' && !dot) {
+                dot = true;
+            } else {
+                break;
+            }
+        }
+        const bool simple_end = q >= e || (*q != 'e' && *q != 'E' && !(*q >= '0' && *q <= '9') && *q != '.');
+        if (any && nd <= 15 && simple_end && frac <= 22) {
+            static const double p10[] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14,
+                                         1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+            const double r = (double)mant / p10[frac];    // both exact doubles: one correctly rounded division
+            v = neg ? -r : r;
+            p = q;
+            return true;
+        }
+        static const locale_t c_loc = newlocale(LC_ALL_MASK, "C", (locale_t)0);
+        char *end = nullptr;
+        v = strtod_l(p, &end, c_loc);
+        if (end == p || end > e) return false;
+        p = end;
+        return true;
+    }
+};
+
+}  // namespace
+
+struct m6a_sites {
+    int n_rep = 1;
+    std::vector<float> X;
+    std::vector<uint8_t> site_kmers;
+    std::vector<int64_t> off, tx_pos;
+    std::vector<double> read_ids;
+    std::vector<int32_t> read_rep;
+    std::vector<std::string> tx_ids, kmer5;
+};
+
+namespace {
+
+// parses one record into rows of `ncol` numbers appended to `vals`; returns the sequence key
+int parse_record(const char *p, const char *e, const std::string &tx, int64_t pos, std::string &kmer,
+                 std::vector<double> &vals, int &ncol)
+{
+    Cursor c{p, e};
+    std::string key;
+    if (!c.eat('{') || !c.str(key) || !c.eat(':')) return fail(M6A_IO_EFORMAT, "record of %s:%lld: bad JSON", tx.c_str(), (long long)pos);
+    if (key != tx) return fail(M6A_IO_EFORMAT, "record at offset of %s:%lld is for transcript %s", tx.c_str(), (long long)pos, key.c_str());
+    if (!c.eat('{') || !c.str(key) || !c.eat(':')) return fail(M6A_IO_EFORMAT, "record of %s:%lld: bad JSON", tx.c_str(), (long long)pos);
+    if (key != std::to_string(pos)) return fail(M6A_IO_EFORMAT, "record of %s:%lld holds position %s", tx.c_str(), (long long)pos, key.c_str());
+    if (!c.eat('{') || !c.str(kmer) || !c.eat(':') || !c.eat('['))
+        return fail(M6A_IO_EFORMAT, "record of %s:%lld: bad JSON", tx.c_str(), (long long)pos);
+    ncol = -1;
+    if (!c.eat(']')) {
+        do {
+            if (!c.eat('[')) return fail(M6A_IO_EFORMAT, "record of %s:%lld: expected a row", tx.c_str(), (long long)pos);
+            int n = 0;
+            do {
+                double v;
+                if (!c.num(v)) return fail(M6A_IO_EFORMAT, "record of %s:%lld: bad number", tx.c_str(), (long long)pos);
+                vals.push_back(v);
+                ++n;
+            } while (c.eat(','));
+            if (!c.eat(']')) return fail(M6A_IO_EFORMAT, "record of %s:%lld: unterminated row", tx.c_str(), (long long)pos);
+            if (ncol < 0) ncol = n;
+            else if (ncol != n) return fail(M6A_IO_EFORMAT, "record of %s:%lld: ragged rows", tx.c_str(), (long long)pos);
+        } while (c.eat(','));
+        if (!c.eat(']')) return fail(M6A_IO_EFORMAT, "record of %s:%lld: unterminated array", tx.c_str(), (long long)pos);
+    }
+    if (c.eat(',')) return fail(M6A_IO_EFORMAT, "site %s:%lld has more than one sequence key", tx.c_str(), (long long)pos);
+    if (!c.eat('}') || !c.eat('}') || !c.eat('}')) return fail(M6A_IO_EFORMAT, "record of %s:%lld: bad JSON tail", tx.c_str(), (long long)pos);
+    return 0;
+}
+
+// str(numpy.float64): shortest repr that round-trips; read indices are integral, so "<int>.0"
+void format_py_float(double v, std::string &out)
+{
+    char buf[40];
+    if (std::isfinite(v) && v == std::floor(v) && std::fabs(v) < 1e16) {
+        snprintf(buf, sizeof buf, "%.1f", v);
+        out += buf;
+        return;
+    }
+    for (int prec = 1; prec <= 17; prec++) {
+        snprintf(buf, sizeof buf, "%.*g", prec, v);
+        if (strtod(buf, nullptr) == v) break;
+    }
+    out += buf;
+    if (!strpbrk(buf, ".en")) out += ".0";
+}
+
+int n_workers(int n_threads, int64_t items)
+{
+    int n = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
+    n = std::max(1, std::min<int>(n, 64));
+    return (int)std::max<int64_t>(1, std::min<int64_t>(n, items));
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *m6a_io_last_error(void) { return g_err.c_str(); }
+
+int m6a_io_load_sites(const char *const *input_dirs, int n_dirs, int min_reads, const char *norm_kmers,
+                      const double *norm_mean, const double *norm_std, int n_norm, int n_threads, m6a_sites **out)
+{
+    if (!out) return M6A_IO_EINVAL;
+    *out = nullptr;
+    if (!input_dirs || n_dirs < 1) return fail(M6A_IO_EINVAL, "no input directory");
+    if (n_norm < 0 || (n_norm > 0 && (!norm_kmers || !norm_mean || !norm_std))) return fail(M6A_IO_EINVAL, "bad normalisation arguments");
+
+    std::vector<SiteRef> all;
+    std::unordered_map<std::string, size_t> index;
+    std::vector<Mapped> json((size_t)n_dirs);
+    for (int r = 0; r < n_dirs; r++) {
+        int rc = parse_info(input_dirs[r], r, all, index);
+        if (rc) return rc;
+        rc = json[(size_t)r].open(std::string(input_dirs[r]) + "/data.json");
+        if (rc) return rc;
+    }
+    std::vector<SiteRef> sites;
+    for (auto &s : all) if (s.n_reads >= min_reads) sites.push_back(std::move(s));
+    if (sites.empty()) return fail(M6A_IO_EFORMAT, "no site with at least %d reads", min_reads);
+    const int64_t S = (int64_t)sites.size();
+
+    std::unordered_map<std::string, int> norm_ix;
+    for (int i = 0; i < n_norm; i++) norm_ix.emplace(std::string(norm_kmers + 5 * i, 5), i);
+
+    m6a_sites *res = new (std::nothrow) m6a_sites;
+    if (!res) return fail(M6A_IO_ENOMEM, "out of memory");
+    res->n_rep = n_dirs;
+    res->off.assign((size_t)S + 1, 0);
+    for (int64_t s = 0; s < S; s++) res->off[(size_t)s + 1] = res->off[(size_t)s] + sites[(size_t)s].n_reads;
+    const int64_t R = res->off[(size_t)S];
+    try {
+        res->X.resize((size_t)R * 9);
+        res->site_kmers.resize((size_t)S * 3);
+        res->tx_pos.resize((size_t)S);
+        res->read_ids.resize((size_t)R);
+        res->read_rep.resize((size_t)R);
+        res->tx_ids.resize((size_t)S);
+        res->kmer5.resize((size_t)S);
+    } catch (const std::bad_alloc &) {
+        delete res;
+        return fail(M6A_IO_ENOMEM, "out of memory for %lld reads", (long long)R);
+    }
+
+    const int nw = n_workers(n_threads, S);
+    std::vector<std::string> errs((size_t)nw);
+    std::vector<int> rcs((size_t)nw, 0);
+    auto work = [&](int w) {
+        std::vector<double> vals;
+        // contiguous site ranges balanced by read count
+        const int64_t r_lo = R * w / nw, r_hi = R * (w + 1) / nw;
+        int64_t s0 = std::lower_bound(res->off.begin(), res->off.end() - 1, r_lo) - res->off.begin();
+        int64_t s1 = (w == nw - 1) ? S : std::lower_bound(res->off.begin(), res->off.end() - 1, r_hi) - res->off.begin();
+        for (int64_t s = s0; s < s1; s++) {
+            const SiteRef &sr = sites[(size_t)s];
+            std::string kmer;
+            int64_t row = res->off[(size_t)s];
+            for (const Part &pt : sr.parts) {
+                const Mapped &m = json[(size_t)pt.rep];
+                if (pt.start < 0 || pt.end > (int64_t)m.n || pt.start >= pt.end) {
+                    rcs[(size_t)w] = fail(M6A_IO_EFORMAT, "site %s:%lld: byte range outside data.json", sr.tx.c_str(), (long long)sr.pos);
+                    errs[(size_t)w] = g_err; return;
+                }
+                vals.clear();
+                std::string k;
+                int ncol = 0;
+                int rc = parse_record(m.p + pt.start, m.p + pt.end, sr.tx, sr.pos, k, vals, ncol);
+                if (rc) { rcs[(size_t)w] = rc; errs[(size_t)w] = g_err; return; }
+                if (kmer.empty()) kmer = k;
+                else if (kmer != k) { rcs[(size_t)w] = fail(M6A_IO_EFORMAT, "replicates disagree on the sequence of %s:%lld", sr.tx.c_str(), (long long)sr.pos); errs[(size_t)w] = g_err; return; }
+                if (kmer.size() != 7 || ncol != 10) {
+                    // data prepared with n_neighbors != 1 (the reference's own slice for that case,
+                    // data_utils.py:276-277, yields a 4-mer and fails too)
+                    rcs[(size_t)w] = fail(M6A_IO_EFORMAT, "site %s:%lld: %zu-mer with %d columns; only dataprep n_neighbors=1 (7-mer, 10 columns) is supported",
+                                          sr.tx.c_str(), (long long)sr.pos, kmer.size(), ncol);
+                    errs[(size_t)w] = g_err; return;
+                }
+                const int64_t nrow = (int64_t)vals.size() / 10;
+                if (row + nrow > res->off[(size_t)s + 1]) { rcs[(size_t)w] = fail(M6A_IO_EFORMAT, "site %s:%lld has more reads than data.info says", sr.tx.c_str(), (long long)sr.pos); errs[(size_t)w] = g_err; return; }
+                double mean[9], sd[9];
+                for (int c = 0; c < 3; c++) {
+                    const std::string k5 = kmer.substr((size_t)c, 5);
+                    if (n_norm) {
+                        auto it = norm_ix.find(k5);
+                        if (it == norm_ix.end()) { rcs[(size_t)w] = fail(M6A_IO_EFORMAT, "no normalisation factors for %s", k5.c_str()); errs[(size_t)w] = g_err; return; }
+                        for (int j = 0; j < 3; j++) { mean[3 * c + j] = norm_mean[3 * it->second + j]; sd[3 * c + j] = norm_std[3 * it->second + j]; }
+                    }
+                }
+                for (int64_t i = 0; i < nrow; i++) {
+                    const double *v = vals.data() + 10 * i;
+                    float *x = res->X.data() + 9 * (row + i);
+                    for (int j = 0; j < 9; j++) x[j] = n_norm ? (float)((v[j] - mean[j]) / sd[j]) : (float)v[j];
+                    res->read_ids[(size_t)(row + i)] = v[9];
+                    res->read_rep[(size_t)(row + i)] = pt.rep;
+                }
+                row += nrow;
+            }
+            if (row != res->off[(size_t)s + 1]) { rcs[(size_t)w] = fail(M6A_IO_EFORMAT, "site %s:%lld: data.info says %lld reads, data.json has %lld", sr.tx.c_str(), (long long)sr.pos, (long long)sr.n_reads, (long long)(row - res->off[(size_t)s])); errs[(size_t)w] = g_err; return; }
+            for (int c = 0; c < 3; c++) {
+                auto it = vocab().find(kmer.substr((size_t)c, 5));
+                if (it == vocab().end()) { rcs[(size_t)w] = fail(M6A_IO_EFORMAT, "site %s:%lld: %s is not a DRACH context", sr.tx.c_str(), (long long)sr.pos, kmer.c_str()); errs[(size_t)w] = g_err; return; }
+                res->site_kmers[(size_t)(3 * s + c)] = (uint8_t)it->second;
+            }
+            res->tx_pos[(size_t)s] = sr.pos;
+            res->tx_ids[(size_t)s] = sr.tx;
+            res->kmer5[(size_t)s] = kmer.substr(1, 5);
+        }
+    };
+    std::vector<std::thread> th;
+    for (int w = 1; w < nw; w++) th.emplace_back(work, w);
+    work(0);
+    for (auto &t : th) t.join();
+    for (int w = 0; w < nw; w++)
+        if (rcs[(size_t)w]) { g_err = errs[(size_t)w]; delete res; return rcs[(size_t)w]; }
+    *out = res;
+    return M6A_IO_OK;
+}
+
+void m6a_io_free(m6a_sites *s) { delete s; }
+int64_t m6a_io_n_sites(const m6a_sites *s) { return s ? (int64_t)s->tx_pos.size() : 0; }
+int64_t m6a_io_n_reads(const m6a_sites *s) { return s ? (int64_t)s->read_ids.size() : 0; }
+int m6a_io_n_replicates(const m6a_sites *s) { return s ? s->n_rep : 0; }
+const float *m6a_io_X(const m6a_sites *s) { return s->X.data(); }
+const uint8_t *m6a_io_site_kmers(const m6a_sites *s) { return s->site_kmers.data(); }
+const int64_t *m6a_io_off(const m6a_sites *s) { return s->off.data(); }
+const int64_t *m6a_io_tx_pos(const m6a_sites *s) { return s->tx_pos.data(); }
+const double *m6a_io_read_ids(const m6a_sites *s) { return s->read_ids.data(); }
+const int32_t *m6a_io_read_rep(const m6a_sites *s) { return s->read_rep.data(); }
+const char *m6a_io_tx_id(const m6a_sites *s, int64_t i) { return s->tx_ids[(size_t)i].c_str(); }
+const char *m6a_io_kmer5(const m6a_sites *s, int64_t i) { return s->kmer5[(size_t)i].c_str(); }
+
+int m6a_io_write_csv(const m6a_sites *s, const char *out_dir, const float *read_prob, const float *site_prob,
+                     const double *mod_ratio, int write_header, int n_threads)
+{
+    if (!s || !out_dir || !read_prob || !site_prob || !mod_ratio) return fail(M6A_IO_EINVAL, "null argument");
+    const int64_t S = m6a_io_n_sites(s);
+    const std::string fs = std::string(out_dir) + "/data.site_proba.csv", fi = std::string(out_dir) + "/data.indiv_proba.csv";
+    FILE *f = fopen(fs.c_str(), write_header ? "w" : "a");
+    if (!f) return fail(M6A_IO_EIO, "cannot open %s", fs.c_str());
+    FILE *g = fopen(fi.c_str(), write_header ? "w" : "a");
+    if (!g) { fclose(f); return fail(M6A_IO_EIO, "cannot open %s", fi.c_str()); }
+    if (write_header) {
+        fputs("transcript_id,transcript_position,n_reads,probability_modified,kmer,mod_ratio\n", f);
+        fputs("transcript_id,transcript_position,read_index,probability_modified\n", g);
+    }
+    // rows are formatted in parallel into per-chunk strings, written in order
+    const int nw = n_workers(n_threads, S);
+    const int64_t R = m6a_io_n_reads(s);
+    int rc = 0;
+    const int64_t chunk_reads = 1 << 20;         // bound memory: ~64 MB of text per thread per round
+    int64_t s_begin = 0;
+    while (s_begin < S && !rc) {
+        std::vector<int64_t> cuts{s_begin};
+        for (int w = 0; w < nw && cuts.back() < S; w++) {
+            const int64_t target = std::min(R, s->off[(size_t)cuts.back()] + chunk_reads);
+            int64_t e = std::upper_bound(s->off.begin(), s->off.end(), target) - s->off.begin() - 1;
+            e = std::min<int64_t>(S, std::max<int64_t>(e, cuts.back() + 1));
+            cuts.push_back(e);
+        }
+        const int nc = (int)cuts.size() - 1;
+        std::vector<std::string> site_txt((size_t)nc), indiv_txt((size_t)nc);
+        auto work = [&](int w) {
+            std::string &a = site_txt[(size_t)w], &b = indiv_txt[(size_t)w];
+            char buf[128];
+            for (int64_t i = cuts[(size_t)w]; i < cuts[(size_t)w + 1]; i++) {
+                const int64_t r0 = s->off[(size_t)i], r1 = s->off[(size_t)i + 1];
+                // '%s,%d,%s,%.16f,%s,%.16f'  (inference_utils.py:62)
+                a += s->tx_ids[(size_t)i];
+                snprintf(buf, sizeof buf, ",%lld,%lld,%.16f,", (long long)s->tx_pos[(size_t)i], (long long)(r1 - r0), (double)site_prob[i]);
+                a += buf;
+                a += s->kmer5[(size_t)i];
+                snprintf(buf, sizeof buf, ",%.16f\n", mod_ratio[i]);
+                a += buf;
+                // '%s,%d,%s,%.16f'  (inference_utils.py:66); read ids: str(float64), or "<int>_<rep>"
+                snprintf(buf, sizeof buf, ",%lld,", (long long)s->tx_pos[(size_t)i]);
+                const std::string head = s->tx_ids[(size_t)i] + buf;
+                for (int64_t r = r0; r < r1; r++) {
+                    b += head;
+                    if (s->n_rep > 1) {
+                        snprintf(buf, sizeof buf, "%lld_%d", (long long)s->read_ids[(size_t)r], (int)s->read_rep[(size_t)r]);
+                        b += buf;
+                    } else {
+                        format_py_float(s->read_ids[(size_t)r], b);
+                    }
+                    snprintf(buf, sizeof buf, ",%.16f\n", (double)read_prob[r]);
+                    b += buf;
+                }
+            }
+        };
+        std::vector<std::thread> th;
+        for (int w = 1; w < nc; w++) th.emplace_back(work, w);
+        work(0);
+        for (auto &t : th) t.join();
+        for (int w = 0; w < nc && !rc; w++) {
+            if (fwrite(site_txt[(size_t)w].data(), 1, site_txt[(size_t)w].size(), f) != site_txt[(size_t)w].size() ||
+                fwrite(indiv_txt[(size_t)w].data(), 1, indiv_txt[(size_t)w].size(), g) != indiv_txt[(size_t)w].size())
+                rc = fail(M6A_IO_EIO, "short write in %s", out_dir);
+        }
+        s_begin = cuts.back();
+    }
+    if (fclose(f) != 0 && !rc) rc = fail(M6A_IO_EIO, "cannot close %s", fs.c_str());
+    if (fclose(g) != 0 && !rc) rc = fail(M6A_IO_EIO, "cannot close %s", fi.c_str());
+    return rc;
+}
+
+}  // extern "C"

@@ -46,11 +46,26 @@ def _read_info(root_dir):
 
 
 class SiteBatch:
-    """Everything one job needs, flat."""
+    """Everything one job needs, flat.  `native` is the libm6a_io handle when the batch came from
+    the native loader (ids then stay on the C side and the CSVs are written natively)."""
 
-    def __init__(self, X, site_kmers, off, tx_ids, tx_pos, read_ids, kmer5):
+    def __init__(self, X, site_kmers, off, tx_ids, tx_pos, read_ids, kmer5, native=None):
         self.X, self.site_kmers, self.off = X, site_kmers, off
-        self.tx_ids, self.tx_pos, self.read_ids, self.kmer5 = tx_ids, tx_pos, read_ids, kmer5
+        self._tx_ids, self.tx_pos, self.read_ids, self._kmer5 = tx_ids, tx_pos, read_ids, kmer5
+        self.native = native
+
+    # id strings stay on the C side for native batches until somebody asks for them
+    @property
+    def tx_ids(self):
+        if self._tx_ids is None:
+            self._tx_ids = [self.native.tx_id(i) for i in range(self.n_sites)]
+        return self._tx_ids
+
+    @property
+    def kmer5(self):
+        if self._kmer5 is None:
+            self._kmer5 = [self.native.kmer5(i) for i in range(self.n_sites)]
+        return self._kmer5
 
     @property
     def n_sites(self):
@@ -61,9 +76,20 @@ class SiteBatch:
         return np.diff(self.off)
 
 
+def load_sites_native(input_dirs, min_reads=DEFAULT_MIN_READS, norm_path=None, n_threads=0):
+    """Same result as load_sites (bit-identical arrays, tests/test_host_io.py) through the native
+    multi-threaded loader of libm6a_io.so."""
+    from . import _io
+    if isinstance(input_dirs, str):
+        input_dirs = [input_dirs]
+    nat = _io.NativeSites(list(input_dirs), min_reads, load_norm_factors(norm_path), n_threads)
+    return SiteBatch(nat.X, nat.site_kmers, nat.off, None, nat.tx_pos, None, None, native=nat)
+
+
 def load_sites(input_dirs, min_reads=DEFAULT_MIN_READS, norm_path=None,
                num_neighboring_features=NUM_NEIGHBORING_FEATURES):
-    """input_dirs: one directory (NanopolishDS) or several (NanopolishReplicateDS)."""
+    """input_dirs: one directory (NanopolishDS) or several (NanopolishReplicateDS).  Pure-Python
+    reference implementation of the loader; load_sites_native is the fast path."""
     if isinstance(input_dirs, str):
         input_dirs = [input_dirs]
     replicate = len(input_dirs) > 1

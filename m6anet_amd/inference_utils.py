@@ -56,6 +56,9 @@ def run_inference(engine, batch, args):
     read_prob, site_prob, mod_ratio = engine.infer(
         batch.X, batch.site_kmers, batch.off, args.num_iterations, N_SAMPLES, args.read_proba_threshold,
         args.seed, args.batch_size, args.save_per_batch)
+    if batch.native is not None:          # native writer: same bytes, formatted on all host threads
+        batch.native.write_csv(args.out_dir, read_prob, site_prob, mod_ratio, write_header=False)
+        return read_prob, site_prob, mod_ratio
     with open(os.path.join(args.out_dir, "data.site_proba.csv"), "a", encoding="utf-8") as f:
         f.writelines(format_site_rows(batch, site_prob, mod_ratio))
     with open(os.path.join(args.out_dir, "data.indiv_proba.csv"), "a", encoding="utf-8") as g:

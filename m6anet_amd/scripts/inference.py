@@ -7,7 +7,7 @@ from argparse import ArgumentDefaultsHelpFormatter, ArgumentParser
 
 from ..constants import (DEFAULT_MIN_READS, DEFAULT_PRETRAINED_MODEL, DEFAULT_PRETRAINED_MODELS,
                          DEFAULT_READ_THRESHOLD, PRETRAINED_CONFIGS)
-from ..data_utils import load_sites
+from ..data_utils import load_sites, load_sites_native
 from ..engine import M6ANetEngine, load_weights, weights_from_state_dict
 from ..inference_utils import INDIV_HEADER, SITE_HEADER, run_inference
 
@@ -69,6 +69,10 @@ def main(args):
         f.write(SITE_HEADER)
     with open(os.path.join(args.out_dir, "data.indiv_proba.csv"), "w", encoding="utf-8") as g:
         g.write(INDIV_HEADER)
-    batch = load_sites(args.input_dir, DEFAULT_MIN_READS, args.norm_path)
+    # --n_processes is the reference's host-parallelism flag: here it sizes the loader / writer threads
+    try:
+        batch = load_sites_native(args.input_dir, DEFAULT_MIN_READS, args.norm_path, n_threads=args.n_processes)
+    except ImportError:
+        batch = load_sites(args.input_dir, DEFAULT_MIN_READS, args.norm_path)   # libm6a_io.so not built
     run_inference(engine, batch, args)
     engine.close()

@@ -3,6 +3,7 @@ import gzip
 import os
 
 import numpy as np
+import pytest
 
 from m6anet_amd import data_utils, inference_utils
 
@@ -64,3 +65,84 @@ def test_replicate_loader_ids_and_order(tmp_path):
     assert [(a, str(b), c) for a, b, c in ours[:len(ref_ids)]] == ref_ids
     s0 = batch.read_ids[0]
     assert s0[0].endswith("_0") and s0[-1].endswith("_1")
+
+
+# ------------------------------------------------------------------ native loader / writers -----
+def test_native_symbols_match_header():
+    import re
+    import subprocess
+    from m6anet_amd import _io
+    h = open(os.path.join(os.path.dirname(GOLD), "..", "include", "m6a_io.h")).read()
+    h = re.sub(r"/\*.*?\*/", "", h, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(m6a_io_[A-Za-z_0-9]+)\s*\(", h)))
+    out = subprocess.run(["nm", "-D", "--defined-only", _io.LIB_PATH], capture_output=True, text=True).stdout
+    exported = sorted(set(re.findall(r" T (m6a_io_[A-Za-z_0-9]+)", out)))
+    assert declared == exported == sorted(_io.SYMBOLS)
+
+
+def test_native_loader_is_bit_identical_to_python_loader(tmp_path):
+    import shutil
+    rep = tmp_path / "rep1"
+    rep.mkdir()
+    for fn in ("data.info", "data.json"):
+        shutil.copyfile(os.path.join(DATA, fn), rep / fn)
+    for dirs, min_reads in (([DATA], 20), ([DATA], 1), ([DATA, str(rep)], 20)):
+        py = data_utils.load_sites(dirs, min_reads, "norm_hct116.npz")
+        for threads in (1, 3):
+            nat = data_utils.load_sites_native(dirs, min_reads, "norm_hct116.npz", n_threads=threads)
+            assert np.array_equal(nat.X, py.X) and nat.X.dtype == np.float32
+            assert np.array_equal(nat.site_kmers, py.site_kmers) and np.array_equal(nat.off, py.off)
+            assert nat.tx_ids == list(py.tx_ids) and np.array_equal(nat.tx_pos, py.tx_pos) and nat.kmer5 == py.kmer5
+            if len(dirs) == 1:
+                assert np.array_equal(nat.native.read_id_values, np.concatenate(py.read_ids))
+            else:
+                ids = ["%d_%d" % (v, r) for v, r in zip(nat.native.read_id_values, nat.native.read_rep)]
+                assert ids == [x for site in py.read_ids for x in site]
+            nat.native.close()
+
+
+def test_native_loader_without_normalisation_and_errors(tmp_path):
+    from m6anet_amd import _io
+    py = data_utils.load_sites([DATA], 20, None)
+    nat = data_utils.load_sites_native([DATA], 20, None)
+    assert np.array_equal(nat.X, py.X)
+    with pytest.raises(_io.M6AIOError):
+        data_utils.load_sites_native([str(tmp_path)], 20, None)                 # no data.info
+    with pytest.raises(_io.M6AIOError):
+        data_utils.load_sites_native([DATA], 100000, None)                      # nothing passes the filter
+    bad = tmp_path / "bad"
+    bad.mkdir()
+    (bad / "data.info").write_text(open(os.path.join(DATA, "data.info")).read())
+    (bad / "data.json").write_text(open(os.path.join(DATA, "data.json")).read()[:5000])
+    with pytest.raises(_io.M6AIOError):
+        data_utils.load_sites_native([str(bad)], 20, None)                      # truncated data.json
+
+
+def test_native_csv_bytes_equal_python_and_reference(golden, tmp_path):
+    import shutil
+    g = golden("bundled_site.npz")
+    rp = golden("bundled_readprob.npz")["hct116"]
+    site, mod = g["T5_bs16_spb2_seed0_site"], g["T5_bs16_spb2_seed0_mod"]
+    py = data_utils.load_sites([DATA], 20, "norm_hct116.npz")
+    nat = data_utils.load_sites_native([DATA], 20, "norm_hct116.npz")
+    out = tmp_path / "o"
+    out.mkdir()
+    nat.native.write_csv(str(out), rp, site, mod, write_header=True, n_threads=3)
+    want_site = inference_utils.SITE_HEADER + "".join(inference_utils.format_site_rows(py, site, mod))
+    want_indiv = inference_utils.INDIV_HEADER + "".join(inference_utils.format_indiv_rows(py, rp))
+    assert (out / "data.site_proba.csv").read_text() == want_site
+    assert (out / "data.indiv_proba.csv").read_text() == want_indiv
+    assert (out / "data.site_proba.csv").read_bytes() == open(os.path.join(GOLD, "config1_site_proba.csv"), "rb").read()
+    # replicates: "<id>_<rep>" read ids
+    rep = tmp_path / "rep1"
+    rep.mkdir()
+    for fn in ("data.info", "data.json"):
+        shutil.copyfile(os.path.join(DATA, fn), rep / fn)
+    py2 = data_utils.load_sites([DATA, str(rep)], 20, "norm_hct116.npz")
+    nat2 = data_utils.load_sites_native([DATA, str(rep)], 20, "norm_hct116.npz")
+    rp2 = np.random.Generator(np.random.PCG64(1)).random(py2.X.shape[0], dtype=np.float32)
+    sp2 = np.random.Generator(np.random.PCG64(2)).random(py2.n_sites, dtype=np.float32)
+    mr2 = np.random.Generator(np.random.PCG64(3)).random(py2.n_sites)
+    nat2.native.write_csv(str(out), rp2, sp2, mr2, write_header=True)
+    assert (out / "data.indiv_proba.csv").read_text() == inference_utils.INDIV_HEADER + "".join(inference_utils.format_indiv_rows(py2, rp2))
+    assert (out / "data.site_proba.csv").read_text() == inference_utils.SITE_HEADER + "".join(inference_utils.format_site_rows(py2, sp2, mr2))
