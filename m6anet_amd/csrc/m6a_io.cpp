@@ -422,7 +422,9 @@ int m6a_io_write_csv(const m6a_sites *s, const char *out_dir, const float *read_
     const int nw = n_workers(n_threads, S);
     const int64_t R = m6a_io_n_reads(s);
     int rc = 0;
-    const int64_t chunk_reads = 1 << 20;         // bound memory: ~64 MB of text per thread per round
+    // one chunk per worker per round; chunks of at most 2^20 reads bound the text held in memory
+    // (~64 MB per worker), at least 2^14 so tiny jobs do not spawn idle threads
+    const int64_t chunk_reads = std::max<int64_t>(1 << 14, std::min<int64_t>(1 << 20, (R + nw - 1) / nw));
     int64_t s_begin = 0;
     while (s_begin < S && !rc) {
         std::vector<int64_t> cuts{s_begin};
