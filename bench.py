@@ -132,18 +132,22 @@ def main():
     rp = torch.empty(R, dtype=torch.float32, device=dev)
     site = torch.empty(Sr, dtype=torch.float32, device=dev)
     mod = torch.empty(Sr, dtype=torch.float64, device=dev)
-    gbufs = {}
+    # the job's one exchange: site_prob + mod_ratio to rank 0, one packed gather per step (RCCL);
+    # issued async and double-buffered so the exchange of step i overlaps the compute of step i+1
+    gather = mdist.SiteGather(cuts, dev if backend == "nccl" else "cpu", dst=0) if world > 1 else None
 
     def step():
         eng.infer(X, km, off, T, 20, thr, 0, 16, 2, out=(rp, site, mod))
-        if world > 1:           # the job's one exchange: site_prob + mod_ratio to rank 0 (RCCL)
+        if world > 1:
             if backend == "nccl":
-                mdist.gather_sites(site, mod, cuts, dst=0, buffers=gbufs)
+                gather.start(site, mod)
             else:
                 eng.sync()
-                mdist.gather_sites(site.cpu(), mod.cpu(), cuts, dst=0, buffers=gbufs)
+                gather.start(site.cpu(), mod.cpu())
 
     def fence():
+        if gather is not None:
+            gather.drain()          # every gather issued so far has completed
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()

@@ -31,35 +31,71 @@ def my_shard(cuts, rank):
     return int(cuts[rank]), int(cuts[rank + 1])
 
 
+class SiteGather:
+    """The job's one exchange: every rank's (site_prob float32 [S_r], mod_ratio float64 [S_r]) to rank
+    `dst`, as ONE collective on a packed 12-byte-per-site buffer padded to the largest shard (so a
+    plain gather works for ragged cuts).  Double-buffered: `start()` may be called for the next step
+    while the previous gather is still in flight (async_op), which lets the exchange of step i
+    overlap the compute of step i+1; `finish()` waits and returns the tensors on rank `dst`."""
+
+    def __init__(self, cuts, device, dst=0, group=None):
+        import torch
+        import torch.distributed as dist
+        self.dist, self.torch = dist, torch
+        self.group, self.dst = group, dst
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.sizes = [int(x) for x in np.diff(np.asarray(cuts, np.int64))]
+        self.smax = max(self.sizes)
+        self.n = self.sizes[self.rank]
+        nbytes = 12 * self.smax
+        self.send = [torch.zeros(nbytes, dtype=torch.uint8, device=device) for _ in range(2)]
+        self.recv = [[torch.empty(nbytes, dtype=torch.uint8, device=device) for _ in range(self.world)]
+                     if self.rank == dst else None for _ in range(2)]
+        self.work = [None, None]
+        self.slot = 0
+
+    def start(self, site, mod):
+        k = self.slot
+        if self.work[k] is not None:          # buffer k is two steps old: its gather must be done
+            self.work[k].wait()
+        buf = self.send[k]
+        assert site.numel() == self.n and mod.numel() == self.n
+        buf[:4 * self.n].view(self.torch.float32).copy_(site)
+        buf[4 * self.smax:4 * self.smax + 8 * self.n].view(self.torch.float64).copy_(mod)
+        self.work[k] = self.dist.gather(buf, self.recv[k], dst=self.dst, group=self.group, async_op=True)
+        self.slot ^= 1
+        return k
+
+    def finish(self, k=None):
+        """Waits for gather `k` (default: the most recent); returns (site_all, mod_all) on dst."""
+        if k is None:
+            k = self.slot ^ 1
+        if self.work[k] is not None:
+            self.work[k].wait()
+            self.work[k] = None
+        if self.rank != self.dst:
+            return None, None
+        t = self.torch
+        site = t.cat([self.recv[k][r][:4 * self.sizes[r]].view(t.float32) for r in range(self.world)])
+        mod = t.cat([self.recv[k][r][4 * self.smax:4 * self.smax + 8 * self.sizes[r]].view(t.float64)
+                     for r in range(self.world)])
+        return site, mod
+
+    def drain(self):
+        for k in (0, 1):
+            if self.work[k] is not None:
+                self.work[k].wait()
+                self.work[k] = None
+
+
 def gather_sites(site, mod, cuts, dst=0, group=None, buffers=None):
-    """Gathers every rank's (site_prob float32 [S_r], mod_ratio float64 [S_r]) to rank `dst`.
-    Shards are padded to the largest shard so a plain gather works for ragged cuts.  Returns
-    (site_all, mod_all) tensors of length cuts[-1] on rank `dst`, (None, None) elsewhere.
-    `buffers` = dict reused across calls (avoids reallocating the padded staging tensors)."""
-    import torch
-    import torch.distributed as dist
-    world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
-    sizes = np.diff(np.asarray(cuts, np.int64))
-    smax = int(sizes.max())
+    """Blocking convenience wrapper around SiteGather: returns (site_all, mod_all) tensors of length
+    cuts[-1] on rank `dst`, (None, None) elsewhere.  `buffers` = dict reused across calls."""
     buffers = buffers if buffers is not None else {}
-    key = (smax, site.device, world)
+    key = (tuple(int(c) for c in cuts), str(site.device), dst)
     if buffers.get("key") != key:
         buffers.clear()
         buffers["key"] = key
-        buffers["ps"] = torch.zeros(smax, dtype=torch.float32, device=site.device)
-        buffers["pm"] = torch.zeros(smax, dtype=torch.float64, device=site.device)
-        if rank == dst:
-            buffers["gs"] = [torch.empty(smax, dtype=torch.float32, device=site.device) for _ in range(world)]
-            buffers["gm"] = [torch.empty(smax, dtype=torch.float64, device=site.device) for _ in range(world)]
-    n = site.numel()
-    assert n == int(sizes[rank]) and mod.numel() == n
-    buffers["ps"][:n].copy_(site)
-    buffers["pm"][:n].copy_(mod)
-    dist.gather(buffers["ps"], buffers.get("gs") if rank == dst else None, dst=dst, group=group)
-    dist.gather(buffers["pm"], buffers.get("gm") if rank == dst else None, dst=dst, group=group)
-    if rank != dst:
-        return None, None
-    site_all = torch.cat([buffers["gs"][r][:int(sizes[r])] for r in range(world)])
-    mod_all = torch.cat([buffers["gm"][r][:int(sizes[r])] for r in range(world)])
-    return site_all, mod_all
+        buffers["g"] = SiteGather(cuts, site.device, dst=dst, group=group)
+    g = buffers["g"]
+    return g.finish(g.start(site, mod))
