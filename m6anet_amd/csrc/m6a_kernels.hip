@@ -694,8 +694,11 @@ __global__ __launch_bounds__(256) void pool_scan_start_kernel(PoolArgs a)
                     const int tot = wave_sum_i32(cl);
                     if (acc + tot >= A) {
                         // the site's last accepted draw is in this step: walk its loads in stream order
+                        // (fully unrolled so w[] stays in registers; the early exit is a flag, not a break)
+                        bool found = false;
 #pragma unroll
                         for (int i = 0; i < M6A_SCAN_A_LOADS; i++) {
+                            if (found) continue;
                             const bool ok = (w[i] & mask) <= rng;
                             const unsigned long long bal = __ballot(ok);
                             const int c = __popcll(bal);
@@ -704,9 +707,10 @@ __global__ __launch_bounds__(256) void pool_scan_start_kernel(PoolArgs a)
                                                  __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0));
                                 const unsigned long long lastb = __ballot(ok && rank == A - acc - 1);
                                 pos += 64 * i + (uint32_t)__builtin_ctzll(lastb) + 1;
-                                break;
+                                found = true;
+                            } else {
+                                acc += c;
                             }
-                            acc += c;
                         }
                         break;
                     }
@@ -735,7 +739,7 @@ __global__ __launch_bounds__(256) void pool_scan_start_kernel(PoolArgs a)
 // sites, conflict-free, and v_pk_mul_f32 advances both products.  Inner loop = LDS + VALU only.
 // =====================================================================================
 #define M6A_TAB_RC 16                       // rounds per LDS chunk
-__global__ __launch_bounds__(256, 6) void pool_table_kernel(PoolArgs a)
+__global__ __launch_bounds__(256, 5) void pool_table_kernel(PoolArgs a)
 {
     __shared__ __attribute__((aligned(16))) uint32_t s_idx[M6A_TAB_RC * 5 * 64];
     // bag arrays: pair p of wave w lives at byte p*2112 + w*256 (+ 8*idx + 4*e).  The odd 2112 B
