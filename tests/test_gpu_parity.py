@@ -363,6 +363,37 @@ def test_job_offset_shards_equal_whole_job(eng):
         assert np.array_equal(np.concatenate([p[2] for p in parts]), mod)
 
 
+def test_soak_repeated_runs_are_bit_identical(engines):
+    """40 back-to-back runs of both pooling paths and both encoder kernels under a busy GPU: any
+    missing LDS ordering / prefetch hazard shows up as a run that differs."""
+    import torch
+    dev = torch.device("cuda:0")
+    for bag, model in ((20, "hct116"), ((20, 200), "hek293t_glori")):
+        eng = engines[model]
+        d = synthetic.make_sites(30000, bag, seed=12)
+        X, km, off = (torch.from_numpy(d[k]).to(dev) for k in ("X", "site_kmers", "off"))
+        eng.use_torch_stream()
+        try:
+            ref = None
+            for i in range(40):
+                eng.set_encoder_variant(1 + (i & 1) if bag == 20 else 0)
+                rp, site, mod = eng.infer(X, km, off, 300)
+                eng.sync()
+                cur = (rp.clone(), site.clone(), mod.clone())
+                key = i & 1 if bag == 20 else 0
+                if ref is None:
+                    ref = {}
+                if key not in ref:
+                    ref[key] = cur
+                else:
+                    assert all(torch.equal(a, b) for a, b in zip(cur, ref[key])), (bag, i)
+            if bag == 20:       # the two encoder kernels agree to float32 rounding
+                assert torch.allclose(ref[0][0], ref[1][0], rtol=1e-5, atol=1e-8)
+        finally:
+            eng.set_encoder_variant(0)
+            eng.set_stream(None)
+
+
 # ------------------------------------------------------------------ full size ------------------
 def test_full_size_properties(eng, orc, weights):
     """BASELINE.json configs[2] size (1M sites x 20 reads, T=1000): size-independent checks.
