@@ -54,6 +54,18 @@ const char *m6a_io_kmer5(const m6a_sites *s, int64_t site);    /* centre 5-mer, 
 int m6a_io_write_csv(const m6a_sites *s, const char *out_dir, const float *read_prob,
                      const float *site_prob, const double *mod_ratio, int write_header, int n_threads);
 
+/* `m6anet dataprep` (m6anet/scripts/dataprep.py:54-70 -> m6anet/utils/dataprep_utils.py):
+ * eventalign.txt -> <out_dir>/eventalign.index (parallel_index, :187-266), data.json + data.info +
+ * data.log (combine :269-325, filter_events :19-168, preprocess_tx :399-488).  Same arithmetic as
+ * the reference on pandas >= 1.3 (Kahan-compensated group sums, np.round half-to-even, floats
+ * printed as Python repr) and the reference's n_processes = 1 record order (transcripts in index
+ * order, positions ascending); inside a position reads stay in index order (the reference's order
+ * there comes from an unstable argsort and is machine-dependent).  n_neighbors must be 1.
+ * skip_index != 0 reads an existing eventalign.index instead of rebuilding it. */
+int m6a_io_dataprep(const char *eventalign_path, const char *out_dir, int n_threads,
+                    int readcount_min, int readcount_max, int min_segment_count, int n_neighbors,
+                    int compress, int skip_index);
+
 #ifdef __cplusplus
 }
 #endif

@@ -8,7 +8,8 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libm6a_io.so")
 SYMBOLS = ["m6a_io_last_error", "m6a_io_load_sites", "m6a_io_free", "m6a_io_n_sites", "m6a_io_n_reads",
            "m6a_io_n_replicates", "m6a_io_X", "m6a_io_site_kmers", "m6a_io_off", "m6a_io_tx_pos",
-           "m6a_io_read_ids", "m6a_io_read_rep", "m6a_io_tx_id", "m6a_io_kmer5", "m6a_io_write_csv"]
+           "m6a_io_read_ids", "m6a_io_read_rep", "m6a_io_tx_id", "m6a_io_kmer5", "m6a_io_write_csv",
+           "m6a_io_dataprep"]
 _lib = None
 
 
@@ -38,6 +39,7 @@ def load():
         getattr(L, name).argtypes = [vp, i64]
         getattr(L, name).restype = C.c_char_p
     L.m6a_io_write_csv.argtypes = [vp, C.c_char_p, vp, vp, vp, i32, i32]
+    L.m6a_io_dataprep.argtypes = [C.c_char_p, C.c_char_p, i32, i32, i32, i32, i32, i32, i32]
     _lib = L
     return L
 
@@ -45,6 +47,15 @@ def load():
 def _chk(rc):
     if rc != 0:
         raise M6AIOError("m6a_io error %d: %s" % (rc, load().m6a_io_last_error().decode()))
+
+
+def dataprep(eventalign, out_dir, n_threads=0, readcount_min=1, readcount_max=1000, min_segment_count=20,
+             n_neighbors=1, compress=False, skip_index=False):
+    """Native `m6anet dataprep` (m6anet/scripts/dataprep.py:54-70)."""
+    os.makedirs(out_dir, exist_ok=True)
+    _chk(load().m6a_io_dataprep(os.fsencode(eventalign), os.fsencode(out_dir), int(n_threads), int(readcount_min),
+                                int(readcount_max), int(min_segment_count), int(n_neighbors), 1 if compress else 0,
+                                1 if skip_index else 0))
 
 
 class NativeSites:

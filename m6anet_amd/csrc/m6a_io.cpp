@@ -8,6 +8,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <charconv>
 #include <clocale>
 #include <cstdlib>
 #include <locale.h>
@@ -15,7 +16,9 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <array>
 #include <map>
+#include <mutex>
 #include <set>
 #include <string>
 #include <thread>
@@ -481,3 +484,358 @@ int m6a_io_write_csv(const m6a_sites *s, const char *out_dir, const float *read_
 }
 
 }  // extern "C"
+
+
+// =====================================================================================================
+// dataprep: eventalign.txt -> eventalign.index, data.json, data.info, data.log
+// (m6anet/scripts/dataprep.py:54-70 -> m6anet/utils/dataprep_utils.py)
+// =====================================================================================================
+namespace {
+
+struct IdxRow { std::string tx; long long read; int64_t start, end; };
+
+// repr(float): shortest digits that round-trip; fixed notation for 1e-4 <= |x| < 1e16, else exponent
+void py_repr(double v, std::string &out)
+{
+    if (v == 0) { out += std::signbit(v) ? "-0.0" : "0.0"; return; }
+    if (!std::isfinite(v)) { out += std::isnan(v) ? "NaN" : (v < 0 ? "-Infinity" : "Infinity"); return; }
+    char buf[64];
+    auto r = std::to_chars(buf, buf + sizeof buf, v, std::chars_format::scientific);   // shortest, d.ddde+XX
+    std::string sci(buf, r.ptr);
+    size_t epos = sci.find('e');
+    std::string mant = sci.substr(0, epos);
+    const int exp10 = std::stoi(sci.substr(epos + 1));
+    bool neg = false;
+    if (mant[0] == '-') { neg = true; mant.erase(0, 1); }
+    std::string digits;
+    for (char c : mant) if (c != '.') digits += c;
+    if (neg) out += '-';
+    if (exp10 >= -4 && exp10 < 16) {
+        if (exp10 < 0) {
+            out += "0.";
+            out.append((size_t)(-exp10 - 1), '0');
+            out += digits;
+        } else if ((int)digits.size() <= exp10 + 1) {
+            out += digits;
+            out.append((size_t)(exp10 + 1 - (int)digits.size()), '0');
+            out += ".0";
+        } else {
+            out.append(digits, 0, (size_t)exp10 + 1);
+            out += '.';
+            out.append(digits, (size_t)exp10 + 1, std::string::npos);
+        }
+    } else {
+        out += digits[0];
+        if (digits.size() > 1) { out += '.'; out.append(digits, 1, std::string::npos); }
+        char eb[16];
+        snprintf(eb, sizeof eb, "e%c%02d", exp10 < 0 ? '-' : '+', std::abs(exp10));
+        out += eb;
+    }
+}
+
+// np.round(x, d): x * 10^d, rint (half to even), / 10^d
+inline double np_round(double x, double scale) { return std::nearbyint(x * scale) / scale; }
+
+// pandas groupby sum (pandas/_libs/groupby.pyx group_sum): Kahan-compensated
+struct Kahan {
+    double sum = 0, comp = 0;
+    void add(double v)
+    {
+        const double y = v - comp, t = sum + y;
+        comp = t - sum - y;
+        if (comp != comp) comp = 0;
+        sum = t;
+    }
+};
+
+struct Pos { long long position; std::string kmer; double dwell, sd, mean; };
+
+const std::set<std::string> &drach18()
+{
+    static const std::set<std::string> s = [] {
+        std::set<std::string> r;
+        for (char d : std::string("AGT")) for (char g : std::string("GA")) for (char h : std::string("ACT"))
+            r.insert(std::string{d, g, 'A', 'C', h});
+        return r;
+    }();
+    return s;
+}
+
+// split one line into tab-separated fields (pointers into the mapping)
+inline int split_tabs(const char *p, const char *e, const char *(&b)[16], const char *(&en)[16])
+{
+    int n = 0;
+    const char *q = p;
+    while (n < 16) {
+        b[n] = q;
+        while (q < e && *q != '\t') ++q;
+        en[n] = q;
+        ++n;
+        if (q >= e) break;
+        ++q;
+    }
+    return n;
+}
+
+// combine() for the lines of ONE (contig, read) run: per position the length-weighted means
+// (dataprep_utils.py:269-325).  Returns false on malformed input.
+bool combine_read(const char *p, const char *e, std::vector<Pos> &out)
+{
+    struct Ev { long long position; std::string kmer; double mean, sd, len_s; long long length; };
+    std::vector<Ev> evs;
+    while (p < e) {
+        const char *le = (const char *)memchr(p, '\n', (size_t)(e - p));
+        if (!le) le = e;
+        const char *eol = le;
+        if (eol > p && eol[-1] == '\r') --eol;
+        if (eol > p) {
+            const char *b[16], *en[16];
+            const int nf = split_tabs(p, eol, b, en);
+            if (nf < 15) return false;
+            // reference_kmer == model_kmer  (dataprep_utils.py:287)
+            if ((en[2] - b[2]) == (en[9] - b[9]) && memcmp(b[2], b[9], (size_t)(en[2] - b[2])) == 0) {
+                Ev ev;
+                double pos, st, ed;
+                Cursor c1{b[1], en[1]}, c6{b[6], en[6]}, c7{b[7], en[7]}, c8{b[8], en[8]}, c13{b[13], en[13]}, c14{b[14], en[14]};
+                if (!c1.num(pos) || !c6.num(ev.mean) || !c7.num(ev.sd) || !c8.num(ev.len_s) || !c13.num(st) || !c14.num(ed)) return false;
+                ev.position = (long long)pos;
+                ev.length = (long long)ed - (long long)st;
+                ev.kmer.assign(b[2], en[2]);
+                evs.push_back(std::move(ev));
+            }
+        }
+        p = le + 1;
+    }
+    // groupby(['read_index','contig','position','reference_kmer']): sorted keys, rows in file order
+    std::vector<size_t> order(evs.size());
+    for (size_t i = 0; i < order.size(); i++) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b2) {
+        if (evs[a].position != evs[b2].position) return evs[a].position < evs[b2].position;
+        return evs[a].kmer < evs[b2].kmer;
+    });
+    size_t i = 0;
+    while (i < order.size()) {
+        size_t j = i;
+        Kahan sm, ss, sd;
+        long long total = 0;
+        const Ev &first = evs[order[i]];
+        while (j < order.size() && evs[order[j]].position == first.position && evs[order[j]].kmer == first.kmer) {
+            const Ev &ev = evs[order[j]];
+            const double len = (double)ev.length;
+            sm.add(ev.mean * len);
+            ss.add(ev.sd * len);
+            sd.add(ev.len_s * len);
+            total += ev.length;
+            ++j;
+        }
+        Pos ps;
+        ps.position = first.position;
+        ps.kmer = first.kmer;
+        ps.mean = np_round(sm.sum / (double)total, 10.0);      // (sum_norm_mean/total_length).round(1)
+        ps.sd = ss.sum / (double)total;
+        ps.dwell = sd.sum / (double)total;
+        out.push_back(std::move(ps));
+        i = j;
+    }
+    return true;
+}
+
+struct SiteRow { long long pos; std::string kmer7; double f[9]; long long read; };
+
+struct TxOut {
+    std::string json;                                  // all records of the transcript
+    std::vector<std::array<long long, 4>> recs;        // pos, offset in json, length, n_reads
+    bool done = false;
+    int rc = 0;
+    std::string err;
+};
+
+}  // namespace
+
+extern "C" int m6a_io_dataprep(const char *eventalign_path, const char *out_dir, int n_threads,
+                               int readcount_min, int readcount_max, int min_segment_count, int n_neighbors,
+                               int compress, int skip_index)
+{
+    if (!eventalign_path || !out_dir) return fail(M6A_IO_EINVAL, "null argument");
+    if (n_neighbors != 1) return fail(M6A_IO_EINVAL, "only n_neighbors = 1 is supported (the shipped models use 1)");
+    Mapped ev;
+    int rc = ev.open(eventalign_path);
+    if (rc) return rc;
+    const char *base = ev.p, *end = ev.p + ev.n;
+    const std::string dir(out_dir);
+
+    // ---- index (parallel_index, dataprep_utils.py:187-266): one row per contiguous (contig, read_index) run
+    std::vector<IdxRow> idx;
+    const std::string idx_path = dir + "/eventalign.index";
+    if (skip_index) {
+        FILE *f = fopen(idx_path.c_str(), "r");
+        if (!f) return fail(M6A_IO_EIO, "--skip_index but %s does not exist", idx_path.c_str());
+        char line[4096];
+        bool first = true;
+        while (fgets(line, sizeof line, f)) {
+            if (first) { first = false; continue; }
+            char *c = strrchr(line, ',');
+            if (!c) continue;
+            IdxRow r;
+            r.end = atoll(c + 1); *c = 0;
+            c = strrchr(line, ','); r.start = atoll(c + 1); *c = 0;
+            c = strrchr(line, ','); r.read = atoll(c + 1); *c = 0;
+            r.tx = line;
+            idx.push_back(std::move(r));
+        }
+        fclose(f);
+    } else {
+        const char *p = (const char *)memchr(base, '\n', ev.n);
+        if (!p) return fail(M6A_IO_EFORMAT, "%s: no header line", eventalign_path);
+        ++p;
+        while (p < end) {
+            const char *le = (const char *)memchr(p, '\n', (size_t)(end - p));
+            const char *next = le ? le + 1 : end;
+            const char *t1 = (const char *)memchr(p, '\t', (size_t)(next - p));
+            if (!t1) { p = next; continue; }
+            const char *q = t1;
+            for (int k = 0; k < 2 && q; k++) q = (const char *)memchr(q + 1, '\t', (size_t)(next - q - 1));
+            if (!q) return fail(M6A_IO_EFORMAT, "%s: short line at byte %lld", eventalign_path, (long long)(p - base));
+            const long long read = atoll(q + 1);
+            if (idx.empty() || idx.back().read != read || idx.back().tx.size() != (size_t)(t1 - p) ||
+                memcmp(idx.back().tx.data(), p, (size_t)(t1 - p)) != 0)
+                idx.push_back(IdxRow{std::string(p, t1), read, (int64_t)(p - base), (int64_t)(p - base)});
+            idx.back().end = (int64_t)(next - base);
+            p = next;
+        }
+        FILE *f = fopen(idx_path.c_str(), "w");
+        if (!f) return fail(M6A_IO_EIO, "cannot write %s", idx_path.c_str());
+        fputs("transcript_id,read_index,pos_start,pos_end\n", f);
+        for (const auto &r : idx) fprintf(f, "%s,%lld,%lld,%lld\n", r.tx.c_str(), r.read, (long long)r.start, (long long)r.end);
+        if (fclose(f) != 0) return fail(M6A_IO_EIO, "cannot close %s", idx_path.c_str());
+    }
+
+    // ---- transcripts in order of first appearance, with their index rows in file order
+    std::vector<std::string> tx_order;
+    std::unordered_map<std::string, std::vector<size_t>> tx_rows;
+    for (size_t i = 0; i < idx.size(); i++) {
+        auto it = tx_rows.find(idx[i].tx);
+        if (it == tx_rows.end()) { tx_order.push_back(idx[i].tx); it = tx_rows.emplace(idx[i].tx, std::vector<size_t>()).first; }
+        it->second.push_back(i);
+    }
+
+    // ---- per transcript: combine -> window -> DRACH filter -> group by position (parallel_preprocess_tx + preprocess_tx)
+    const int64_t NT = (int64_t)tx_order.size();
+    std::vector<TxOut> outs((size_t)NT);
+    std::vector<char> wanted((size_t)NT, 0);
+    auto do_tx = [&](int64_t ti) {
+        TxOut &o = outs[(size_t)ti];
+        const std::string &tx = tx_order[(size_t)ti];
+        const auto &rows = tx_rows[tx];
+        // data_dict: read_index -> combined events, insertion order of first appearance (a repeated
+        // read_index overwrites its entry but keeps its place, like a Python dict)
+        std::vector<long long> read_order;
+        std::unordered_map<long long, std::vector<Pos>> by_read;
+        int readcount = 0;
+        for (size_t ri : rows) {
+            const IdxRow &r = idx[ri];
+            if (r.start < 0 || r.end > (int64_t)ev.n || r.start > r.end) { o.rc = M6A_IO_EFORMAT; o.err = "index row outside eventalign.txt"; return; }
+            std::vector<Pos> ps;
+            if (!combine_read(base + r.start, base + r.end, ps)) { o.rc = M6A_IO_EFORMAT; o.err = "malformed eventalign line for " + tx; return; }
+            if (ps.size() > 1) {                          // `if data.size > 1`
+                if (!by_read.count(r.read)) read_order.push_back(r.read);
+                by_read[r.read] = std::move(ps);
+            }
+            if (++readcount > readcount_max) break;      // (sic) up to readcount_max + 1 reads
+        }
+        if (readcount < readcount_min) return;
+        wanted[(size_t)ti] = 1;
+        std::vector<SiteRow> sites;
+        for (long long rd : read_order) {
+            const std::vector<Pos> &ps = by_read[rd];     // sorted by position already
+            size_t a = 0;
+            while (a < ps.size()) {                       // runs of consecutive positions
+                size_t b = a + 1;
+                while (b < ps.size() && ps[b].position == ps[b - 1].position + 1) ++b;
+                if (b - a >= 3) {
+                    for (size_t i = a + 1; i + 1 < b; i++) {
+                        if (!drach18().count(ps[i].kmer)) continue;
+                        SiteRow sr;
+                        sr.pos = ps[i].position + 2;      // centre of the 5-mer
+                        sr.kmer7 = ps[i - 1].kmer;
+                        sr.kmer7 += ps[i].kmer.back();
+                        sr.kmer7 += ps[i + 1].kmer.back();
+                        for (int w = 0; w < 3; w++) {
+                            const Pos &q = ps[i - 1 + (size_t)w];
+                            sr.f[3 * w] = q.dwell; sr.f[3 * w + 1] = q.sd; sr.f[3 * w + 2] = q.mean;
+                        }
+                        sr.read = rd;
+                        sites.push_back(std::move(sr));
+                    }
+                }
+                a = b;
+            }
+        }
+        if (sites.empty()) return;
+        // reference: np.argsort(positions) (unstable, machine-dependent order inside a position);
+        // here: stable, i.e. reads stay in index order inside a position
+        std::stable_sort(sites.begin(), sites.end(), [](const SiteRow &x, const SiteRow &y) { return x.pos < y.pos; });
+        size_t i = 0;
+        while (i < sites.size()) {
+            size_t j = i;
+            while (j < sites.size() && sites[j].pos == sites[i].pos) {
+                if (sites[j].kmer7 != sites[i].kmer7) { o.rc = M6A_IO_EFORMAT; o.err = "reads disagree on the sequence at " + tx + ":" + std::to_string(sites[i].pos); return; }
+                ++j;
+            }
+            if ((int)(j - i) >= min_segment_count) {
+                const size_t start = o.json.size();
+                o.json += "{\"" + tx + "\":{\"" + std::to_string(sites[i].pos) + "\":{\"" + sites[i].kmer7 + "\":[";
+                for (size_t k = i; k < j; k++) {
+                    o.json += k == i ? "[" : ",[";
+                    for (int c = 0; c < 9; c++) {
+                        py_repr(compress ? np_round(sites[k].f[c], 1000.0) : sites[k].f[c], o.json);
+                        o.json += ',';
+                    }
+                    py_repr((double)sites[k].read, o.json);
+                    o.json += ']';
+                }
+                o.json += "]}}}\n";
+                o.recs.push_back({sites[i].pos, (long long)start, (long long)(o.json.size() - start), (long long)(j - i)});
+            }
+            i = j;
+        }
+    };
+    {
+        const int nw = n_workers(n_threads, NT);
+        std::vector<std::thread> th;
+        std::vector<int64_t> next(1, 0);
+        std::mutex mu;
+        auto worker = [&]() {
+            for (;;) {
+                int64_t t;
+                { std::lock_guard<std::mutex> g(mu); t = next[0]++; }
+                if (t >= NT) break;
+                do_tx(t);
+            }
+        };
+        for (int w = 1; w < nw; w++) th.emplace_back(worker);
+        worker();
+        for (auto &t : th) t.join();
+    }
+    for (int64_t t = 0; t < NT; t++)
+        if (outs[(size_t)t].rc) return fail(outs[(size_t)t].rc, "%s", outs[(size_t)t].err.c_str());
+
+    // ---- write data.json / data.info / data.log in transcript order
+    FILE *fj = fopen((dir + "/data.json").c_str(), "w"), *fi = fopen((dir + "/data.info").c_str(), "w"), *fl = fopen((dir + "/data.log").c_str(), "w");
+    if (!fj || !fi || !fl) { if (fj) fclose(fj); if (fi) fclose(fi); if (fl) fclose(fl); return fail(M6A_IO_EIO, "cannot write into %s", out_dir); }
+    fputs("transcript_id,transcript_position,start,end,n_reads\n", fi);
+    long long off = 0;
+    for (int64_t t = 0; t < NT; t++) {
+        const TxOut &o = outs[(size_t)t];
+        if (!wanted[(size_t)t]) continue;
+        if (!o.json.empty()) fwrite(o.json.data(), 1, o.json.size(), fj);
+        for (const auto &r : o.recs)
+            fprintf(fi, "%s,%lld,%lld,%lld,%lld\n", tx_order[(size_t)t].c_str(), r[0], off + r[1], off + r[1] + r[2], r[3]);
+        off += (long long)o.json.size();
+        if (!o.recs.empty() || !o.json.empty() || true) fprintf(fl, "%s: Data preparation ... Done.\n", tx_order[(size_t)t].c_str());
+    }
+    int bad = 0;
+    bad |= fclose(fj); bad |= fclose(fi); bad |= fclose(fl);
+    if (bad) return fail(M6A_IO_EIO, "cannot close outputs in %s", out_dir);
+    return M6A_IO_OK;
+}

@@ -28,7 +28,10 @@ What each file pins (reference file:line):
   config1_*.csv(.gz)               exact CSV bytes (inference_utils.py:62-67)
   ref_tests_data/                  the reference's own test fixtures (data files only):
                                    m6anet/tests/data/{data.info,data.json,
-                                   data.site_proba.csv.gz,data.indiv_proba.csv.gz}
+                                   data.site_proba.csv.gz,data.indiv_proba.csv.gz,
+                                   eventalign.txt(.gz here),eventalign.index}
+  dataprep_ref_run/                parallel_index + parallel_preprocess_tx at n_processes=1
+                                   (m6anet/utils/dataprep_utils.py:210-266,328-488)
 """
 import gzip
 import io
@@ -168,7 +171,37 @@ def parse_site_csv(b):
     return df
 
 
+def dataprep_goldens():
+    """eventalign.txt -> index / data.json / data.info through the reference at n_processes=1
+    (m6anet/scripts/dataprep.py:54-70), plus the reference's own fixtures (data files only)."""
+    from m6anet.utils.dataprep_utils import parallel_index, parallel_preprocess_tx
+    rdir = os.path.join(HERE, "ref_tests_data")
+    os.makedirs(rdir, exist_ok=True)
+    with open(os.path.join(DATA, "eventalign.txt"), "rb") as f, \
+            gzip.GzipFile(os.path.join(rdir, "eventalign.txt.gz"), "wb", mtime=0) as g:
+        g.write(f.read())
+    shutil.copyfile(os.path.join(DATA, "eventalign.index"), os.path.join(rdir, "eventalign.index"))
+    os.chmod(os.path.join(rdir, "eventalign.index"), 0o644)
+    out = os.path.join(HERE, "dataprep_ref_run")
+    os.makedirs(out, exist_ok=True)
+    for tag, kw in (("msc1", dict(min_segment_count=1, compress=False)),
+                    ("msc20_compress", dict(min_segment_count=20, compress=True))):
+        tmp = tempfile.mkdtemp(prefix="m6a_dp_")
+        parallel_index(os.path.join(DATA, "eventalign.txt"), 1000000, tmp, 1)
+        assert open(os.path.join(tmp, "eventalign.index")).read() == open(os.path.join(DATA, "eventalign.index")).read()
+        parallel_preprocess_tx(os.path.join(DATA, "eventalign.txt"), tmp, 1, 1, 1000, 1, kw["min_segment_count"], kw["compress"])
+        with open(os.path.join(tmp, "data.json"), "rb") as f, gzip.GzipFile(os.path.join(out, tag + ".data.json.gz"), "wb", mtime=0) as g:
+            g.write(f.read())
+        shutil.copyfile(os.path.join(tmp, "data.info"), os.path.join(out, tag + ".data.info"))
+        shutil.rmtree(tmp)
+        print("dataprep golden", tag)
+
+
 def main():
+    if "--only-dataprep" in sys.argv:
+        dataprep_goldens()
+        return
+    dataprep_goldens()
     os.makedirs(ASSETS, exist_ok=True)
     np.set_printoptions(precision=9)
 

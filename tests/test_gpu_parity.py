@@ -496,3 +496,32 @@ def test_cli_reference_test_suite_bar(tmp_path):
 def test_cli_rejects_cpu_device(tmp_path):
     with pytest.raises(ValueError):
         _run_cli(tmp_path, ["--device", "cpu"])
+
+
+def test_full_pipeline_from_eventalign(tmp_path):
+    """eventalign.txt -> native dataprep -> inference CLI on the GPU, against the reference's golden
+    CSVs.  Read order inside a site differs from the reference's data.json (machine-dependent there),
+    so: ids / n_reads / k-mers exact, read probabilities equal as per-site multisets (allclose),
+    mod_ratio exact, site probabilities at the reference's own bar (atol 1e-2, T=10000)."""
+    import gzip
+    import os
+    import pandas as pd
+    from m6anet_amd.__main__ import main
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_tests_data")
+    ev = tmp_path / "eventalign.txt"
+    ev.write_bytes(gzip.open(os.path.join(gold, "eventalign.txt.gz"), "rb").read())
+    prep, out = str(tmp_path / "prep"), str(tmp_path / "out")
+    main(["dataprep", "--eventalign", str(ev), "--out_dir", prep, "--n_processes", "0", "--min_segment_count", "1"])
+    main(["inference", "--input_dir", prep, "--out_dir", out, "--num_iterations", "10000"])
+    key_s = ["transcript_id", "transcript_position"]
+    ts = pd.read_csv(os.path.join(out, "data.site_proba.csv")).sort_values(key_s).reset_index(drop=True)
+    gs = pd.read_csv(os.path.join(gold, "data.site_proba.csv.gz")).sort_values(key_s).reset_index(drop=True)
+    for k in key_s + ["n_reads", "kmer"]:
+        assert (ts[k] == gs[k]).all(), k
+    assert np.allclose(ts["mod_ratio"], gs["mod_ratio"])
+    assert np.allclose(ts["probability_modified"], gs["probability_modified"], atol=1e-2)
+    key_i = key_s + ["read_index"]
+    ti = pd.read_csv(os.path.join(out, "data.indiv_proba.csv")).sort_values(key_i).reset_index(drop=True)
+    gi = pd.read_csv(os.path.join(gold, "data.indiv_proba.csv.gz")).sort_values(key_i).reset_index(drop=True)
+    assert (ti[key_i].values == gi[key_i].values).all()
+    assert np.allclose(ti["probability_modified"], gi["probability_modified"], rtol=2e-5, atol=1e-7)
