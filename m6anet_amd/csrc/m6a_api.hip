@@ -47,6 +47,20 @@ struct Profiler {
 
 }  // namespace
 
+// NumPy's float32 pairwise sum as a plan (built by build_mean_plan below)
+struct MeanPlan {
+    int T = 0;
+    std::vector<int> leaf_start;        // [L+1]
+    std::vector<uint8_t> merge_after;   // [L]
+    // table kernel rows, 4 dwords each: flags (bit 24 pass ends here, bit 25 tail row, bits 26-29 leaves
+    // in the pass, bit 30 last pass) | live-lane mask lo | hi | merge_after of the pass's leaves (nibbles)
+    std::vector<uint32_t> row_meta;
+    std::vector<int> row_pass, row_round;   // host side of the same rows (pass -1 = tail row)
+    int n_rem = 0;
+    int depth = 1;                      // deepest the merge stack gets
+    int max_merge = 0;                  // largest merge_after[]
+};
+
 struct m6a_ctx {
     int device = 0;
     int n_cu = 256;
@@ -57,7 +71,8 @@ struct m6a_ctx {
     float *d_wfrag = nullptr, *d_wfrag2 = nullptr, *d_w1e = nullptr, *d_emb = nullptr;
     float b3 = 0.f;
     // sampling state (device) + what it was built for
-    DevBuf raw, tab, goff, rp_scratch, off_scratch, start_pos;
+    DevBuf raw, tab, goff, rp_scratch, off_scratch, start_pos, plan_dev;
+    MeanPlan plan; size_t plan_off[3] = {0, 0, 0};
     uint32_t raw_seed = 0; int64_t raw_len = 0;
     struct { uint32_t seed; int n, T, K, jmax; bool valid; } tab_key = {0, 0, 0, 0, 0, false};
     struct { int64_t S, bs, spb, base, G, gmax; bool valid; } goff_key = {0, 0, 0, 0, 0, 0, false};
@@ -228,26 +243,148 @@ int ensure_raw(m6a_ctx *c, uint32_t seed, int64_t len)
     return M6A_OK;
 }
 
+// ---- NumPy's float32 pairwise sum, as a plan ------------------------------------------------------
+// ndarray.mean() of the T per-iteration values is add.reduce's pairwise summation
+// (numpy/core/src/umath/loops_utils.h.src): n <= 128 -> a LEAF: 8 interleaved accumulators
+// r[k] += a[8i+k] over the first n - n%8 elements, combined ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)),
+// then the n%8 tail added one by one (n < 8: everything is tail); n > 128 -> split at
+// n2 = n/2 - (n/2)%8 and add the two halves.  The kernels make lanes the accumulator chains and
+// replay the tree as "push leaf sum, then merge_after[leaf] times: pop two, push their sum".
+void pairwise_rec(int lo, int n, MeanPlan &p)
+{
+    if (n <= 128) {
+        p.leaf_start.push_back(lo);
+        p.merge_after.push_back(0);
+        return;
+    }
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    pairwise_rec(lo, n2, p);
+    pairwise_rec(lo + n2, n - n2, p);
+    p.merge_after.back()++;             // the MERGE event follows the right subtree's last leaf
+}
+
+// iteration handled by (row, lane) of the table kernel, or -1: lane = accumulator chain (lane & 7) of
+// leaf 8*pass + lane/8, row = round of the pass; the tail row holds the last leaf's n % 8 elements
+int plan_iteration(const MeanPlan &p, int row, int lane)
+{
+    const int L = (int)p.merge_after.size();
+    const int ps = p.row_pass[row], i = p.row_round[row];
+    if (ps < 0) return lane < p.n_rem ? p.T - p.n_rem + lane : -1;
+    const int b = 8 * ps + (lane >> 3);
+    if (b >= L) return -1;
+    const int len = p.leaf_start[b + 1] - p.leaf_start[b];
+    return i < len / 8 ? p.leaf_start[b] + 8 * i + (lane & 7) : -1;
+}
+
+void build_mean_plan(int T, MeanPlan &p)
+{
+    p = MeanPlan();
+    p.T = T;
+    pairwise_rec(0, T, p);
+    p.leaf_start.push_back(T);
+    const int L = (int)p.merge_after.size();
+    const int last_len = p.leaf_start[L] - p.leaf_start[L - 1];
+    p.n_rem = last_len % 8;             // only the rightmost leaf can have a tail (every n2 is a multiple of 8)
+    // table-kernel rows: the tail row first (its values wait in LDS for the last leaf), then per pass of 8
+    // leaves as many rounds as its longest chain; the last row of a pass carries the flush
+    if (p.n_rem) { p.row_pass.push_back(-1); p.row_round.push_back(0); }
+    const int P = (L + 7) / 8;
+    for (int ps = 0; ps < P; ps++) {
+        int rounds = 0;
+        for (int b = 8 * ps; b < std::min(L, 8 * ps + 8); b++)
+            rounds = std::max(rounds, (p.leaf_start[b + 1] - p.leaf_start[b]) / 8);
+        rounds = std::max(rounds, 1);   // T < 8: no chains at all, the row only carries the flush
+        for (int i = 0; i < rounds; i++) { p.row_pass.push_back(ps); p.row_round.push_back(i); }
+    }
+    int d = 0;
+    for (int b = 0; b < L; b++) {
+        d++; p.depth = std::max(p.depth, d); d -= p.merge_after[b];
+        p.max_merge = std::max<int>(p.max_merge, p.merge_after[b]);
+    }
+    const int rows = (int)p.row_pass.size();
+    p.row_meta.assign((size_t)rows * 4, 0u);
+    for (int r = 0; r < rows; r++) {
+        uint32_t *m = &p.row_meta[(size_t)r * 4];
+        uint64_t live = 0;
+        for (int l = 0; l < 64; l++) live |= (uint64_t)(plan_iteration(p, r, l) >= 0) << l;
+        m[1] = (uint32_t)live; m[2] = (uint32_t)(live >> 32);
+        const int ps = p.row_pass[r];
+        if (ps < 0) { m[0] = 1u << 25; continue; }
+        if (r + 1 == rows || p.row_pass[r + 1] != ps) {
+            const int nl = std::min(8, L - 8 * ps);
+            m[0] = (1u << 24) | ((uint32_t)nl << 26) | (ps == P - 1 ? 1u << 30 : 0u);
+            for (int bl = 0; bl < nl; bl++) m[3] |= (uint32_t)(p.merge_after[8 * ps + bl] & 15) << (4 * bl);
+        }
+    }
+}
+
+int ensure_mean_plan(m6a_ctx *c, int T)
+{
+    if (c->plan.T == T && c->plan_dev.p) return M6A_OK;
+    build_mean_plan(T, c->plan);
+    const MeanPlan &p = c->plan;
+    if (p.depth > M6A_MEAN_STACK) return fail(c, M6A_EUNSUPPORTED, "n_iters %d: pairwise-sum tree deeper than %d", T, M6A_MEAN_STACK);
+    const size_t b0 = p.leaf_start.size() * 4, b1 = (p.merge_after.size() + 3) / 4 * 4, b2 = std::max<size_t>(p.row_meta.size(), 1) * 4;
+    HIPCHK(c, c->plan_dev.ensure(b0 + b1 + b2));
+    char *d = (char *)c->plan_dev.p;
+    HIPCHK(c, hipMemcpyAsync(d, p.leaf_start.data(), b0, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d + b0, p.merge_after.data(), p.merge_after.size(), hipMemcpyHostToDevice, c->stream));
+    if (!p.row_meta.empty())
+        HIPCHK(c, hipMemcpyAsync(d + b0 + b1, p.row_meta.data(), p.row_meta.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->plan_off[0] = 0; c->plan_off[1] = b0; c->plan_off[2] = b0 + b1;
+    c->tab_key.valid = false;           // the table layout follows the plan
+    return M6A_OK;
+}
+
+void plan_args(m6a_ctx *c, PoolArgs &a)
+{
+    const char *d = (const char *)c->plan_dev.p;
+    a.leaf_start = (const int *)(d + c->plan_off[0]);
+    a.merge_after = (const uint8_t *)(d + c->plan_off[1]);
+    a.row_meta = (const uint32_t *)(d + c->plan_off[2]);
+    a.n_leaves = (int)c->plan.merge_after.size();
+    a.n_rows = (int)c->plan.row_pass.size();
+    a.n_rem = c->plan.n_rem;
+    a.stack_depth = c->plan.depth;
+}
+
 // accepted-index table for uniform bags of n reads (legacy randint masked rejection),
 // layout tab[j][round][plane][lane], 4 byte offsets (8*idx) per dword
 int ensure_table(m6a_ctx *c, uint32_t seed, int n, int T, int K, int jmax)
 {
+    int rc = ensure_mean_plan(c, T);    // invalidates the key when the plan changes
+    if (rc) return rc;
     auto &k = c->tab_key;
     if (k.valid && k.seed == seed && k.n == n && k.T == T && k.K == K && k.jmax >= jmax) return M6A_OK;
-    const int rounds = (T + 63) / 64;
-    std::vector<uint32_t> tab((size_t)jmax * rounds * 5 * 64, 0u);
+    const MeanPlan &p = c->plan;
+    const int rows = (int)p.row_pass.size();
+    // which iteration each (row, lane) holds: lanes are the accumulator chains of the pairwise sum
+    std::vector<int> iter_of((size_t)rows * 64);
+    for (int r = 0; r < rows; r++)
+        for (int l = 0; l < 64; l++) iter_of[(size_t)r * 64 + l] = plan_iteration(p, r, l);
+    std::vector<uint32_t> tab((size_t)jmax * rows * 5 * 64, 0u);
+    std::vector<uint8_t> idx((size_t)T * K);
     std::mt19937 gen(seed);
     const uint32_t rng = (uint32_t)(n - 1);
     uint32_t mask = rng;
     mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
-    for (int j = 0; j < jmax; j++)
-        for (int t = 0; t < T; t++)
-            for (int kk = 0; kk < K; kk++) {
-                uint32_t v = 0;
-                if (rng) do { v = (uint32_t)gen() & mask; } while (v > rng);
-                const size_t word = (((size_t)j * rounds + (t >> 6)) * 5 + (kk >> 2)) * 64 + (t & 63);
-                tab[word] |= (v * 8u) << (8 * (kk & 3));
+    for (int j = 0; j < jmax; j++) {
+        for (size_t i = 0; i < idx.size(); i++) {          // stream order: iteration-major, then sample
+            uint32_t v = 0;
+            if (rng) do { v = (uint32_t)gen() & mask; } while (v > rng);
+            idx[i] = (uint8_t)v;
+        }
+        for (int r = 0; r < rows; r++)
+            for (int l = 0; l < 64; l++) {
+                const int t = iter_of[(size_t)r * 64 + l];
+                if (t < 0) continue;                        // idle lane: index 0, value discarded
+                uint32_t *w = &tab[(((size_t)j * rows + r) * 5) * 64 + l];
+                for (int kk = 0; kk < K; kk++)
+                    w[(size_t)(kk >> 2) * 64] |= ((uint32_t)idx[(size_t)t * K + kk] * 8u) << (8 * (kk & 3));
             }
+    }
     HIPCHK(c, c->tab.ensure(tab.size() * 4));
     HIPCHK(c, hipMemcpyAsync(c->tab.p, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -336,9 +473,12 @@ int launch_pool(m6a_ctx *c, const float *rp, const int64_t *off, int64_t S, int 
     a.err = c->d_err; a.n_groups = c->goff_key.G; a.n_sites = S; a.T = T; a.K = K; a.thr = thr;
     const int64_t gmax = c->goff_key.gmax;
 
-    if (nmin == nmax && nmin >= 1 && nmin <= M6A_TABLE_MAX_N && K == 20 && gmax <= 4096) {
+    rc = ensure_mean_plan(c, T);
+    if (rc) return rc;
+    if (nmin == nmax && nmin >= 1 && nmin <= M6A_TABLE_MAX_N && K == 20 && gmax <= 4096 && c->plan.max_merge <= 15) {
         rc = ensure_table(c, seed, (int)nmin, T, K, (int)gmax);
         if (rc) return rc;
+        plan_args(c, a);
         a.tab = (const uint32_t *)c->tab.p; a.uniform_n = (int)nmin; a.jmax = (int)gmax;
         // workgroups are bound to a position j: jmax x nbj of them, 5 resident per CU (LDS)
         const int64_t gblocks = (a.n_groups + 7) / 8;
@@ -347,7 +487,8 @@ int launch_pool(m6a_ctx *c, const float *rp, const int64_t *off, int64_t S, int 
         const unsigned blocks = (unsigned)(nbj * a.jmax);
         c->pool_variant = "table";
         prof_begin(c, 1);
-        hipLaunchKernelGGL(pool_table_kernel, dim3(blocks), dim3(256), 0, c->stream, a);
+        const size_t mean_lds = (size_t)4 * (128 + 8 * a.stack_depth) * sizeof(float);
+        hipLaunchKernelGGL(pool_table_kernel, dim3(blocks), dim3(256), mean_lds, c->stream, a);
         prof_end(c, 1);
     } else {
         // expected words per accepted draw <= 2; slack covers the rejection-count spread
@@ -355,12 +496,13 @@ int launch_pool(m6a_ctx *c, const float *rp, const int64_t *off, int64_t S, int 
         const int64_t need = gmax * (2 * A + A / 16) + 8192;     // incl. the kernels' 2 x 1024-word read-ahead
         rc = ensure_raw(c, seed, need);
         if (rc) return rc;
+        plan_args(c, a);
         a.raw = (const uint32_t *)c->raw.p; a.raw_len = c->raw_len;
         HIPCHK(c, c->start_pos.ensure((size_t)S * sizeof(uint32_t)));
         a.start_pos = (uint32_t *)c->start_pos.p;
         // LDS bag sized to the largest bag of this call (bags beyond M6A_BAG_LDS gather from global)
         a.bag_cap = (int)std::min<int64_t>(M6A_BAG_LDS, std::max<int64_t>(64, (nmax + 63) / 64 * 64));
-        const size_t lds = (size_t)4 * (a.bag_cap + (64 * K) * 5 / 4 + 32) * sizeof(float);
+        const size_t lds = (size_t)4 * (a.bag_cap + (64 * K) * 5 / 4 + 32 + M6A_MEAN_STACK) * sizeof(float);
         const int64_t wg_per_cu = std::max<int64_t>(1, std::min<int64_t>(8, (160 * 1024) / (int64_t)lds));
         const int64_t wave_slots = (int64_t)c->n_cu * wg_per_cu * 4;
         // enough flush groups to fill the chip several times over: walk each group's sites in
@@ -504,7 +646,7 @@ void m6a_destroy(m6a_ctx *c)
         for (auto e : c->prof.start[k]) (void)hipEventDestroy(e);
         for (auto e : c->prof.stop[k]) (void)hipEventDestroy(e);
     }
-    for (DevBuf *b : {&c->raw, &c->tab, &c->goff, &c->rp_scratch, &c->off_scratch, &c->start_pos, &c->sX, &c->sK, &c->sOff,
+    for (DevBuf *b : {&c->raw, &c->tab, &c->goff, &c->rp_scratch, &c->off_scratch, &c->start_pos, &c->plan_dev, &c->sX, &c->sK, &c->sOff,
                       &c->sP, &c->sSite, &c->sMod}) b->release();
     if (c->d_wfrag) (void)hipFree(c->d_wfrag);
     if (c->d_wfrag2) (void)hipFree(c->d_wfrag2);

@@ -8,6 +8,7 @@
 #define M6A_WFRAG_FLOATS (136 * 64)   // 40 (W1) + 80 (W2) + 16 (W3) registers x 64 lanes
 #define M6A_WFRAG2_FLOATS (25 * 64)   // 20 (W1 x-slots) + 5 (W1[:,8]) registers x 64 lanes
 #define M6A_W1E_FLOATS (35 * 32)
+#define M6A_MEAN_STACK 32             // pairwise-sum merge stack (tree height + 1 fits for any T*K < 2^30)
 #define M6A_CSITE_MIN_BAG 16          // enc_csite_kernel: a 32-read tile must span <= 3 sites
 #define M6A_TABLE_MAX_N 32        // pool_table_kernel: byte offsets 8*idx must fit a byte
 
@@ -34,6 +35,12 @@ struct PoolArgs {
     float *site_prob;             // [S]
     double *mod_ratio;            // [S]
     uint32_t *start_pos;          // [S] first stream word of each site (scan)
+    // NumPy pairwise-sum plan for the mean over T iterations (host-built, see m6a_api.hip):
+    const int *leaf_start;        // [L+1] leaf b covers iterations [leaf_start[b], leaf_start[b+1])
+    const uint8_t *merge_after;   // [L]   merges to perform after pushing leaf b (post-order)
+    const uint32_t *row_meta;     // [rows][4] table kernel: flags | live mask lo | hi | merge nibbles
+    int n_leaves, n_rows, n_rem;  // n_rem = iterations of the last leaf beyond a multiple of 8
+    int stack_depth;              // deepest the merge stack gets (<= M6A_MEAN_STACK)
     int *err;
     int64_t n_groups, n_sites, raw_len;
     int T, K, uniform_n, jmax, bag_cap;

@@ -27,6 +27,17 @@ __device__ __forceinline__ float wave_sum_f32(float v)
     return v;
 }
 
+// sum over each group of 8 consecutive lanes, in NumPy's pairwise-leaf order
+// ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)); every lane of the group gets it.  DPP only (no LDS traffic):
+// quad_perm [1,0,3,2], quad_perm [2,3,0,1], then row_half_mirror pairs the two quads.
+__device__ __forceinline__ float chain8_sum(float r)
+{
+    r += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, r), 0xB1, 0xf, 0xf, false));
+    r += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, r), 0x4E, 0xf, 0xf, false));
+    r += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, r), 0x141, 0xf, 0xf, false));
+    return r;
+}
+
 __device__ __forceinline__ int wave_sum_i32(int v)
 {
 #pragma unroll
@@ -473,6 +484,7 @@ template <int KT>
 __device__ __forceinline__ bool scan_site(const PoolArgs &a, int64_t s, uint32_t &pos, float *bag, float *ring,
                                           int lane, int K)
 {
+    float *stack = ring + (64 * K) * 5 / 4 + 32; // merge stack of the pairwise sum when it outgrows the registers
     const int bag_cap = a.bag_cap;
     const int CH = 32 * K;                       // slots per window
     const int A = a.T * K;                       // accepted draws per site
@@ -496,14 +508,82 @@ __device__ __forceinline__ bool scan_site(const PoolArgs &a, int64_t s, uint32_t
         float prod = 1.0f;
         const float a0 = bag[0];
         for (int k = 0; k < K; k++) prod *= a0;
-        if (lane == 0) a.site_prob[s] = 1.0f - prod;
+        // T equal values still go through the pairwise sum (its roundings are part of the result)
+        const float x = 1.0f - prod;
+        int sp = 0;
+        for (int b = 0; b < a.n_leaves; b++) {
+            const int len = a.leaf_start[b + 1] - a.leaf_start[b];
+            float r = 0.0f;
+            for (int i = 0; i < (len >> 3); i++) r += x;
+            r = ((r + r) + (r + r)) + ((r + r) + (r + r));
+            for (int i = 0; i < (len & 7); i++) r += x;
+            if (lane == 0) {
+                for (int m = a.merge_after[b]; m > 0; --m) r = stack[--sp] + r;
+                stack[sp++] = r;
+            }
+        }
+        if (lane == 0) a.site_prob[s] = stack[0] / (float)a.T;
         wave_lds_fence();
         return true;
     }
     const uint32_t mask = pow2_mask(rng);
     const bool in_lds = n <= bag_cap;            // wave-uniform: no per-lane test on the fast path
-    float sum = 0.0f;
     int acc = 0, cnt = 0, wbase = 0;
+    // mean over iterations = NumPy's pairwise sum (see MeanPlan in m6a_api.hip).  A window hands over
+    // 32 consecutive iterations in lanes 0..31; leaf starts are multiples of 8, so each group of 8 lanes is
+    // one round of the current leaf's 8 accumulator chains: lanes 0..7 carry the chains (`chain`), groups are
+    // shifted down to them in iteration order (DPP row_shl:8 within a 16-lane row, one ds_bpermute across
+    // rows).  A finished leaf combines its chains (chain8_sum = NumPy's order), adds the n % 8 tail (last
+    // leaf only) and is pushed / merged as the tree says; every lane runs the same (garbage outside 0..7).
+    int it_base = 0, leaf = 0, sp = 0;
+    int leaf_end = a.leaf_start[1];
+    float chain = 0.0f;
+    // the merge stack stays in LDS (lane 0): a register stack with wave-uniform height costs ~20 register
+    // copies per pass of the main loop below (loop-carried select chains), far more than the two LDS
+    // accesses per finished leaf it would save
+    auto leaf_done = [&](float r) {
+        // plan reads are scalar loads (uniform index): a vector load here would wait on vmcnt behind the
+        // stream prefetch
+        const uint32_t mw = ((const uint32_t *)a.merge_after)[leaf >> 2];
+        const int merges = (int)((mw >> (8 * (leaf & 3))) & 0xffu);
+        if (lane == 0) {
+            int p = sp;
+            for (int m = merges; m > 0; --m) r = stack[--p] + r;
+            stack[p] = r;
+        }
+        sp = __builtin_amdgcn_readfirstlane(sp + 1 - merges);
+        leaf = __builtin_amdgcn_readfirstlane(leaf + 1);
+        leaf_end = leaf < a.n_leaves ? a.leaf_start[leaf + 1] : 0x7fffffff;
+        chain = 0.0f;
+    };
+    // v: lanes 0..nvalid-1 hold iterations it_base .. it_base+nvalid-1 (nvalid = 32 except at the site's end)
+    auto feed = [&](float v, int nvalid) {
+        // lanes 16..31 -> 0..15.  (v_permlane16_swap would do this without the LDS crossbar, but measured
+        // no faster here.)
+        const float v16 = __shfl(v, (lane + 16) & 63, 64);
+        const float g1 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x108, 0xf, 0xf, true));
+        const float g3 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v16), 0x108, 0xf, 0xf, true));
+        if (nvalid == 32 && leaf_end >= it_base + 32) {          // no leaf boundary inside: four rounds
+            chain = (((chain + v) + g1) + v16) + g3;
+            if (leaf_end == it_base + 32) leaf_done(chain8_sum(chain));
+            it_base = __builtin_amdgcn_readfirstlane(it_base + 32);
+            return;
+        }
+#pragma unroll 1
+        for (int j = 0; 8 * j < nvalid; ++j) {
+            if (it_base + 8 * j == leaf_end) leaf_done(chain8_sum(chain));
+            const float g = j == 0 ? v : j == 1 ? g1 : j == 2 ? v16 : g3;
+            if (8 * j + 8 <= nvalid) {
+                chain += g;
+            } else {                             // the last leaf's tail: one by one after the chains combine
+                float r = chain8_sum(chain);
+                const int gbits = __builtin_bit_cast(int, g);
+                for (int i = 0; i < nvalid - 8 * j; i++) r += __builtin_bit_cast(float, __builtin_amdgcn_readlane(gbits, i));
+                leaf_done(r);
+            }
+        }
+        it_base = __builtin_amdgcn_readfirstlane(it_base + nvalid);
+    };
     if ((uint64_t)pos + 512 > (uint64_t)a.raw_len) { if (lane == 0) atomicExch(a.err, 1); return false; }
     uint32_t w[4], wn[4];
 #pragma unroll
@@ -520,10 +600,12 @@ __device__ __forceinline__ bool scan_site(const PoolArgs &a, int64_t s, uint32_t
     };
     auto close_window = [&]() {
         wave_lds_fence();
-        if (lane < 32) sum += 1.0f - window_product<KT>(ring, wbase, lane, K);
+        float v = 0.0f;
+        if (lane < 32) v = 1.0f - window_product<KT>(ring, wbase, lane, K);
         wbase = CH - wbase;                      // other window
         cnt -= CH;
         wave_lds_fence();
+        feed(v, 32);
     };
 
     // ---- whole 256-word blocks, branch-free inside: the gather index is clamped so every lane
@@ -605,15 +687,20 @@ __device__ __forceinline__ bool scan_site(const PoolArgs &a, int64_t s, uint32_t
     }
     wave_lds_fence();
     const int t_rem = cnt / K;                   // iterations left in the current window (< 32)
-    if (lane < t_rem) sum += 1.0f - window_product<KT>(ring, wbase, lane, K);
-    sum = wave_sum_f32(sum);
-    if (lane == 0) a.site_prob[s] = sum / (float)a.T;
+    {
+        float v = 0.0f;
+        if (lane < t_rem) v = 1.0f - window_product<KT>(ring, wbase, lane, K);
+        feed(v, t_rem);                          // it_base == T now
+        if (leaf < a.n_leaves) leaf_done(chain8_sum(chain));
+    }
+    if (lane == 0) a.site_prob[s] = stack[0] / (float)a.T;
     wave_lds_fence();
     return true;
 }
 
-// LDS per wavefront: the bag, then the ring (2 windows of 32*K slots at 5/4 dwords per slot)
-__device__ __forceinline__ int scan_wave_floats(int bag_cap, int K) { return bag_cap + (64 * K) * 5 / 4 + 32; }
+// LDS per wavefront: the bag, the ring (2 windows of 32*K slots at 5/4 dwords per slot, + trash) and the
+// pairwise-sum stack for very long T
+__device__ __forceinline__ int scan_wave_floats(int bag_cap, int K) { return bag_cap + (64 * K) * 5 / 4 + 32 + M6A_MEAN_STACK; }
 
 template <int KT>
 __global__ __launch_bounds__(256) void pool_scan_group_kernel(PoolArgs a)
@@ -738,10 +825,12 @@ __global__ __launch_bounds__(256) void pool_scan_start_kernel(PoolArgs a)
 // 160 B per array, each array inside one 256 B bank row), so every ds_read_b64 gathers for two
 // sites, conflict-free, and v_pk_mul_f32 advances both products.  Inner loop = LDS + VALU only.
 // =====================================================================================
-#define M6A_TAB_RC 16                       // rounds per LDS chunk
-__global__ __launch_bounds__(256, 5) void pool_table_kernel(PoolArgs a)
+#define M6A_TAB_RC 16                       // rows per LDS chunk
+#define M6A_TAB_REG_STACK 8                  // merge stacks up to this height live in registers (T <= ~16k)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void pool_table_kernel(PoolArgs a)
 {
     __shared__ __attribute__((aligned(16))) uint32_t s_idx[M6A_TAB_RC * 5 * 64];
+    __shared__ __attribute__((aligned(16))) uint32_t s_meta[M6A_TAB_RC * 4];    // row_meta of the chunk
     // bag arrays: pair p of wave w lives at byte p*2112 + w*256 (+ 8*idx + 4*e).  The odd 2112 B
     // pair stride is deliberate: no difference of two pair bases fits ds_read2_b64's offset field
     // (<= 2040 B) or is a multiple of ds_read2st64_b64's 512 B unit, so the four gathers of one
@@ -749,23 +838,30 @@ __global__ __launch_bounds__(256, 5) void pool_table_kernel(PoolArgs a)
     // collide).  Fused into ds_read2_b64 they run at half rate and bank modulo 32 dwords, where
     // entries i and i+16 collide -- measured 2.4 conflict cycles per gather.
     __shared__ __attribute__((aligned(256))) float s_bag[4 * 528];
+    // per wave: stage[8 sites][8 leaf sums of a pass] | rem[8 sites][8 tail values] | stack[8 sites][depth]
+    extern __shared__ __attribute__((aligned(16))) float s_mean[];
     const int lane = threadIdx.x & 63;
-    const int wib = threadIdx.x >> 6;
+    const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // scalar: site ids, offsets -> SGPRs
     float *bag = s_bag + wib * 64;             // + pair * 528 floats
     const char *bagb = (const char *)bag;
+    const int depth = a.stack_depth;
+    float *w_stage = s_mean + wib * (128 + 8 * depth);
+    float *w_rem = w_stage + 64;
+    float *w_stack = w_rem + 64 + (lane & 7) * depth;      // lane q < 8 owns site q's stack
     const int n = a.uniform_n;
-    const int rounds = (a.T + 63) >> 6;
-    const int n_chunks = (rounds + M6A_TAB_RC - 1) / M6A_TAB_RC;
+    const int rows = a.n_rows;
+    const int n_chunks = (rows + M6A_TAB_RC - 1) / M6A_TAB_RC;
     const int j = (int)(blockIdx.x % (unsigned)a.jmax);
     const int64_t c = blockIdx.x / (unsigned)a.jmax;
     const int64_t nbj = gridDim.x / (unsigned)a.jmax;          // workgroups per position
     const int64_t gblocks = (a.n_groups + 7) >> 3;
     const int64_t stride = nbj * 4;
     const int64_t n_iter = (gblocks + stride - 1) / stride;
-    const uint32_t *row = a.tab + (int64_t)j * rounds * 5 * 64;
+    const uint32_t *row = a.tab + (int64_t)j * rows * 5 * 64;
 
     if (n_chunks == 1) {
-        for (int i = threadIdx.x; i < rounds * 5 * 64; i += 256) s_idx[i] = row[i];
+        for (int i = threadIdx.x; i < rows * 5 * 64; i += 256) s_idx[i] = row[i];
+        if (threadIdx.x < rows * 4) s_meta[threadIdx.x] = a.row_meta[threadIdx.x];
         __syncthreads();
     }
     for (int64_t it = 0; it < n_iter; ++it) {
@@ -795,12 +891,17 @@ __global__ __launch_bounds__(256, 5) void pool_table_kernel(PoolArgs a)
             }
             wave_lds_fence();
         }
+        int sp = 0;                              // stack height (wave-uniform; lanes 0..7 hold the stacks)
+        float st[M6A_TAB_REG_STACK];
+#pragma unroll
+        for (int d = 0; d < M6A_TAB_REG_STACK; d++) st[d] = 0.0f;
         for (int ch = 0; ch < n_chunks; ++ch) {
             const int rd0 = ch * M6A_TAB_RC;
-            const int nr = rounds - rd0 < M6A_TAB_RC ? rounds - rd0 : M6A_TAB_RC;
+            const int nr = rows - rd0 < M6A_TAB_RC ? rows - rd0 : M6A_TAB_RC;
             if (n_chunks > 1) {
                 __syncthreads();
                 for (int i = threadIdx.x; i < nr * 5 * 64; i += 256) s_idx[i] = row[rd0 * 5 * 64 + i];
+                if (threadIdx.x < nr * 4) s_meta[threadIdx.x] = a.row_meta[rd0 * 4 + threadIdx.x];
                 __syncthreads();
             }
             if (!active) continue;
@@ -809,34 +910,115 @@ __global__ __launch_bounds__(256, 5) void pool_table_kernel(PoolArgs a)
 #pragma unroll
                 for (int pr = 0; pr < 4; pr++) prod[pr] = make_float2(1.0f, 1.0f);
                 const uint32_t *ixp = s_idx + rd * 5 * 64 + lane;
+                const uint4 mt = *(const uint4 *)(s_meta + rd * 4);      // consumed after the gathers
 #pragma unroll 1
                 for (int pl = 0; pl < 5; pl++) {
                     const uint32_t ixw = ixp[pl * 64];
+                    // all 16 gathers of the plane in flight before the first multiply; pinned, because
+                    // the scheduler otherwise sometimes picks a minimum-register order that waits on every
+                    // single gather (measured 0.83 -> 1.26 ms for the kernel)
+                    float2 g[4][4];
 #pragma unroll
                     for (int bb = 0; bb < 4; bb++) {
                         const uint32_t o = (ixw >> (8 * bb)) & 0xffu;
 #pragma unroll
+                        for (int pr = 0; pr < 4; pr++) g[bb][pr] = *(const float2 *)(bagb + pr * 2112 + o);
+                    }
+#pragma unroll
+                    for (int bb = 0; bb < 4; bb++)
+#pragma unroll
                         for (int pr = 0; pr < 4; pr++) {
-                            const float2 v = *(const float2 *)(bagb + pr * 2112 + o);
-                            prod[pr].x *= v.x;
-                            prod[pr].y *= v.y;
+                            prod[pr].x *= g[bb][pr].x;
+                            prod[pr].y *= g[bb][pr].y;
+                        }
+                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);     // 4 address adds
+                    __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);    // 16 ds_read_b64
+                    __builtin_amdgcn_sched_group_barrier(0x002, 16, 0);    // 16 v_pk_mul_f32
+                }
+                // which iteration this (row, lane) was: lane = accumulator chain (lane & 7) of leaf
+                // 8*pass + lane/8, row = round of the pass -- or the tail row of the last leaf.  Idle
+                // lanes (shorter chains, leaves beyond the last) gathered entry 0 and are masked here.
+                const uint32_t flags = (uint32_t)__builtin_amdgcn_readfirstlane((int)mt.x);
+                const uint64_t lmask = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)mt.z) << 32) |
+                                       (uint32_t)__builtin_amdgcn_readfirstlane((int)mt.y);
+                if (flags & (1u << 25)) {
+                    if (lane < 8) {
+#pragma unroll
+                        for (int pr = 0; pr < 4; pr++) {
+                            w_rem[(2 * pr) * 8 + lane] = 1.0f - prod[pr].x;
+                            w_rem[(2 * pr + 1) * 8 + lane] = 1.0f - prod[pr].y;
                         }
                     }
+                    continue;
                 }
-                const bool live = (rd0 + rd) * 64 + lane < a.T;
+                const bool live = (lmask >> lane) & 1;
 #pragma unroll
                 for (int pr = 0; pr < 4; pr++) {
                     sum[2 * pr] += live ? 1.0f - prod[pr].x : 0.0f;
                     sum[2 * pr + 1] += live ? 1.0f - prod[pr].y : 0.0f;
                 }
+                if (!(flags & (1u << 24))) continue;
+                // pass complete: chains -> leaf sums, then lane q pushes site q's leaves in order and
+                // merges as the tree says (merge_after nibbles ride in the row's meta)
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const float sv = chain8_sum(sum[q]);
+                    if ((lane & 7) == 0) w_stage[q * 8 + (lane >> 3)] = sv;
+                    sum[q] = 0.0f;
+                }
+                wave_lds_fence();
+                if (lane < 8) {
+                    const uint32_t mc = (uint32_t)__builtin_amdgcn_readfirstlane((int)mt.w);
+                    const int nl = (int)((flags >> 26) & 0xfu);
+                    const bool final_pass = flags & (1u << 30);
+                    if (depth <= M6A_TAB_REG_STACK) {
+                        // stack in registers (height is wave-uniform: select chains, no LDS round trips --
+                        // with the LDS pipe saturated by the other waves' gathers each dependent LDS access
+                        // here would cost microseconds)
+                        float xs[8], tl[7];
+#pragma unroll
+                        for (int bl = 0; bl < 8; bl++) xs[bl] = w_stage[lane * 8 + bl];
+#pragma unroll
+                        for (int i = 0; i < 7; i++) tl[i] = w_rem[lane * 8 + i];
+#pragma unroll
+                        for (int bl = 0; bl < 8; bl++) {
+                            if (bl >= nl) break;
+                            float x = xs[bl];
+                            if (final_pass && bl == nl - 1) {
+#pragma unroll
+                                for (int i = 0; i < 7; i++)
+                                    if (i < a.n_rem) x += tl[i];
+                            }
+                            for (int m = (int)((mc >> (4 * bl)) & 15u); m > 0; --m) {
+                                --sp;
+                                float top = st[0];
+#pragma unroll
+                                for (int d = 1; d < M6A_TAB_REG_STACK; d++) top = sp == d ? st[d] : top;
+                                x = top + x;
+                            }
+#pragma unroll
+                            for (int d = 0; d < M6A_TAB_REG_STACK; d++) st[d] = sp == d ? x : st[d];
+                            ++sp;
+                        }
+                    } else {
+                        for (int bl = 0; bl < nl; bl++) {
+                            float x = w_stage[lane * 8 + bl];
+                            if (final_pass && bl == nl - 1)
+                                for (int i = 0; i < a.n_rem; i++) x += w_rem[lane * 8 + i];
+                            for (int m = (int)((mc >> (4 * bl)) & 15u); m > 0; --m) x = w_stack[--sp] + x;
+                            w_stack[sp++] = x;
+                        }
+                    }
+                }
+                wave_lds_fence();
             }
         }
         if (active) {
+            float tot = 0.0f;
+            if (lane < 8) tot = (depth <= M6A_TAB_REG_STACK ? st[0] : w_stack[0]) / (float)a.T;
 #pragma unroll
-            for (int q = 0; q < 8; q++) {
-                const float tot = wave_sum_f32(sum[q]);
-                if (lane == 0 && site[q] >= 0) a.site_prob[site[q]] = tot / (float)a.T;
-            }
+            for (int q = 0; q < 8; q++)
+                if (lane == q && site[q] >= 0) a.site_prob[site[q]] = tot;
             wave_lds_fence();
         }
     }
