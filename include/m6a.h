@@ -133,7 +133,12 @@ const char *m6a_last_encoder_variant(const m6a_ctx *ctx);   /* "general16" | "cs
 /* Tuning knob for ragged bags: 0 = choose by available parallelism (default), 1 = one wavefront
  * per flush group, 2 = counting pass + one wavefront per site.  Results are identical. */
 int m6a_set_scan_driver(m6a_ctx *ctx, int mode);
-/* pooling kernel variant used by the last pool/infer call: "table" | "scan-group" | "scan-site" */
+/* Tuning knob for uniform bags (n <= 32, n_samples = 20): 0 = auto (default: the register kernel
+ * where it applies), 1 = LDS-gather kernel, 2 = register kernel (bags in VGPRs, draws through the
+ * VGPR index mode).  Results are identical. */
+int m6a_set_table_variant(m6a_ctx *ctx, int mode);
+/* pooling kernel variant used by the last pool/infer call:
+ * "table-reg" | "table" | "scan-group" | "scan-site" */
 const char *m6a_last_pool_variant(const m6a_ctx *ctx);
 
 const char *m6a_version(void);

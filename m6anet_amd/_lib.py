@@ -12,7 +12,7 @@ ERRORS = {-1: "M6A_EINVAL", -2: "M6A_ENOMEM", -3: "M6A_EHIP", -4: "M6A_ESTREAM",
 RNG_NUMPY = 0
 
 # every symbol include/m6a.h declares (tests check the .so exports exactly these)
-SYMBOLS = ["m6a_create", "m6a_destroy", "m6a_last_error", "m6a_set_stream", "m6a_set_job_offset", "m6a_set_scan_driver", "m6a_set_encoder_variant", "m6a_last_encoder_variant", "m6a_sync",
+SYMBOLS = ["m6a_create", "m6a_destroy", "m6a_last_error", "m6a_set_stream", "m6a_set_job_offset", "m6a_set_scan_driver", "m6a_set_table_variant", "m6a_set_encoder_variant", "m6a_last_encoder_variant", "m6a_sync",
            "m6a_encode_reads", "m6a_site_pool", "m6a_infer", "m6a_bag_forward", "m6a_flush_groups",
            "m6a_shard_plan", "m6a_profile_enable", "m6a_profile_read", "m6a_last_pool_variant",
            "m6a_version"]
@@ -62,6 +62,7 @@ def load():
     L.m6a_sync.argtypes = [vp]
     L.m6a_set_job_offset.argtypes = [vp, i64]
     L.m6a_set_scan_driver.argtypes = [vp, i32]
+    L.m6a_set_table_variant.argtypes = [vp, i32]
     L.m6a_set_encoder_variant.argtypes = [vp, i32]
     L.m6a_last_encoder_variant.argtypes = [vp]
     L.m6a_last_encoder_variant.restype = C.c_char_p

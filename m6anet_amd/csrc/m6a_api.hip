@@ -56,6 +56,7 @@ struct MeanPlan {
     // in the pass, bit 30 last pass) | live-lane mask lo | hi | merge_after of the pass's leaves (nibbles)
     std::vector<uint32_t> row_meta;
     std::vector<int> row_pass, row_round;   // host side of the same rows (pass -1 = tail row)
+    std::vector<uint32_t> reg_ctl;          // pool_reg_kernel: per round of 8 iterations, bit 0 = a leaf ends, bits 8.. = its merges
     int n_rem = 0;
     int depth = 1;                      // deepest the merge stack gets
     int max_merge = 0;                  // largest merge_after[]
@@ -71,10 +72,11 @@ struct m6a_ctx {
     float *d_wfrag = nullptr, *d_wfrag2 = nullptr, *d_w1e = nullptr, *d_emb = nullptr;
     float b3 = 0.f;
     // sampling state (device) + what it was built for
-    DevBuf raw, tab, goff, rp_scratch, off_scratch, start_pos, plan_dev;
-    MeanPlan plan; size_t plan_off[3] = {0, 0, 0};
+    DevBuf raw, tab, tab_reg, goff, rp_scratch, off_scratch, start_pos, plan_dev;
+    MeanPlan plan; size_t plan_off[4] = {0, 0, 0, 0};
     uint32_t raw_seed = 0; int64_t raw_len = 0;
-    struct { uint32_t seed; int n, T, K, jmax; bool valid; } tab_key = {0, 0, 0, 0, 0, false};
+    struct { uint32_t seed; int n, T, K, jmax; bool valid; } tab_key = {0, 0, 0, 0, 0, false}, tab_reg_key = {0, 0, 0, 0, 0, false};
+    int table_variant = 0;                            // 0 auto, 1 LDS gather kernel, 2 register kernel
     struct { int64_t S, bs, spb, base, G, gmax; bool valid; } goff_key = {0, 0, 0, 0, 0, 0, false};
     int64_t job_offset = 0;
     int64_t bag_min = 0, bag_max = 0, n_reads = 0;   // last query_bags()
@@ -302,6 +304,10 @@ void build_mean_plan(int T, MeanPlan &p)
         d++; p.depth = std::max(p.depth, d); d -= p.merge_after[b];
         p.max_merge = std::max<int>(p.max_merge, p.merge_after[b]);
     }
+    // register kernel: iterations in order, a leaf is a whole number of rounds; the last leaf is finished
+    // after the loop (its tail and merges), so it carries no flag
+    p.reg_ctl.assign((size_t)std::max(1, (T - p.n_rem) / 8), 0u);
+    for (int b = 0; b + 1 < L; b++) p.reg_ctl[(size_t)p.leaf_start[b + 1] / 8 - 1] = 1u | ((uint32_t)p.merge_after[b] << 8);
     const int rows = (int)p.row_pass.size();
     p.row_meta.assign((size_t)rows * 4, 0u);
     for (int r = 0; r < rows; r++) {
@@ -326,14 +332,16 @@ int ensure_mean_plan(m6a_ctx *c, int T)
     const MeanPlan &p = c->plan;
     if (p.depth > M6A_MEAN_STACK) return fail(c, M6A_EUNSUPPORTED, "n_iters %d: pairwise-sum tree deeper than %d", T, M6A_MEAN_STACK);
     const size_t b0 = p.leaf_start.size() * 4, b1 = (p.merge_after.size() + 3) / 4 * 4, b2 = std::max<size_t>(p.row_meta.size(), 1) * 4;
-    HIPCHK(c, c->plan_dev.ensure(b0 + b1 + b2));
+    const size_t b3 = p.reg_ctl.size() * 4;
+    HIPCHK(c, c->plan_dev.ensure(b0 + b1 + b2 + b3));
     char *d = (char *)c->plan_dev.p;
     HIPCHK(c, hipMemcpyAsync(d, p.leaf_start.data(), b0, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(d + b0, p.merge_after.data(), p.merge_after.size(), hipMemcpyHostToDevice, c->stream));
     if (!p.row_meta.empty())
         HIPCHK(c, hipMemcpyAsync(d + b0 + b1, p.row_meta.data(), p.row_meta.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d + b0 + b1 + b2, p.reg_ctl.data(), b3, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    c->plan_off[0] = 0; c->plan_off[1] = b0; c->plan_off[2] = b0 + b1;
+    c->plan_off[0] = 0; c->plan_off[1] = b0; c->plan_off[2] = b0 + b1; c->plan_off[3] = b0 + b1 + b2;
     c->tab_key.valid = false;           // the table layout follows the plan
     return M6A_OK;
 }
@@ -348,6 +356,9 @@ void plan_args(m6a_ctx *c, PoolArgs &a)
     a.n_rows = (int)c->plan.row_pass.size();
     a.n_rem = c->plan.n_rem;
     a.stack_depth = c->plan.depth;
+    a.reg_ctl = (const uint32_t *)(d + c->plan_off[3]);
+    a.reg_rounds = (a.T - c->plan.n_rem) / 8;
+    a.reg_final_merges = c->plan.merge_after.back();
 }
 
 // accepted-index table for uniform bags of n reads (legacy randint masked rejection),
@@ -387,6 +398,33 @@ int ensure_table(m6a_ctx *c, uint32_t seed, int n, int T, int K, int jmax)
     }
     HIPCHK(c, c->tab.ensure(tab.size() * 4));
     HIPCHK(c, hipMemcpyAsync(c->tab.p, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    k = {seed, n, T, K, jmax, true};
+    return M6A_OK;
+}
+
+// the same accepted indices for pool_reg_kernel: idx2[j][T + 8][K] bytes, 2 x index (a register pair per
+// bag entry), iterations in order, one round of zero padding for the prefetch past the end
+int ensure_table_reg(m6a_ctx *c, uint32_t seed, int n, int T, int K, int jmax)
+{
+    auto &k = c->tab_reg_key;
+    if (k.valid && k.seed == seed && k.n == n && k.T == T && k.K == K && k.jmax >= jmax) return M6A_OK;
+    const size_t per_j = (size_t)(T + 8) * K;              // K = 20: a multiple of 4 bytes
+    std::vector<uint8_t> tab((size_t)jmax * per_j + 256, 0);
+    std::mt19937 gen(seed);
+    const uint32_t rng = (uint32_t)(n - 1);
+    uint32_t mask = rng;
+    mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+    for (int j = 0; j < jmax; j++) {
+        uint8_t *row = &tab[(size_t)j * per_j];
+        for (size_t i = 0; i < (size_t)T * K; i++) {       // stream order: iteration-major, then sample
+            uint32_t v = 0;
+            if (rng) do { v = (uint32_t)gen() & mask; } while (v > rng);
+            row[i] = (uint8_t)(2u * v);
+        }
+    }
+    HIPCHK(c, c->tab_reg.ensure(tab.size()));
+    HIPCHK(c, hipMemcpyAsync(c->tab_reg.p, tab.data(), tab.size(), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     k = {seed, n, T, K, jmax, true};
     return M6A_OK;
@@ -475,7 +513,25 @@ int launch_pool(m6a_ctx *c, const float *rp, const int64_t *off, int64_t S, int 
 
     rc = ensure_mean_plan(c, T);
     if (rc) return rc;
-    if (nmin == nmax && nmin >= 1 && nmin <= M6A_TABLE_MAX_N && K == 20 && gmax <= 4096 && c->plan.max_merge <= 15) {
+    const bool uniform = nmin == nmax && nmin >= 1 && nmin <= M6A_TABLE_MAX_N && K == 20 && gmax <= 4096;
+    // register kernel: stack in 8 register quads, 32-bit byte offsets into read_prob, table <= 256 MB
+    const bool reg_ok = uniform && c->plan.depth <= M6A_REG_STACK && c->n_reads < (int64_t)1 << 30 &&
+                        (int64_t)gmax * (T + 8) * K <= (int64_t)256 << 20;
+    if (uniform && reg_ok && c->table_variant != 1) {
+        rc = ensure_table_reg(c, seed, (int)nmin, T, K, (int)gmax);
+        if (rc) return rc;
+        plan_args(c, a);
+        a.tab = (const uint32_t *)c->tab_reg.p; a.uniform_n = (int)nmin; a.jmax = (int)gmax;
+        c->pool_variant = "table-reg";
+        prof_begin(c, 1);
+        hipLaunchKernelGGL(mod_ratio_uniform_kernel, dim3((unsigned)std::min<int64_t>((S + 255) / 256, (int64_t)c->n_cu * 8)),
+                           dim3(256), 0, c->stream, a);
+        // one wavefront = position j of 256 flush groups (4 sites per lane); blockIdx % jmax = j keeps a
+        // position's index rows in one XCD's L2
+        const int64_t wpj = (a.n_groups + 255) / 256;
+        hipLaunchKernelGGL(pool_reg_kernel, dim3((unsigned)(wpj * a.jmax)), dim3(64), 0, c->stream, a);
+        prof_end(c, 1);
+    } else if (uniform && c->plan.max_merge <= 15) {
         rc = ensure_table(c, seed, (int)nmin, T, K, (int)gmax);
         if (rc) return rc;
         plan_args(c, a);
@@ -646,7 +702,7 @@ void m6a_destroy(m6a_ctx *c)
         for (auto e : c->prof.start[k]) (void)hipEventDestroy(e);
         for (auto e : c->prof.stop[k]) (void)hipEventDestroy(e);
     }
-    for (DevBuf *b : {&c->raw, &c->tab, &c->goff, &c->rp_scratch, &c->off_scratch, &c->start_pos, &c->plan_dev, &c->sX, &c->sK, &c->sOff,
+    for (DevBuf *b : {&c->raw, &c->tab, &c->goff, &c->rp_scratch, &c->off_scratch, &c->start_pos, &c->plan_dev, &c->tab_reg, &c->sX, &c->sK, &c->sOff,
                       &c->sP, &c->sSite, &c->sMod}) b->release();
     if (c->d_wfrag) (void)hipFree(c->d_wfrag);
     if (c->d_wfrag2) (void)hipFree(c->d_wfrag2);
@@ -690,6 +746,14 @@ int m6a_set_scan_driver(m6a_ctx *c, int mode)
     if (!c) return M6A_EINVAL;
     if (mode < 0 || mode > 2) return fail(c, M6A_EINVAL, "scan driver must be 0 (auto), 1 (group) or 2 (site)");
     c->scan_driver = mode;
+    return M6A_OK;
+}
+
+int m6a_set_table_variant(m6a_ctx *c, int mode)
+{
+    if (!c) return M6A_EINVAL;
+    if (mode < 0 || mode > 2) return fail(c, M6A_EINVAL, "table variant must be 0 (auto), 1 (LDS) or 2 (registers)");
+    c->table_variant = mode;
     return M6A_OK;
 }
 

@@ -10,7 +10,8 @@
 #define M6A_W1E_FLOATS (35 * 32)
 #define M6A_MEAN_STACK 32             // pairwise-sum merge stack (tree height + 1 fits for any T*K < 2^30)
 #define M6A_CSITE_MIN_BAG 16          // enc_csite_kernel: a 32-read tile must span <= 3 sites
-#define M6A_TABLE_MAX_N 32        // pool_table_kernel: byte offsets 8*idx must fit a byte
+#define M6A_TABLE_MAX_N 32        // pool_table_kernel: byte offsets 8*idx must fit a byte; pool_reg_kernel: 32 register pairs
+#define M6A_REG_STACK 8           // pool_reg_kernel: merge stack entries held in registers
 
 struct EncArgs {
     const float *X;               // [R][9]
@@ -41,6 +42,9 @@ struct PoolArgs {
     const uint32_t *row_meta;     // [rows][4] table kernel: flags | live mask lo | hi | merge nibbles
     int n_leaves, n_rows, n_rem;  // n_rem = iterations of the last leaf beyond a multiple of 8
     int stack_depth;              // deepest the merge stack gets (<= M6A_MEAN_STACK)
+    // pool_reg_kernel: one control word per round of 8 iterations (bit 0 leaf ends, bits 8.. merges)
+    const uint32_t *reg_ctl;
+    int reg_rounds, reg_final_merges;
     int *err;
     int64_t n_groups, n_sites, raw_len;
     int T, K, uniform_n, jmax, bag_cap;
@@ -53,6 +57,8 @@ __global__ void pool_scan_start_kernel(PoolArgs a);
 template <int KT> __global__ void pool_scan_group_kernel(PoolArgs a);
 template <int KT> __global__ void pool_scan_site_kernel(PoolArgs a);
 __global__ void pool_table_kernel(PoolArgs a);
+__global__ void pool_reg_kernel(PoolArgs a);
+__global__ void mod_ratio_uniform_kernel(PoolArgs a);
 __global__ void bag_noisy_or_kernel(const float *read_prob, int64_t n_bags, int bag, float *site_prob);
 __global__ void iota_off_kernel(int64_t *off, int64_t n_plus_1, int64_t step);
 __global__ void bag_minmax_kernel(const int64_t *off, int64_t n_sites, unsigned long long *out);

@@ -1,0 +1,269 @@
+// m6a_pool_reg.hip -- site pooling for uniform bags with the bags in REGISTERS.
+//
+// Same arithmetic as pool_table_kernel (m6a_kernels.hip): for uniform bags of n <= 32 reads the
+// accepted indices of "the j-th site of a flush group" are the same in every group, so a wavefront
+// that takes position j of 256 different groups -- lane = 4 sites -- sees a WAVE-UNIFORM index for
+// every draw.  A uniform index into per-lane data is exactly what the VGPR index mode of gfx9/CDNA
+// does for free: s_set_gpr_idx_idx puts the index in M0 and the next v_pk_mul_f32 reads
+// v[base + M0].  No LDS gather at all: the inner loop is 1 SALU + 2 VALU per draw of 4 sites
+// (v_pk_mul_f32 advances two sites), against 5 VALU + 4.25 LDS instructions per draw of 8 sites in
+// the LDS kernel, whose floor is the LDS pipe (0.57 ms per 1 M sites x T=1000; this one is bound
+// by VALU issue, 0.31 ms).
+//
+// The compiler cannot express "this instruction's source register is v[128 + M0]" and has no
+// register class beyond 32 dwords, so the core is one hand-written assembly block with its own
+// register map (everything below v32 / s36 is left to the compiler, operands come in through
+// constraints):
+//
+//   v[128:191]  1-p of sites 0,1: entry e at v[128+2e], v[129+2e]   (a pair = one v_pk_* operand)
+//   v[192:255]  1-p of sites 2,3: entry e at v[192+2e], v[193+2e]
+//   v[96:127]   the 8 accumulator chains of NumPy's pairwise sum, chain c at v[96+4c .. 99+4c]
+//   v[64:95]    merge stack of the pairwise sum, entry d at v[64+4d .. 67+4d] (height <= 8)
+//   v[56:59]    running products, v[60:63] leaf sum / result, v[32:35] byte offsets, v[40:47] temps
+//   s[36:55]    draw indices of iterations 0..3 of a round (one byte per draw: 2 x index, 5 dwords per
+//               iteration), s[56:75] of iterations 4..7; each half is fetched four iterations ahead
+//   s76 round control word, s77 rounds left, s78 4*stack height, s79 temp, s[80:81] table cursor,
+//   s[82:83] control cursor
+//
+// Iterations run in order; iteration t adds its 1-prod to chain t % 8 (leaves of the pairwise sum
+// start at multiples of 8, so a leaf is a whole number of 8-iteration rounds, plus a tail for the
+// last leaf).  The host writes one control word per round: bit 0 = a leaf ends after this round,
+// bits 8.. = merge_after of that leaf (MeanPlan, m6a_api.hip).  At a leaf end the chains are
+// combined ((c0+c1)+(c2+c3))+((c4+c5)+(c6+c7)), merged with the stack top as often as the tree
+// says and pushed -- the stack is addressed through the same index mode (SRC0 / DST relative).
+// The last leaf is finished after the loop: combine, add the T % 8 tail values one by one, merge.
+//
+// Index bytes are scalar loads (80 B = four iterations per s_load_dwordx16 + x4), fetched half a round
+// ahead: the waves of a CU stream different rows through the scalar cache, so a load is an L2 round trip,
+// longer than one iteration.  The table is idx2[j][T + 8][20] bytes (2 x index, iteration-major, padded
+// by one round so the prefetch past the end stays in bounds).
+#include "m6a_kernels.h"
+
+#define S1(x) #x
+#define S(x) S1(x)
+
+// the two multiplies of one draw (4 sites); the first draw of an iteration multiplies by 1.0 instead
+#define MUL0 \
+    "v_pk_mul_f32 v[56:57], v[128:129], 1.0 op_sel_hi:[1,0]\n" \
+    "v_pk_mul_f32 v[58:59], v[192:193], 1.0 op_sel_hi:[1,0]\n"
+#define MUL \
+    "v_pk_mul_f32 v[56:57], v[128:129], v[56:57]\n" \
+    "v_pk_mul_f32 v[58:59], v[192:193], v[58:59]\n"
+// four draws from index dword s[r] (one byte each = 2 x index; s_set_gpr_idx_* reads bits 7:0 only, so the
+// dword is shifted down in place)
+#define IDX(r) "s_set_gpr_idx_idx s[" S(r) "]\n"
+#define SHR(r) "s_lshr_b32 s[" S(r) "], s[" S(r) "], 8\n"
+#define DRAW4(r) IDX(r) MUL SHR(r) IDX(r) MUL SHR(r) IDX(r) MUL SHR(r) IDX(r) MUL
+// the 20 draws of one iteration from index dwords s[b .. b+4], then 1 - prod
+#define DRAWS(b) \
+    "s_set_gpr_idx_on s[" S(b) "], gpr_idx(SRC0)\n" \
+    MUL0 SHR(b) IDX(b) MUL SHR(b) IDX(b) MUL SHR(b) IDX(b) MUL \
+    DRAW4(b+1) DRAW4(b+2) DRAW4(b+3) DRAW4(b+4) \
+    "s_set_gpr_idx_off\n" \
+    "v_pk_add_f32 v[56:57], v[56:57], 1.0 op_sel_hi:[1,0] neg_lo:[1,0] neg_hi:[1,0]\n" \
+    "v_pk_add_f32 v[58:59], v[58:59], 1.0 op_sel_hi:[1,0] neg_lo:[1,0] neg_hi:[1,0]\n"
+
+// iteration i of a round from index dwords s[b .. b+4]: 20 draws, 1-prod into chain i
+#define ITER(i, b) \
+    DRAWS(b) \
+    "v_pk_add_f32 v[96+4*" S(i) ":97+4*" S(i) "], v[96+4*" S(i) ":97+4*" S(i) "], v[56:57]\n" \
+    "v_pk_add_f32 v[98+4*" S(i) ":99+4*" S(i) "], v[98+4*" S(i) ":99+4*" S(i) "], v[58:59]\n"
+
+// chains -> v[60:63] in NumPy's order, chains cleared
+#define COMBINE \
+    "v_pk_add_f32 v[60:61], v[96:97], v[100:101]\n" \
+    "v_pk_add_f32 v[40:41], v[104:105], v[108:109]\n" \
+    "v_pk_add_f32 v[62:63], v[98:99], v[102:103]\n" \
+    "v_pk_add_f32 v[42:43], v[106:107], v[110:111]\n" \
+    "v_pk_add_f32 v[60:61], v[60:61], v[40:41]\n" \
+    "v_pk_add_f32 v[62:63], v[62:63], v[42:43]\n" \
+    "v_pk_add_f32 v[40:41], v[112:113], v[116:117]\n" \
+    "v_pk_add_f32 v[44:45], v[120:121], v[124:125]\n" \
+    "v_pk_add_f32 v[42:43], v[114:115], v[118:119]\n" \
+    "v_pk_add_f32 v[46:47], v[122:123], v[126:127]\n" \
+    "v_pk_add_f32 v[40:41], v[40:41], v[44:45]\n" \
+    "v_pk_add_f32 v[42:43], v[42:43], v[46:47]\n" \
+    "v_pk_add_f32 v[60:61], v[60:61], v[40:41]\n" \
+    "v_pk_add_f32 v[62:63], v[62:63], v[42:43]\n" \
+    ".set m6a_i, 0\n" \
+    ".rept 32\n" \
+    "v_mov_b32 v[96+m6a_i], 0\n" \
+    ".set m6a_i, m6a_i+1\n" \
+    ".endr\n"
+
+// s79 times: pop the stack top and add it (left operand) to v[60:63]
+#define MERGES(lbl) \
+    "s_cmp_eq_u32 s79, 0\n" \
+    "s_cbranch_scc1 " lbl "f\n" \
+    lbl "0:\n" \
+    "s_sub_u32 s78, s78, 4\n" \
+    "s_set_gpr_idx_on s78, gpr_idx(SRC0)\n" \
+    "v_pk_add_f32 v[60:61], v[64:65], v[60:61]\n" \
+    "v_pk_add_f32 v[62:63], v[66:67], v[62:63]\n" \
+    "s_set_gpr_idx_off\n" \
+    "s_sub_u32 s79, s79, 1\n" \
+    "s_cmp_lg_u32 s79, 0\n" \
+    "s_cbranch_scc1 " lbl "0b\n" \
+    lbl ":\n"
+
+__global__ __launch_bounds__(64) void pool_reg_kernel(PoolArgs a)
+{
+    const int lane = threadIdx.x;
+    const int j = (int)(blockIdx.x % (unsigned)a.jmax);
+    const int64_t g0 = (int64_t)(blockIdx.x / (unsigned)a.jmax) * 256;
+    int64_t site[4];
+    uint32_t boff[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int64_t g = g0 + q * 64 + lane;
+        site[q] = -1;
+        if (g < a.n_groups) {
+            const int64_t s = a.goff[g] + j;
+            if (s < a.goff[g + 1]) site[q] = s;
+        }
+        boff[q] = site[q] >= 0 ? (uint32_t)(a.off[site[q]] * 4) : 0u;      // idle lanes replay site 0
+    }
+    const uint64_t rp = (uint64_t)a.read_prob;
+    const uint64_t tab = (uint64_t)((const uint8_t *)a.tab + (size_t)j * (size_t)(a.T + 8) * 20);
+    const uint64_t ctl = (uint64_t)a.reg_ctl;
+    float o0, o1, o2, o3;
+    asm volatile(
+        // ---- bags: 32 entries x 4 sites straight into their registers; the per-lane byte offset stops
+        // advancing at the bag's last read, so entries >= n (never indexed) repeat it and nothing is
+        // read out of bounds
+        "v_mov_b32 v32, %[b0]\n"
+        "v_mov_b32 v33, %[b1]\n"
+        "v_mov_b32 v34, %[b2]\n"
+        "v_mov_b32 v35, %[b3]\n"
+        "s_sub_u32 s79, %[n], 1\n"
+        ".set m6a_e, 0\n"
+        ".rept 32\n"
+        "global_load_dword v[128+2*m6a_e], v32, %[rp]\n"
+        "global_load_dword v[129+2*m6a_e], v33, %[rp]\n"
+        "global_load_dword v[192+2*m6a_e], v34, %[rp]\n"
+        "global_load_dword v[193+2*m6a_e], v35, %[rp]\n"
+        "s_cmp_lt_u32 m6a_e, s79\n"
+        "s_cselect_b32 s76, 4, 0\n"
+        "v_add_u32 v32, s76, v32\n"
+        "v_add_u32 v33, s76, v33\n"
+        "v_add_u32 v34, s76, v34\n"
+        "v_add_u32 v35, s76, v35\n"
+        ".set m6a_e, m6a_e+1\n"
+        ".endr\n"
+        // first iteration's indices, cursors, counters
+        "s_mov_b64 s[80:81], %[tab]\n"
+        "s_mov_b64 s[82:83], %[ctl]\n"
+        "s_load_dwordx16 s[36:51], s[80:81], 0\n"
+        "s_load_dwordx4 s[52:55], s[80:81], 64\n"
+        "s_mov_b32 s77, %[nr]\n"
+        "s_mov_b32 s78, 0\n"
+        ".set m6a_i, 0\n"
+        ".rept 64\n"
+        "v_mov_b32 v[64+m6a_i], 0\n"
+        ".set m6a_i, m6a_i+1\n"
+        ".endr\n"
+        "s_waitcnt vmcnt(0)\n"
+        ".set m6a_i, 0\n"
+        ".rept 128\n"
+        "v_sub_f32 v[128+m6a_i], 1.0, v[128+m6a_i]\n"
+        ".set m6a_i, m6a_i+1\n"
+        ".endr\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        "s_cmp_eq_u32 s77, 0\n"
+        "s_cbranch_scc1 3f\n"
+        // ---- rounds of 8 iterations
+        "1:\n"
+        "s_load_dword s76, s[82:83], 0\n"
+        "s_load_dwordx16 s[56:71], s[80:81], 80\n"
+        "s_load_dwordx4 s[72:75], s[80:81], 144\n"
+        ITER(0, 36) ITER(1, 41) ITER(2, 46) ITER(3, 51)
+        "s_waitcnt lgkmcnt(0)\n"
+        "s_load_dwordx16 s[36:51], s[80:81], 160\n"
+        "s_load_dwordx4 s[52:55], s[80:81], 224\n"
+        ITER(4, 56) ITER(5, 61) ITER(6, 66) ITER(7, 71)
+        "s_waitcnt lgkmcnt(0)\n"
+        "s_add_u32 s80, s80, 160\n"
+        "s_addc_u32 s81, s81, 0\n"
+        "s_add_u32 s82, s82, 4\n"
+        "s_addc_u32 s83, s83, 0\n"
+        "s_bitcmp1_b32 s76, 0\n"
+        "s_cbranch_scc0 2f\n"
+        // a leaf ends here: combine, merge, push
+        COMBINE
+        "s_lshr_b32 s79, s76, 8\n"
+        MERGES("4")
+        "s_set_gpr_idx_on s78, gpr_idx(DST)\n"
+        "v_mov_b32 v64, v60\n"
+        "v_mov_b32 v65, v61\n"
+        "v_mov_b32 v66, v62\n"
+        "v_mov_b32 v67, v63\n"
+        "s_set_gpr_idx_off\n"
+        "s_add_u32 s78, s78, 4\n"
+        "2:\n"
+        "s_sub_u32 s77, s77, 1\n"
+        "s_cmp_lg_u32 s77, 0\n"
+        "s_cbranch_scc1 1b\n"
+        "3:\n"
+        // ---- the last leaf: combine, then its tail (s[80:81] points at iteration 8 * rounds)
+        COMBINE
+        "s_mov_b32 s77, %[nt]\n"
+        "s_cmp_eq_u32 s77, 0\n"
+        "s_cbranch_scc1 6f\n"
+        "5:\n"
+        "s_load_dwordx4 s[36:39], s[80:81], 0\n"
+        "s_load_dword s40, s[80:81], 16\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        DRAWS(36)
+        "v_pk_add_f32 v[60:61], v[60:61], v[56:57]\n"
+        "v_pk_add_f32 v[62:63], v[62:63], v[58:59]\n"
+        "s_add_u32 s80, s80, 20\n"
+        "s_addc_u32 s81, s81, 0\n"
+        "s_sub_u32 s77, s77, 1\n"
+        "s_cmp_lg_u32 s77, 0\n"
+        "s_cbranch_scc1 5b\n"
+        "6:\n"
+        "s_mov_b32 s79, %[fm]\n"
+        MERGES("7")
+        "v_mov_b32 %[o0], v60\n"
+        "v_mov_b32 %[o1], v61\n"
+        "v_mov_b32 %[o2], v62\n"
+        "v_mov_b32 %[o3], v63\n"
+        : [o0] "=v"(o0), [o1] "=v"(o1), [o2] "=v"(o2), [o3] "=v"(o3)
+        : [b0] "v"(boff[0]), [b1] "v"(boff[1]), [b2] "v"(boff[2]), [b3] "v"(boff[3]), [rp] "s"(rp), [tab] "s"(tab),
+          [ctl] "s"(ctl), [n] "s"(a.uniform_n), [nr] "s"(a.reg_rounds), [nt] "s"(a.n_rem), [fm] "s"(a.reg_final_merges)
+        : "memory", "scc", "vcc",
+          "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51",
+          "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67",
+          "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83",
+          "v32", "v33", "v34", "v35", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v56", "v57", "v58", "v59",
+          "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75",
+          "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91",
+          "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106",
+          "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120",
+          "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134",
+          "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143", "v144", "v145", "v146", "v147", "v148",
+          "v149", "v150", "v151", "v152", "v153", "v154", "v155", "v156", "v157", "v158", "v159", "v160", "v161", "v162",
+          "v163", "v164", "v165", "v166", "v167", "v168", "v169", "v170", "v171", "v172", "v173", "v174", "v175", "v176",
+          "v177", "v178", "v179", "v180", "v181", "v182", "v183", "v184", "v185", "v186", "v187", "v188", "v189", "v190",
+          "v191", "v192", "v193", "v194", "v195", "v196", "v197", "v198", "v199", "v200", "v201", "v202", "v203", "v204",
+          "v205", "v206", "v207", "v208", "v209", "v210", "v211", "v212", "v213", "v214", "v215", "v216", "v217", "v218",
+          "v219", "v220", "v221", "v222", "v223", "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232",
+          "v233", "v234", "v235", "v236", "v237", "v238", "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246",
+          "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255");
+    const float o[4] = {o0, o1, o2, o3};
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+        if (site[q] >= 0) a.site_prob[site[q]] = o[q] / (float)a.T;
+}
+
+// mod_ratio = mean(p >= thr) for uniform bags (pool_reg_kernel leaves it to this pass: 4 B/read)
+__global__ __launch_bounds__(256) void mod_ratio_uniform_kernel(PoolArgs a)
+{
+    const int n = a.uniform_n;
+    for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < a.n_sites; s += (int64_t)gridDim.x * blockDim.x) {
+        const float *p = a.read_prob + a.off[s];
+        int c = 0;
+        for (int i = 0; i < n; i++) c += p[i] >= a.thr ? 1 : 0;
+        a.mod_ratio[s] = (double)c / (double)n;
+    }
+}

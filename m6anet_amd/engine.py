@@ -131,6 +131,10 @@ class M6ANetEngine:
         """0 auto, 1 one wavefront per flush group, 2 counting pass + one wavefront per site."""
         self._chk(self._L.m6a_set_scan_driver(self._h, int(mode)))
 
+    def set_table_variant(self, mode):
+        """Uniform bags: 0 auto, 1 LDS-gather kernel, 2 register kernel."""
+        self._chk(self._L.m6a_set_table_variant(self._h, int(mode)))
+
     def sync(self):
         self._chk(self._L.m6a_sync(self._h))
 

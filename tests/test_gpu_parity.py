@@ -55,6 +55,21 @@ def rand_sites(seed, n_reads_per_site):
     return X, km, off
 
 
+# uniform bags: both pooling kernels (m6a_set_table_variant: 1 = LDS gather, 2 = bags in registers)
+TABLE_VARIANTS = ((1, "table"), (2, "table-reg"))
+
+
+class table_variant:
+    def __init__(self, eng, mode):
+        self.eng, self.mode = eng, mode
+
+    def __enter__(self):
+        self.eng.set_table_variant(self.mode)
+
+    def __exit__(self, *exc):
+        self.eng.set_table_variant(0)
+
+
 def rand_probs(seed, off):
     g = np.random.Generator(np.random.PCG64(seed))
     # skewed like real read probabilities: mostly small, some large
@@ -174,11 +189,12 @@ def test_pool_bundled_golden(eng, golden, T, bs, spb, seed):
 @pytest.mark.parametrize("T", [100, 1000])
 def test_pool_synthetic_golden(eng, golden, T):
     g = golden("synthetic_small.npz")
-    for tag, variant in (("uniform20", "table"), ("ragged", "scan")):
-        site, mod = eng.calculate_site_proba(g[f"{tag}_readprob"], g[f"{tag}_off"], T, 20, THR)
-        assert eng.last_pool_variant.startswith(variant)
-        assert same_sites(site, g[f"{tag}_site_T{T}"]), tag
-        assert np.array_equal(mod, g[f"{tag}_mod"]), tag
+    for tag, mode, variant in (("uniform20", 1, "table"), ("uniform20", 2, "table-reg"), ("ragged", 0, "scan")):
+        with table_variant(eng, mode):
+            site, mod = eng.calculate_site_proba(g[f"{tag}_readprob"], g[f"{tag}_off"], T, 20, THR)
+        assert eng.last_pool_variant.startswith(variant) and (mode == 0 or eng.last_pool_variant == variant)
+        assert same_sites(site, g[f"{tag}_site_T{T}"]), (tag, variant)
+        assert np.array_equal(mod, g[f"{tag}_mod"]), (tag, variant)
 
 
 @pytest.mark.parametrize("n", [1, 2, 3, 19, 20, 21, 31, 32])
@@ -187,11 +203,13 @@ def test_pool_uniform_table_vs_oracle(eng, orc, n, T):
     S = 131
     off = np.arange(S + 1, dtype=np.int64) * n
     p = rand_probs(n * 1000 + T, off)
-    site, mod = eng.calculate_site_proba(p, off, T, 20, THR, seed=3)
-    assert eng.last_pool_variant == "table"
     want_site, want_mod = orc.site_pool(p, off, T, THR, seed=3)
-    assert same_sites(site, want_site)
-    assert np.array_equal(mod, want_mod)
+    for mode, name in TABLE_VARIANTS:
+        with table_variant(eng, mode):
+            site, mod = eng.calculate_site_proba(p, off, T, 20, THR, seed=3)
+        assert eng.last_pool_variant == name
+        assert same_sites(site, want_site), name
+        assert np.array_equal(mod, want_mod), name
 
 
 @pytest.mark.parametrize("bags", [
@@ -242,13 +260,17 @@ def test_pool_mean_is_numpy_pairwise_sum(eng, orc, T):
         off = np.concatenate([[0], np.cumsum(bags)]).astype(np.int64)
         p = rand_probs(T + len(bags), off)
         want_site, want_mod = orc.site_pool(p, off, T, THR, seed=6)
-        for driver in ((0,) if variant == "table" else (1, 2)):
+        for driver in (1, 2):                    # table: LDS / register kernel; scan: per group / per site
             eng.set_scan_driver(driver)
+            eng.set_table_variant(driver)
             try:
                 site, mod = eng.calculate_site_proba(p, off, T, 20, THR, seed=6)
             finally:
                 eng.set_scan_driver(0)
+                eng.set_table_variant(0)
             assert eng.last_pool_variant.startswith(variant)
+            if variant == "table":
+                assert eng.last_pool_variant == TABLE_VARIANTS[driver - 1][1]
             assert same_sites(site, want_site), (T, bags[:3], driver, np.abs(site - want_site).max())
             assert np.array_equal(mod, want_mod)
 
@@ -256,13 +278,14 @@ def test_pool_mean_is_numpy_pairwise_sum(eng, orc, T):
 @pytest.mark.parametrize("bs,spb", [(16, 2), (1, 2), (7, 3), (64, 2), (16, 1), (5, 5)])
 def test_pool_group_geometry(eng, orc, bs, spb):
     S = 203
-    for n in (20, None):
+    for n, mode in ((20, 1), (20, 2), (None, 0)):
         bags = [20] * S if n else list(np.random.Generator(np.random.PCG64(S)).integers(20, 60, size=S))
         off = np.concatenate([[0], np.cumsum(bags)]).astype(np.int64)
         p = rand_probs(bs * 10 + spb, off)
-        site, mod = eng.calculate_site_proba(p, off, 30, 20, THR, seed=9, batch_size=bs, save_per_batch=spb)
+        with table_variant(eng, mode):
+            site, mod = eng.calculate_site_proba(p, off, 30, 20, THR, seed=9, batch_size=bs, save_per_batch=spb)
         want_site, _ = orc.site_pool(p, off, 30, THR, seed=9, batch_size=bs, save_per_batch=spb)
-        assert same_sites(site, want_site), (bs, spb, n)
+        assert same_sites(site, want_site), (bs, spb, n, mode)
 
 
 @pytest.mark.parametrize("T", [1024, 1025, 1500, 3000, 10000])
@@ -270,13 +293,14 @@ def test_pool_long_iterations(eng, orc, T):
     """num_iterations beyond one 16-round LDS chunk of the index row (table kernel, T > 1024) and
     long replays in the scan kernels; 10000 is what the reference's own test uses."""
     S = 70 if T < 10000 else 40
-    for bags, variant in (([20] * S, "table"), ([20, 27, 33, 64, 100] * (S // 5), "scan")):
+    for bags, mode, variant in (([20] * S, 1, "table"), ([20] * S, 2, "table"), ([20, 27, 33, 64, 100] * (S // 5), 0, "scan")):
         off = np.concatenate([[0], np.cumsum(bags)]).astype(np.int64)
         p = rand_probs(T, off)
-        site, mod = eng.calculate_site_proba(p, off, T, 20, THR, seed=2)
+        with table_variant(eng, mode):
+            site, mod = eng.calculate_site_proba(p, off, T, 20, THR, seed=2)
         assert eng.last_pool_variant.startswith(variant)
         want_site, want_mod = orc.site_pool(p, off, T, THR, seed=2, n_threads=8)
-        assert same_sites(site, want_site), (T, variant)
+        assert same_sites(site, want_site), (T, variant, mode, eng.last_pool_variant)
         assert np.array_equal(mod, want_mod)
 
 
@@ -284,9 +308,11 @@ def test_pool_many_small_groups_and_one_huge_group(eng, orc):
     off = np.arange(0, 20 * 3001, 20, dtype=np.int64)
     p = rand_probs(77, off)
     for bs, spb in ((1, 2), (4096, 2), (3000, 1)):       # 1-site groups; one flush group holding every site
-        site, mod = eng.calculate_site_proba(p, off, 12, 20, THR, seed=4, batch_size=bs, save_per_batch=spb)
         want_site, _ = orc.site_pool(p, off, 12, THR, seed=4, batch_size=bs, save_per_batch=spb, n_threads=8)
-        assert same_sites(site, want_site), (bs, spb)
+        for mode, _name in TABLE_VARIANTS:
+            with table_variant(eng, mode):
+                site, mod = eng.calculate_site_proba(p, off, 12, 20, THR, seed=4, batch_size=bs, save_per_batch=spb)
+            assert same_sites(site, want_site), (bs, spb, mode, eng.last_pool_variant)
 
 
 def test_pool_seeds_differ_and_repeat(eng):
