@@ -524,8 +524,6 @@ int launch_pool(m6a_ctx *c, const float *rp, const int64_t *off, int64_t S, int 
         a.tab = (const uint32_t *)c->tab_reg.p; a.uniform_n = (int)nmin; a.jmax = (int)gmax;
         c->pool_variant = "table-reg";
         prof_begin(c, 1);
-        hipLaunchKernelGGL(mod_ratio_uniform_kernel, dim3((unsigned)std::min<int64_t>((S + 255) / 256, (int64_t)c->n_cu * 8)),
-                           dim3(256), 0, c->stream, a);
         // one wavefront = position j of 256 flush groups (4 sites per lane); blockIdx % jmax = j keeps a
         // position's index rows in one XCD's L2
         const int64_t wpj = (a.n_groups + 255) / 256;

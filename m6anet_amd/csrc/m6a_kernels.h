@@ -58,7 +58,6 @@ template <int KT> __global__ void pool_scan_group_kernel(PoolArgs a);
 template <int KT> __global__ void pool_scan_site_kernel(PoolArgs a);
 __global__ void pool_table_kernel(PoolArgs a);
 __global__ void pool_reg_kernel(PoolArgs a);
-__global__ void mod_ratio_uniform_kernel(PoolArgs a);
 __global__ void bag_noisy_or_kernel(const float *read_prob, int64_t n_bags, int bag, float *site_prob);
 __global__ void iota_off_kernel(int64_t *off, int64_t n_plus_1, int64_t step);
 __global__ void bag_minmax_kernel(const int64_t *off, int64_t n_sites, unsigned long long *out);

@@ -127,6 +127,7 @@ __global__ __launch_bounds__(64) void pool_reg_kernel(PoolArgs a)
     const uint64_t tab = (uint64_t)((const uint8_t *)a.tab + (size_t)j * (size_t)(a.T + 8) * 20);
     const uint64_t ctl = (uint64_t)a.reg_ctl;
     float o0, o1, o2, o3;
+    int c0, c1, c2, c3;
     asm volatile(
         // ---- bags: 32 entries x 4 sites straight into their registers; the per-lane byte offset stops
         // advancing at the bag's last read, so entries >= n (never indexed) repeat it and nothing is
@@ -163,6 +164,33 @@ __global__ __launch_bounds__(64) void pool_reg_kernel(PoolArgs a)
         ".set m6a_i, m6a_i+1\n"
         ".endr\n"
         "s_waitcnt vmcnt(0)\n"
+        // mod_ratio numerators: reads with p >= thr among the bag's n entries (v40..v43, one per site)
+        "v_mov_b32 v40, 0\n"
+        "v_mov_b32 v41, 0\n"
+        "v_mov_b32 v42, 0\n"
+        "v_mov_b32 v43, 0\n"
+        ".set m6a_e, 0\n"
+        ".rept 32\n"
+        "s_cmp_lt_u32 m6a_e, %[n]\n"
+        "s_cselect_b64 s[84:85], exec, 0\n"
+        "v_cmp_le_f32 vcc, %[thr], v[128+2*m6a_e]\n"
+        "s_and_b64 vcc, vcc, s[84:85]\n"
+        "v_addc_co_u32 v40, vcc, 0, v40, vcc\n"
+        "v_cmp_le_f32 vcc, %[thr], v[129+2*m6a_e]\n"
+        "s_and_b64 vcc, vcc, s[84:85]\n"
+        "v_addc_co_u32 v41, vcc, 0, v41, vcc\n"
+        "v_cmp_le_f32 vcc, %[thr], v[192+2*m6a_e]\n"
+        "s_and_b64 vcc, vcc, s[84:85]\n"
+        "v_addc_co_u32 v42, vcc, 0, v42, vcc\n"
+        "v_cmp_le_f32 vcc, %[thr], v[193+2*m6a_e]\n"
+        "s_and_b64 vcc, vcc, s[84:85]\n"
+        "v_addc_co_u32 v43, vcc, 0, v43, vcc\n"
+        ".set m6a_e, m6a_e+1\n"
+        ".endr\n"
+        "v_mov_b32 %[c0], v40\n"
+        "v_mov_b32 %[c1], v41\n"
+        "v_mov_b32 %[c2], v42\n"
+        "v_mov_b32 %[c3], v43\n"
         ".set m6a_i, 0\n"
         ".rept 128\n"
         "v_sub_f32 v[128+m6a_i], 1.0, v[128+m6a_i]\n"
@@ -228,13 +256,13 @@ __global__ __launch_bounds__(64) void pool_reg_kernel(PoolArgs a)
         "v_mov_b32 %[o1], v61\n"
         "v_mov_b32 %[o2], v62\n"
         "v_mov_b32 %[o3], v63\n"
-        : [o0] "=v"(o0), [o1] "=v"(o1), [o2] "=v"(o2), [o3] "=v"(o3)
-        : [b0] "v"(boff[0]), [b1] "v"(boff[1]), [b2] "v"(boff[2]), [b3] "v"(boff[3]), [rp] "s"(rp), [tab] "s"(tab),
+        : [o0] "=v"(o0), [o1] "=v"(o1), [o2] "=v"(o2), [o3] "=v"(o3), [c0] "=&v"(c0), [c1] "=&v"(c1), [c2] "=&v"(c2), [c3] "=&v"(c3)
+        : [thr] "s"(a.thr), [b0] "v"(boff[0]), [b1] "v"(boff[1]), [b2] "v"(boff[2]), [b3] "v"(boff[3]), [rp] "s"(rp), [tab] "s"(tab),
           [ctl] "s"(ctl), [n] "s"(a.uniform_n), [nr] "s"(a.reg_rounds), [nt] "s"(a.n_rem), [fm] "s"(a.reg_final_merges)
         : "memory", "scc", "vcc",
           "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51",
           "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67",
-          "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83",
+          "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85",
           "v32", "v33", "v34", "v35", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v56", "v57", "v58", "v59",
           "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75",
           "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91",
@@ -251,19 +279,11 @@ __global__ __launch_bounds__(64) void pool_reg_kernel(PoolArgs a)
           "v233", "v234", "v235", "v236", "v237", "v238", "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246",
           "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255");
     const float o[4] = {o0, o1, o2, o3};
+    const int cge[4] = {c0, c1, c2, c3};
 #pragma unroll
     for (int q = 0; q < 4; q++)
-        if (site[q] >= 0) a.site_prob[site[q]] = o[q] / (float)a.T;
-}
-
-// mod_ratio = mean(p >= thr) for uniform bags (pool_reg_kernel leaves it to this pass: 4 B/read)
-__global__ __launch_bounds__(256) void mod_ratio_uniform_kernel(PoolArgs a)
-{
-    const int n = a.uniform_n;
-    for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < a.n_sites; s += (int64_t)gridDim.x * blockDim.x) {
-        const float *p = a.read_prob + a.off[s];
-        int c = 0;
-        for (int i = 0; i < n; i++) c += p[i] >= a.thr ? 1 : 0;
-        a.mod_ratio[s] = (double)c / (double)n;
-    }
+        if (site[q] >= 0) {
+            a.site_prob[site[q]] = o[q] / (float)a.T;
+            a.mod_ratio[site[q]] = (double)cge[q] / (double)a.uniform_n;
+        }
 }
