@@ -106,6 +106,22 @@ int m6a_infer(m6a_ctx *ctx, const float *X, const uint8_t *site_kmers, const int
 int m6a_bag_forward(m6a_ctx *ctx, const float *X, const uint8_t *site_kmers, int64_t n_bags,
                     int bag, float *site_prob);
 
+/* validate() at DataLoader num_workers=0, shuffle=False (m6anet/utils/training_utils.py:213-268):
+ * n_iters passes over the sites in order; each pass draws n_samples reads of every site WITHOUT
+ * replacement -- np.random.choice(n, n_samples, replace=False), m6anet/utils/data_utils.py:213-214,
+ * i.e. the legacy shuffle of arange(n), the stream seeded once with `seed` -- and predicts
+ * y_pred[t][s] = 1 - prod_k (1 - p[read k of the sample]) (MILModel.forward, model.py:155-164).
+ * y_pred [n_iters][n_sites]; y_pred_avg [n_sites] = np.mean(y_pred, axis=0) (training_utils.py:253)
+ * or NULL.  Every bag needs >= n_samples reads (NumPy raises otherwise: M6A_EINVAL).  The sampler
+ * is a sequential walk over one random stream and runs on the host; gathers, products and the
+ * mean run on the GPU.  m6a_validate_pool starts from read probabilities, m6a_validate encodes
+ * first (read_prob [R] or NULL).  Pointers: all host or all device, as everywhere. */
+int m6a_validate_pool(m6a_ctx *ctx, const float *read_prob, const int64_t *off, int64_t n_sites,
+                      int n_iters, int n_samples, uint32_t seed, float *y_pred, float *y_pred_avg);
+int m6a_validate(m6a_ctx *ctx, const float *X, const uint8_t *site_kmers, const int64_t *off,
+                 int64_t n_sites, int n_iters, int n_samples, uint32_t seed, float *read_prob,
+                 float *y_pred, float *y_pred_avg);
+
 /* Host-only helpers (no GPU, usable with ctx == NULL semantics: they take no ctx). */
 
 /* Flush groups of the reference's loop (inference_utils.py:33,47): batches of `batch_size`

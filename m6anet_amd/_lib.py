@@ -13,7 +13,7 @@ RNG_NUMPY = 0
 
 # every symbol include/m6a.h declares (tests check the .so exports exactly these)
 SYMBOLS = ["m6a_create", "m6a_destroy", "m6a_last_error", "m6a_set_stream", "m6a_set_job_offset", "m6a_set_scan_driver", "m6a_set_table_variant", "m6a_set_encoder_variant", "m6a_last_encoder_variant", "m6a_sync",
-           "m6a_encode_reads", "m6a_site_pool", "m6a_infer", "m6a_bag_forward", "m6a_flush_groups",
+           "m6a_encode_reads", "m6a_site_pool", "m6a_infer", "m6a_bag_forward", "m6a_validate_pool", "m6a_validate", "m6a_flush_groups",
            "m6a_shard_plan", "m6a_profile_enable", "m6a_profile_read", "m6a_last_pool_variant",
            "m6a_version"]
 
@@ -70,6 +70,8 @@ def load():
     L.m6a_site_pool.argtypes = [vp, vp, vp, i64, i32, i32, f32, u32, i32, i64, i64, vp, vp]
     L.m6a_infer.argtypes = [vp, vp, vp, vp, i64, i32, i32, f32, u32, i32, i64, i64, vp, vp, vp]
     L.m6a_bag_forward.argtypes = [vp, vp, vp, i64, i32, vp]
+    L.m6a_validate_pool.argtypes = [vp, vp, vp, i64, i32, i32, C.c_uint32, vp, vp]
+    L.m6a_validate.argtypes = [vp, vp, vp, vp, i64, i32, i32, C.c_uint32, vp, vp, vp]
     L.m6a_flush_groups.argtypes = [i64, i64, i64, vp, i64]
     L.m6a_flush_groups.restype = i64
     L.m6a_shard_plan.argtypes = [vp, i64, i64, i64, i32, vp]

@@ -88,7 +88,7 @@ struct m6a_ctx {
     unsigned long long *h_minmax = nullptr;   // pinned
     int *h_err = nullptr;                     // pinned
     // host-pointer staging
-    DevBuf sX, sK, sOff, sP, sSite, sMod;
+    DevBuf sX, sK, sOff, sP, sSite, sMod, val_idx, val_y, val_avg;
     Profiler prof;
     const char *pool_variant = "none";
 };
@@ -700,7 +700,7 @@ void m6a_destroy(m6a_ctx *c)
         for (auto e : c->prof.start[k]) (void)hipEventDestroy(e);
         for (auto e : c->prof.stop[k]) (void)hipEventDestroy(e);
     }
-    for (DevBuf *b : {&c->raw, &c->tab, &c->goff, &c->rp_scratch, &c->off_scratch, &c->start_pos, &c->plan_dev, &c->tab_reg, &c->sX, &c->sK, &c->sOff,
+    for (DevBuf *b : {&c->raw, &c->tab, &c->goff, &c->rp_scratch, &c->off_scratch, &c->start_pos, &c->plan_dev, &c->tab_reg, &c->val_idx, &c->val_y, &c->val_avg, &c->sX, &c->sK, &c->sOff,
                       &c->sP, &c->sSite, &c->sMod}) b->release();
     if (c->d_wfrag) (void)hipFree(c->d_wfrag);
     if (c->d_wfrag2) (void)hipFree(c->d_wfrag2);
@@ -912,6 +912,156 @@ int m6a_bag_forward(m6a_ctx *c, const float *X, const uint8_t *km, int64_t B, in
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
     return M6A_OK;
+}
+
+namespace {
+
+// the training-mode sampler of a whole validation run (data_utils.py:213-214 under
+// training_utils.py:235-240, num_workers=0): RandomState.choice(n, K, replace=False) =
+// permutation(n)[:K] = legacy shuffle of arange(n): for i = n-1..1: j = rk_interval(i) (masked rejection over
+// 32-bit words), swap.  One stream, seeded once, pass after pass, site after site -- inherently serial, so it
+// runs here; gidx gets GLOBAL read indices [T][S][K].
+int validation_indices(m6a_ctx *c, const int64_t *h_off, int64_t S, int T, int K, uint32_t seed, std::vector<int32_t> &gidx)
+{
+    int64_t nmax = 0;
+    for (int64_t s = 0; s < S; s++) {
+        const int64_t n = h_off[s + 1] - h_off[s];
+        if (n < K) return fail(c, M6A_EINVAL, "site %lld has %lld reads, fewer than n_samples = %d (sampling without replacement)",
+                               (long long)s, (long long)n, K);
+        nmax = std::max(nmax, n);
+    }
+    if (h_off[S] > 0x7fffffff) return fail(c, M6A_EUNSUPPORTED, "more than 2^31 reads");
+    gidx.resize((size_t)T * S * K);
+    std::vector<int32_t> perm((size_t)nmax);
+    std::mt19937 gen(seed);
+    int32_t *out = gidx.data();
+    for (int t = 0; t < T; t++)
+        for (int64_t s = 0; s < S; s++) {
+            const int64_t n = h_off[s + 1] - h_off[s];
+            for (int64_t i = 0; i < n; i++) perm[i] = (int32_t)i;
+            for (int64_t i = n - 1; i >= 1; i--) {
+                uint32_t mask = (uint32_t)i, v;
+                mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+                do { v = (uint32_t)gen() & mask; } while (v > (uint32_t)i);
+                std::swap(perm[i], perm[v]);
+            }
+            for (int k = 0; k < K; k++) *out++ = (int32_t)h_off[s] + perm[k];
+        }
+    return M6A_OK;
+}
+
+// d_rp: device read probabilities; d_y [T][S] and d_avg [S] (or null): device
+int launch_validate_pool(m6a_ctx *c, const float *d_rp, const int64_t *h_off, int64_t S, int T, int K, uint32_t seed,
+                         float *d_y, float *d_avg)
+{
+    std::vector<int32_t> gidx;
+    int rc = validation_indices(c, h_off, S, T, K, seed, gidx);
+    if (rc) return rc;
+    HIPCHK(c, c->val_idx.ensure(gidx.size() * 4));
+    HIPCHK(c, hipMemcpyAsync(c->val_idx.p, gidx.data(), gidx.size() * 4, hipMemcpyHostToDevice, c->stream));
+    const int64_t nb = (int64_t)T * S;
+    prof_begin(c, 1);
+    hipLaunchKernelGGL(sampled_noisy_or_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, c->stream,
+                       d_rp, (const int32_t *)c->val_idx.p, nb, K, d_y);
+    if (d_avg)
+        hipLaunchKernelGGL(mean_over_passes_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, c->stream,
+                           (const float *)d_y, T, S, d_avg);
+    prof_end(c, 1);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));      // gidx (pageable) must outlive the copy
+    return M6A_OK;
+}
+
+int check_validate_args(m6a_ctx *c, int64_t S, int T, int K)
+{
+    if (!c) return M6A_EINVAL;
+    if (S < 0) return fail(c, M6A_EINVAL, "n_sites < 0");
+    if (T < 1) return fail(c, M6A_EINVAL, "n_iters must be >= 1");
+    if (K < 1 || K > M6A_MAX_SAMPLES) return fail(c, M6A_EINVAL, "n_samples must be in 1..%d", M6A_MAX_SAMPLES);
+    if ((double)T * (double)S * K > 2.0e9) return fail(c, M6A_EUNSUPPORTED, "n_iters * n_sites * n_samples too large for one call");
+    return M6A_OK;
+}
+
+}  // namespace
+
+int m6a_validate_pool(m6a_ctx *c, const float *rp, const int64_t *off, int64_t S, int T, int K, uint32_t seed,
+                      float *y, float *avg)
+{
+    int rc = check_validate_args(c, S, T, K);
+    if (rc) return rc;
+    if (S == 0) return M6A_OK;
+    if (!rp || !off || !y) return fail(c, M6A_EINVAL, "null pointer argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    const bool dev = is_device_ptr(rp);
+    if (dev != is_device_ptr(off) || dev != is_device_ptr(y) || (avg && dev != is_device_ptr(avg)))
+        return fail(c, M6A_EINVAL, "read_prob, off, y_pred, y_pred_avg must be all host or all device pointers");
+    std::vector<int64_t> h_off;
+    const int64_t *ho = off;
+    if (dev) {
+        h_off.resize((size_t)S + 1);
+        HIPCHK(c, hipMemcpyAsync(h_off.data(), off, (size_t)(S + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        ho = h_off.data();
+    }
+    if (ho[0] != 0) return fail(c, M6A_EINVAL, "off[0] must be 0");
+    for (int64_t s = 0; s < S; s++) if (ho[s + 1] < ho[s]) return fail(c, M6A_EINVAL, "off[] must be non-decreasing");
+    if (dev) return launch_validate_pool(c, rp, ho, S, T, K, seed, y, avg);
+    const int64_t R = ho[S];
+    HIPCHK(c, c->sP.ensure((size_t)std::max<int64_t>(R, 1) * 4));
+    HIPCHK(c, c->val_y.ensure((size_t)T * S * 4));
+    HIPCHK(c, c->val_avg.ensure((size_t)S * 4));
+    HIPCHK(c, hipMemcpyAsync(c->sP.p, rp, (size_t)R * 4, hipMemcpyHostToDevice, c->stream));
+    rc = launch_validate_pool(c, (const float *)c->sP.p, ho, S, T, K, seed, (float *)c->val_y.p, avg ? (float *)c->val_avg.p : nullptr);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(y, c->val_y.p, (size_t)T * S * 4, hipMemcpyDeviceToHost, c->stream));
+    if (avg) HIPCHK(c, hipMemcpyAsync(avg, c->val_avg.p, (size_t)S * 4, hipMemcpyDeviceToHost, c->stream));
+    return sync_and_check(c);
+}
+
+int m6a_validate(m6a_ctx *c, const float *X, const uint8_t *km, const int64_t *off, int64_t S, int T, int K,
+                 uint32_t seed, float *rp, float *y, float *avg)
+{
+    int rc = check_validate_args(c, S, T, K);
+    if (rc) return rc;
+    if (S == 0) return M6A_OK;
+    if (!X || !km || !off || !y) return fail(c, M6A_EINVAL, "null pointer argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    const bool dev = is_device_ptr(X);
+    if (dev != is_device_ptr(km) || dev != is_device_ptr(off) || dev != is_device_ptr(y) || (rp && dev != is_device_ptr(rp)) ||
+        (avg && dev != is_device_ptr(avg)))
+        return fail(c, M6A_EINVAL, "X, site_kmers, off and the outputs must be all host or all device pointers");
+    if (dev) {
+        float *d_rp = rp;
+        rc = query_bags(c, off, S);
+        if (rc) return rc;
+        if (!d_rp) { HIPCHK(c, c->rp_scratch.ensure((size_t)std::max<int64_t>(c->n_reads, 1) * 4)); d_rp = (float *)c->rp_scratch.p; }
+        rc = launch_encode(c, X, km, off, S, c->n_reads, d_rp);
+        if (rc) return rc;
+        return m6a_validate_pool(c, d_rp, off, S, T, K, seed, y, avg);
+    }
+    // host pointers: encode through the staging buffers, pool from the staged read probabilities
+    if (off[0] != 0) return fail(c, M6A_EINVAL, "off[0] must be 0");
+    for (int64_t s = 0; s < S; s++) if (off[s + 1] < off[s]) return fail(c, M6A_EINVAL, "off[] must be non-decreasing");
+    const int64_t R = off[S];
+    if (R == 0) return fail(c, M6A_EINVAL, "no reads");
+    HIPCHK(c, c->sX.ensure((size_t)R * 9 * 4));
+    HIPCHK(c, c->sK.ensure((size_t)S * 3));
+    HIPCHK(c, c->sOff.ensure((size_t)(S + 1) * 8));
+    HIPCHK(c, c->sP.ensure((size_t)R * 4));
+    HIPCHK(c, c->val_y.ensure((size_t)T * S * 4));
+    HIPCHK(c, c->val_avg.ensure((size_t)S * 4));
+    HIPCHK(c, hipMemcpyAsync(c->sX.p, X, (size_t)R * 9 * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->sK.p, km, (size_t)S * 3, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->sOff.p, off, (size_t)(S + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    host_bag_range(c, off, S);
+    rc = launch_encode(c, (const float *)c->sX.p, (const uint8_t *)c->sK.p, (const int64_t *)c->sOff.p, S, R, (float *)c->sP.p);
+    if (rc) return rc;
+    rc = launch_validate_pool(c, (const float *)c->sP.p, off, S, T, K, seed, (float *)c->val_y.p, avg ? (float *)c->val_avg.p : nullptr);
+    if (rc) return rc;
+    if (rp) HIPCHK(c, hipMemcpyAsync(rp, c->sP.p, (size_t)R * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(y, c->val_y.p, (size_t)T * S * 4, hipMemcpyDeviceToHost, c->stream));
+    if (avg) HIPCHK(c, hipMemcpyAsync(avg, c->val_avg.p, (size_t)S * 4, hipMemcpyDeviceToHost, c->stream));
+    return sync_and_check(c);
 }
 
 int64_t m6a_flush_groups(int64_t S, int64_t bs, int64_t spb, int64_t *group_off, int64_t cap)

@@ -60,6 +60,8 @@ __global__ void pool_table_kernel(PoolArgs a);
 __global__ void pool_reg_kernel(PoolArgs a);
 __global__ void bag_noisy_or_kernel(const float *read_prob, int64_t n_bags, int bag, float *site_prob);
 __global__ void iota_off_kernel(int64_t *off, int64_t n_plus_1, int64_t step);
+__global__ void sampled_noisy_or_kernel(const float *read_prob, const int32_t *gidx, int64_t n_bags, int k, float *y);
+__global__ void mean_over_passes_kernel(const float *y, int n_iters, int64_t n_sites, float *avg);
 __global__ void bag_minmax_kernel(const int64_t *off, int64_t n_sites, unsigned long long *out);
 
 #endif

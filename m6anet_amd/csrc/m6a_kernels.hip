@@ -1034,6 +1034,29 @@ __global__ void bag_noisy_or_kernel(const float *read_prob, int64_t n_bags, int 
     site_prob[b] = 1.0f - prod;
 }
 
+// validation-style forward: y[b] = 1 - prod_k (1 - p[gidx[b][k]]), float32 left to right
+// (training_utils.py:239 -> MILModel.forward -> pooling_blocks.py:127-129 on the sampled 20-read bag)
+__global__ void sampled_noisy_or_kernel(const float *read_prob, const int32_t *gidx, int64_t n_bags, int k, float *y)
+{
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_bags) return;
+    const int32_t *row = gidx + b * k;
+    float prod = 1.0f;
+    for (int j = 0; j < k; j++) prod *= 1.0f - read_prob[row[j]];
+    y[b] = 1.0f - prod;
+}
+
+// np.mean(y, axis=0) of a C-contiguous float32 [n_iters][n_sites]: pass after pass, one divide
+// (training_utils.py:253)
+__global__ void mean_over_passes_kernel(const float *y, int n_iters, int64_t n_sites, float *avg)
+{
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_sites) return;
+    float acc = 0.0f;
+    for (int t = 0; t < n_iters; t++) acc += y[(int64_t)t * n_sites + s];
+    avg[s] = acc / (float)n_iters;
+}
+
 __global__ void iota_off_kernel(int64_t *off, int64_t n_plus_1, int64_t step)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

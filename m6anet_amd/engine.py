@@ -218,6 +218,35 @@ class M6ANetEngine:
         return site
 
 
+    def validate_pool(self, read_probs, off, n_iterations=1, n_samples=N_SAMPLES, seed=0):
+        """The prediction part of the reference's `validate` (training_utils.py:233-253) from read
+        probabilities: each pass samples n_samples reads per site without replacement
+        (data_utils.py:213-214).  Returns (y_pred float32 [n_iterations, S], y_pred_avg float32 [S])."""
+        aP, aO = _Arg(read_probs, np.float32, "float32"), _Arg(off, np.int64, "int64")
+        S = aO.size - 1
+        y = self._out(aP.is_dev, int(n_iterations) * S, np.float32, "float32")
+        avg = self._out(aP.is_dev, S, np.float32, "float32")
+        aY, aA = _Arg(y, np.float32, "float32"), _Arg(avg, np.float32, "float32")
+        self._chk(self._L.m6a_validate_pool(self._h, aP.ptr, aO.ptr, S, int(n_iterations), int(n_samples),
+                                            int(seed) & 0xffffffff, aY.ptr, aA.ptr))
+        return y.reshape(int(n_iterations), S), avg
+
+    def validate_forward(self, X, site_kmers, off, n_iterations=1, n_samples=N_SAMPLES, seed=0, want_read_probs=False):
+        """Encoder + validate_pool in one call.  Returns (y_pred, y_pred_avg[, read_probs])."""
+        aX, aK, aO = _Arg(X, np.float32, "float32"), _Arg(site_kmers, np.uint8, "uint8"), _Arg(off, np.int64, "int64")
+        S = aO.size - 1
+        R = aX.size // 9
+        y = self._out(aX.is_dev, int(n_iterations) * S, np.float32, "float32")
+        avg = self._out(aX.is_dev, S, np.float32, "float32")
+        rp = self._out(aX.is_dev, R, np.float32, "float32") if want_read_probs else None
+        aY, aA = _Arg(y, np.float32, "float32"), _Arg(avg, np.float32, "float32")
+        aP = _Arg(rp, np.float32, "float32") if rp is not None else None
+        self._chk(self._L.m6a_validate(self._h, aX.ptr, aK.ptr, aO.ptr, S, int(n_iterations), int(n_samples),
+                                       int(seed) & 0xffffffff, aP.ptr if aP else None, aY.ptr, aA.ptr))
+        y = y.reshape(int(n_iterations), S)
+        return (y, avg, rp) if want_read_probs else (y, avg)
+
+
 def flush_groups(n_sites, batch_size=16, save_per_batch=2):
     """Site offsets of the reference's flush groups (inference_utils.py:33,47)."""
     L = _lib.load()

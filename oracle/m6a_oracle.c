@@ -341,3 +341,62 @@ void m6a_or_bag_noisy_or(const float *read_prob, int64_t n_bags, int bag, float 
         site_prob[b] = 1.0f - prod;
     }
 }
+
+/* ------------------------------------------- validation-style forward ----- */
+/* data_utils.py:213-214 -> RandomState.choice(n, k, replace=False) -> permutation(n)[:k] -> legacy
+ * shuffle: for i in reversed(range(1, n)): j = rk_interval(i); arr[i], arr[j] = arr[j], arr[i] */
+int m6a_or_choice_noreplace(m6a_or_mt *st, int64_t n, int k, int32_t *perm, int32_t *out_idx)
+{
+    if (k > n) return -1;
+    for (int64_t i = 0; i < n; i++) perm[i] = (int32_t)i;
+    for (int64_t i = n - 1; i >= 1; i--) {
+        uint32_t mask = (uint32_t)i, v;
+        mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+        do { v = m6a_or_mt_next(st) & mask; } while (v > (uint32_t)i);
+        const int32_t tmp = perm[i]; perm[i] = perm[v]; perm[v] = tmp;
+    }
+    for (int j = 0; j < k; j++) out_idx[j] = perm[j];
+    return 0;
+}
+
+int m6a_or_validation_indices(uint32_t seed, const int64_t *off, int64_t n_sites, int n_iters, int k,
+                              int32_t *idx)
+{
+    int64_t nmax = 0;
+    for (int64_t s = 0; s < n_sites; s++) if (off[s + 1] - off[s] > nmax) nmax = off[s + 1] - off[s];
+    int32_t *perm = (int32_t *)malloc((size_t)(nmax > 0 ? nmax : 1) * sizeof(int32_t));
+    if (!perm) return -2;
+    m6a_or_mt st;
+    m6a_or_mt_seed(&st, seed);
+    int rc = 0;
+    for (int t = 0; t < n_iters && !rc; t++)
+        for (int64_t s = 0; s < n_sites && !rc; s++)
+            rc = m6a_or_choice_noreplace(&st, off[s + 1] - off[s], k, perm, idx + ((int64_t)t * n_sites + s) * k);
+    free(perm);
+    return rc;
+}
+
+int m6a_or_validate(const float *read_prob, const int64_t *off, int64_t n_sites, int n_iters, int k,
+                    uint32_t seed, float *y_pred, float *y_pred_avg)
+{
+    int32_t *idx = (int32_t *)malloc((size_t)n_iters * (size_t)n_sites * (size_t)k * sizeof(int32_t) + 4);
+    if (!idx) return -2;
+    int rc = m6a_or_validation_indices(seed, off, n_sites, n_iters, k, idx);
+    if (!rc) {
+        for (int t = 0; t < n_iters; t++)
+            for (int64_t s = 0; s < n_sites; s++) {
+                const int32_t *row = idx + ((int64_t)t * n_sites + s) * k;
+                float prod = 1.0f;
+                for (int j = 0; j < k; j++) prod *= (1.0f - read_prob[off[s] + row[j]]);
+                y_pred[(int64_t)t * n_sites + s] = 1.0f - prod;
+            }
+        if (y_pred_avg)
+            for (int64_t s = 0; s < n_sites; s++) {
+                float acc = 0.0f;                 /* np.mean(axis=0) of a C-contiguous (T,S) array: row by row */
+                for (int t = 0; t < n_iters; t++) acc += y_pred[(int64_t)t * n_sites + s];
+                y_pred_avg[s] = acc / (float)n_iters;
+            }
+    }
+    free(idx);
+    return rc;
+}

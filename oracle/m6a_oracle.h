@@ -73,6 +73,24 @@ int m6a_or_site_pool_at(const float *read_prob, const int64_t *off, int64_t n_si
  * (m6anet/model/model_blocks/pooling_blocks.py:127-129). */
 void m6a_or_bag_noisy_or(const float *read_prob, int64_t n_bags, int bag, float *site_prob);
 
+/* RandomState.choice(n, k, replace=False) == permutation(n)[:k]: legacy shuffle of arange(n), for
+ * i = n-1 .. 1: j = rk_interval(i) (masked rejection over 32-bit words, mask = smallest 2^b-1 >= i),
+ * swap(i, j) -- the training-mode read sampler, m6anet/utils/data_utils.py:213-214.
+ * perm is scratch of n entries; returns -1 when k > n (NumPy raises ValueError). */
+int m6a_or_choice_noreplace(m6a_or_mt *st, int64_t n, int k, int32_t *perm, int32_t *out_idx);
+
+/* The sampler of a whole validation run at DataLoader num_workers=0, shuffle=False
+ * (m6anet/utils/training_utils.py:235-240 over data_utils.py:213-214): the stream is seeded once,
+ * pass after pass, site after site.  idx [n_iters][n_sites][k] = read index inside the site's bag. */
+int m6a_or_validation_indices(uint32_t seed, const int64_t *off, int64_t n_sites, int n_iters, int k,
+                              int32_t *idx);
+
+/* validate()'s predictions (training_utils.py:233-250): y_pred[t][s] = 1 - prod_k (1 - p[off[s]+idx[t][s][k]])
+ * (float32, left to right: MILModel.forward -> SigmoidProdPooling, pooling_blocks.py:127-129), and
+ * y_pred_avg = np.mean(y_pred, axis=0): float32, pass after pass, then one divide. */
+int m6a_or_validate(const float *read_prob, const int64_t *off, int64_t n_sites, int n_iters, int k,
+                    uint32_t seed, float *y_pred, float *y_pred_avg);
+
 #ifdef __cplusplus
 }
 #endif

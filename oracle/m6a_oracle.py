@@ -45,6 +45,8 @@ def lib():
                                           C.c_int64, C.c_int64, C.c_int64, C.c_int, f32p, f64p]
         L.m6a_or_site_pool_at.restype = C.c_int
         L.m6a_or_bag_noisy_or.argtypes = [f32p, C.c_int64, C.c_int, f32p]
+        L.m6a_or_validation_indices.argtypes = [C.c_uint32, i64p, C.c_int64, C.c_int, C.c_int, i32p]
+        L.m6a_or_validate.argtypes = [f32p, i64p, C.c_int64, C.c_int, C.c_int, C.c_uint32, f32p, f32p]
         _lib = L
     return _lib
 
@@ -119,3 +121,28 @@ def bag_noisy_or(read_prob, bag=20):
     out = np.empty(nb, np.float32)
     lib().m6a_or_bag_noisy_or(_p(read_prob, C.c_float), nb, bag, _p(out, C.c_float))
     return out
+
+
+def validation_indices(seed, off, n_iters, k=20):
+    """[n_iters][S][k] read indices of the training-mode sampler (choice without replacement)."""
+    off = np.ascontiguousarray(off, np.int64)
+    S = len(off) - 1
+    idx = np.empty((n_iters, S, k), np.int32)
+    rc = lib().m6a_or_validation_indices(seed, _p(off, C.c_int64), S, n_iters, k, _p(idx, C.c_int32))
+    if rc:
+        raise ValueError("a bag holds fewer than %d reads" % k)
+    return idx
+
+
+def validate(read_prob, off, n_iters, seed=0, k=20):
+    """(y_pred [n_iters][S], y_pred_avg [S]) of validate() at num_workers=0."""
+    read_prob = np.ascontiguousarray(read_prob, np.float32)
+    off = np.ascontiguousarray(off, np.int64)
+    S = len(off) - 1
+    y = np.empty((n_iters, S), np.float32)
+    avg = np.empty(S, np.float32)
+    rc = lib().m6a_or_validate(_p(read_prob, C.c_float), _p(off, C.c_int64), S, n_iters, k, seed,
+                               _p(y, C.c_float), _p(avg, C.c_float))
+    if rc:
+        raise ValueError("a bag holds fewer than %d reads" % k)
+    return y, avg

@@ -32,6 +32,9 @@ What each file pins (reference file:line):
                                    eventalign.txt(.gz here),eventalign.index}
   dataprep_ref_run/                parallel_index + parallel_preprocess_tx at n_processes=1
                                    (m6anet/utils/dataprep_utils.py:210-266,328-488)
+  validate.npz                     `validate` over a 'Val'-mode NanopolishDS, DataLoader num_workers=0
+                                   (m6anet/utils/training_utils.py:213-268; the 20-read sampler without
+                                   replacement at m6anet/utils/data_utils.py:213-214)
 """
 import gzip
 import io
@@ -197,11 +200,51 @@ def dataprep_goldens():
         print("dataprep golden", tag)
 
 
+def validate_goldens():
+    """The reference's validation pass on the bundled data: a labelled copy of data.info (every site in
+    the 'Val' split), `validate()` at num_workers=0 -- the only setting in which its sampler is
+    reproducible -- for a few (seed, n_iterations, batch_size).  Also the sampler alone:
+    np.random.choice(n, 20, replace=False) in the same order, as index arrays."""
+    import pandas as pd
+    from torch.utils.data import DataLoader
+    from m6anet.utils.data_utils import train_collate
+    from m6anet.utils.training_utils import validate
+    tmp = tempfile.mkdtemp(prefix="m6a_val_")
+    shutil.copy(os.path.join(DATA, "data.json"), tmp)
+    info = pd.read_csv(os.path.join(DATA, "data.info"))
+    info["set_type"] = "Val"
+    info["modification_status"] = (np.arange(len(info)) % 3 == 0).astype(int)
+    info.to_csv(os.path.join(tmp, "data.info.labelled"), index=False)
+    ds = NanopolishDS(tmp, min_reads=20, norm_path=NORMS["hct116"], mode="Val")
+    model = load_model(MODELS["hct116"])
+    out = {"n_reads": ds.data_info["n_reads"].values.astype(np.int64), "y_true": ds.labels.astype(np.float32)}
+    for seed, T, bs in ((0, 5, 16), (7, 3, 101), (1, 12, 1)):
+        dl = DataLoader(ds, batch_size=bs, shuffle=False, num_workers=0, collate_fn=train_collate)
+        np.random.seed(seed)
+        res = validate(model, dl, "cpu", torch.nn.BCELoss(), n_iterations=T)
+        key = "seed%d_T%d_bs%d" % (seed, T, bs)
+        out[key + "_y_pred"] = np.asarray(res["y_pred"], dtype=np.float32)               # [T][S]
+        out[key + "_y_pred_avg"] = np.mean(res["y_pred"], axis=0)                        # as validate() averages
+        out[key + "_avg_loss"] = np.float64(res["avg_loss"])
+        out[key + "_roc_auc"] = np.float64(res["roc_auc"])
+        out[key + "_pr_auc"] = np.float64(res["pr_auc"])
+        np.random.seed(seed)
+        out[key + "_idx"] = np.stack([np.stack([np.random.choice(int(n), 20, replace=False) for n in out["n_reads"]])
+                                      for _ in range(T)]).astype(np.int32)             # [T][S][20]
+        print(key, out[key + "_y_pred"].shape, out[key + "_y_pred_avg"].dtype, float(out[key + "_avg_loss"]))
+    np.savez_compressed(os.path.join(HERE, "validate.npz"), **out)
+    shutil.rmtree(tmp)
+
+
 def main():
+    if "--only-validate" in sys.argv:
+        validate_goldens()
+        return
     if "--only-dataprep" in sys.argv:
         dataprep_goldens()
         return
     dataprep_goldens()
+    validate_goldens()
     os.makedirs(ASSETS, exist_ok=True)
     np.set_printoptions(precision=9)
 

@@ -368,6 +368,55 @@ def test_infer_ragged_end_to_end_vs_oracle(engines, orc, weights, driver):
     assert np.array_equal(mod, want_mod)
 
 
+# ------------------------------------------------------------------ validation-style forward -----
+@pytest.mark.parametrize("key,seed,T,same_batching", [("seed0_T5_bs16", 0, 5, True), ("seed7_T3_bs101", 7, 3, True),
+                                                     ("seed1_T12_bs1", 1, 12, False)])
+def test_validate_pool_vs_reference_validate(eng, golden, key, seed, T, same_batching):
+    """`validate` at num_workers=0 (training_utils.py:213-268) -- sampler without
+    replacement, per-pass predictions, float32 mean -- from the reference's own read probabilities."""
+    g = golden("validate.npz")
+    b = golden("bundled_inputs.npz")
+    p = golden("bundled_readprob.npz")["hct116"]
+    y, avg = eng.validate_pool(p, b["off"], T, seed=seed)
+    if same_batching:
+        assert np.array_equal(y, g[key + "_y_pred"]) and np.array_equal(avg, g[key + "_y_pred_avg"])
+    else:   # batch_size 1: the reference's own read probabilities differ by 1 ulp between batchings
+        assert np.abs(y - g[key + "_y_pred"]).max() <= 2.4e-7 and np.abs(avg - g[key + "_y_pred_avg"]).max() <= 2.4e-7
+
+
+def test_validate_forward_vs_oracle_and_errors(engines, orc, weights):
+    from m6anet_amd._lib import M6AError
+    e = engines["hek293t_glori"]
+    d = synthetic.make_sites(3000, (20, 300), seed=12)
+    y, avg, rp = e.validate_forward(d["X"], d["site_kmers"], d["off"], n_iterations=4, seed=5, want_read_probs=True)
+    p = orc.encode_reads(weights["hek293t_glori"], d["X"], d["site_kmers"], d["off"], n_threads=8)
+    assert np.allclose(rp, p, rtol=1e-5, atol=1e-8)
+    want_y, want_avg = orc.validate(rp, d["off"], 4, seed=5)
+    assert np.array_equal(y, want_y) and np.array_equal(avg, want_avg)
+    # device tensors give the same bits
+    import torch
+    dev = torch.device("cuda:0")
+    ty, tavg = e.validate_forward(*(torch.from_numpy(d[k]).to(dev) for k in ("X", "site_kmers", "off")), n_iterations=4, seed=5)
+    assert np.array_equal(ty.cpu().numpy(), y) and np.array_equal(tavg.cpu().numpy(), avg)
+    # other sample counts; a bag shorter than the sample is NumPy's ValueError
+    y7, avg7 = e.validate_pool(rp, d["off"], 3, n_samples=7, seed=1)
+    w7, wavg7 = orc.validate(rp, d["off"], 3, seed=1, k=7)
+    assert np.array_equal(y7, w7) and np.array_equal(avg7, wavg7)
+    with pytest.raises(M6AError):
+        e.validate_pool(rp[:44], np.array([0, 25, 44], np.int64), 2)
+
+
+def test_validate_dictionary_like_the_reference(eng, golden):
+    from m6anet_amd import training_utils as tu
+    g = golden("validate.npz")
+    b = golden("bundled_inputs.npz")
+    res = tu.validate(eng, b["X"], b["site_kmers"], b["off"], g["y_true"], n_iterations=5, seed=0)
+    assert set(res) == {"y_pred", "y_true", "compute_time", "roc_auc", "pr_auc", "avg_loss"}
+    assert len(res["y_pred"]) == 5 and np.abs(np.asarray(res["y_pred"]) - g["seed0_T5_bs16_y_pred"]).max() <= 1e-5
+    assert abs(res["avg_loss"] - float(g["seed0_T5_bs16_avg_loss"])) < 1e-4
+    assert abs(res["roc_auc"] - float(g["seed0_T5_bs16_roc_auc"])) < 1e-3
+
+
 def test_device_tensors_match_host_path(eng):
     import torch
     d = synthetic.make_sites(5000, 20, seed=3)
