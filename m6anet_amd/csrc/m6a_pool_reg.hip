@@ -5,10 +5,11 @@
 // that takes position j of 256 different groups -- lane = 4 sites -- sees a WAVE-UNIFORM index for
 // every draw.  A uniform index into per-lane data is exactly what the VGPR index mode of gfx9/CDNA
 // does for free: s_set_gpr_idx_idx puts the index in M0 and the next v_pk_mul_f32 reads
-// v[base + M0].  No LDS gather at all: the inner loop is 1 SALU + 2 VALU per draw of 4 sites
+// v[base + M0].  No LDS gather at all: the inner loop is 1-2 SALU + 2 VALU per draw of 4 sites
 // (v_pk_mul_f32 advances two sites), against 5 VALU + 4.25 LDS instructions per draw of 8 sites in
-// the LDS kernel, whose floor is the LDS pipe (0.57 ms per 1 M sites x T=1000; this one is bound
-// by VALU issue, 0.31 ms).
+// the LDS kernel, whose floor is the LDS pipe (0.57 ms per 1 M sites x T=1000, 0.93 ms measured).
+// This one is bound by VALU issue: an indexed v_pk_mul_f32 issues every ~6 cycles per wavefront
+// (tools/gpr_index_bench.hip), i.e. ~0.43 ms; measured 0.50 ms.
 //
 // The compiler cannot express "this instruction's source register is v[128 + M0]" and has no
 // register class beyond 32 dwords, so the core is one hand-written assembly block with its own
