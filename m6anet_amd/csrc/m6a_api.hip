@@ -484,8 +484,8 @@ int launch_encode(m6a_ctx *c, const float *X, const uint8_t *km, const int64_t *
     a.tiles_per_wave = (a.n_tiles + max_waves - 1) / max_waves;
     const int64_t waves = (a.n_tiles + a.tiles_per_wave - 1) / a.tiles_per_wave;
     const unsigned blocks = (unsigned)((waves + 3) / 4);
-    // every bag >= 16 reads: a 32-read tile spans <= 3 sites -> 12-slot layer 1 (110 MFMAs per tile);
-    // otherwise the general 16-slot kernel (120)
+    // every bag >= 16 reads: a 32-read tile spans <= 3 sites -> 12-slot layer 1 (106 MFMAs per tile);
+    // otherwise the general 16-slot kernel (116)
     const bool csite = c->enc_variant ? c->enc_variant == 2 : c->bag_min >= M6A_CSITE_MIN_BAG;
     c->enc_variant_used = csite ? "csite12" : "general16";
     prof_begin(c, 0);

@@ -45,6 +45,12 @@ __device__ __forceinline__ int wave_sum_i32(int v)
     return v;
 }
 
+// Accumulator registers of layer-1 unit group m that feed layer 2: register q of a lane holds units
+// 32m + (q&3) + 8(q>>2) + 4*half, so in the last group (units 128..159) registers 12..15 are units 152..159:
+// padding beyond the 150 hidden units and the constant-one unit (150) -- zero weights, skipped (76 instead of
+// 80 layer-2 MFMAs per tile, same bits).
+#define L2_REGS(m) ((m) == 4 ? 12 : 16)
+
 // ReLU as one integer max: negative floats (and -0.0) have the sign bit set, i.e. are negative
 // as int32, so max(bits, 0) zeroes them and leaves positive values untouched.  fmaxf() costs two
 // VALU ops here (a canonicalising v_max first), and the encoder issues 96 of them per tile.
@@ -221,10 +227,10 @@ __global__ __launch_bounds__(256, 2) void enc_kernel(EncArgs a)
             if (m == 0) link1(tn, s_base, o, sn, km, fn);
             if (m == 2) link2(km, fn);
 #pragma unroll
-            for (int q = 0; q < 16; q++) cur[q] = relu_bits(cur[q]);
+            for (int q = 0; q < L2_REGS(m); q++) cur[q] = relu_bits(cur[q]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int q = 0; q < 16; q++)
+            for (int q = 0; q < L2_REGS(m); q++)
                 acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(w2[m * 16 + q], cur[q], acc2, 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -404,10 +410,10 @@ __global__ __launch_bounds__(256, 2) void enc_csite_kernel(EncArgs a)
             if (m == 1) link2(kidn, evn);
             if (m == 3) link3(evn, reln, fn[4], f, a4, a5);             // layer1(4) has issued: in place
 #pragma unroll
-            for (int q = 0; q < 16; q++) cur[q] = relu_bits(cur[q]);
+            for (int q = 0; q < L2_REGS(m); q++) cur[q] = relu_bits(cur[q]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int q = 0; q < 16; q++)
+            for (int q = 0; q < L2_REGS(m); q++)
                 acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(w2[m * 16 + q], cur[q], acc2, 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
