@@ -315,6 +315,28 @@ def test_pool_many_small_groups_and_one_huge_group(eng, orc):
             assert same_sites(site, want_site), (bs, spb, mode, eng.last_pool_variant)
 
 
+def test_pool_uniform_random_configurations(eng, orc):
+    """Random (bag size, num_iterations, batch geometry, seed) for uniform bags: the register kernel, the LDS
+    kernel and the oracle must agree bit for bit (tails, several leaves, many positions per group, ...)."""
+    g = np.random.Generator(np.random.PCG64(2026))
+    for _ in range(24):
+        n = int(g.integers(1, 33))
+        T = int(g.choice([1, 3, 8, 9, 40, 129, 250, 777, 1000, 1023, 1500, 2600]))
+        bs = int(g.choice([1, 3, 16, 50]))
+        spb = int(g.choice([1, 2, 3]))
+        S = int(g.integers(1, 400))
+        seed = int(g.integers(0, 2 ** 32))
+        off = np.arange(S + 1, dtype=np.int64) * n
+        p = rand_probs(seed % 1000, off)
+        want_site, want_mod = orc.site_pool(p, off, T, THR, seed=seed, batch_size=bs, save_per_batch=spb, n_threads=8)
+        for mode, name in TABLE_VARIANTS:
+            with table_variant(eng, mode):
+                site, mod = eng.calculate_site_proba(p, off, T, 20, THR, seed=seed, batch_size=bs, save_per_batch=spb)
+            assert eng.last_pool_variant == name
+            assert same_sites(site, want_site), (n, T, bs, spb, S, seed, name)
+            assert np.array_equal(mod, want_mod), (n, T, bs, spb, S, seed, name)
+
+
 def test_pool_seeds_differ_and_repeat(eng):
     off = np.arange(101, dtype=np.int64) * 20
     p = rand_probs(1, off)
