@@ -1,15 +1,19 @@
 // m6a_kernels.hip -- gfx950 (MI355X / CDNA4) kernels of the m6A inference hot path.
 //
-//   enc_kernel         read encoder: [x(9) | emb(6) | 1] -> 150 (BN folded) -> ReLU -> 32 -> ReLU
-//                      -> 1 -> sigmoid, all in registers on v_mfma_f32_32x32x2_f32 (exact f32).
-//   pool_scan_start_kernel + pool_scan_kernel
+//   enc_kernel, enc_csite_kernel
+//                      read encoder: [x(9) | emb(6) | 1] -> 150 (BN folded) -> ReLU -> 32 -> ReLU
+//                      -> 1 -> sigmoid, all in registers on v_mfma_f32_32x32x2_f32 (exact f32); the
+//                      csite variant folds the per-site constants (12 K-slots, bags >= 16 reads).
+//   pool_scan_start_kernel + pool_scan_site_kernel, pool_scan_group_kernel
 //                      site pooling, exact NumPy-stream replay, any bag sizes: a counting pass per
 //                      flush group finds where each site starts in the shared MT19937 word stream
-//                      (masked rejection); then one wavefront per site compacts its accepted draws
-//                      through LDS and multiplies the 20-term products.
-//   pool_table_kernel  same result when every bag has the same size n <= 32: the accepted
-//                      index sequence is then identical in every flush group, so it is a
-//                      precomputed table and the kernel is a pure LDS gather, 8 sites per pass.
+//                      (masked rejection), then one wavefront per site compacts its accepted draws
+//                      through LDS and multiplies the 20-term products; or one wavefront per group.
+//   pool_table_kernel  same result when every bag has the same size n <= 32: the accepted index
+//                      sequence is then identical in every flush group, so it is a precomputed table
+//                      and the kernel is a pure LDS gather, 8 sites per pass.  (The default for uniform
+//                      bags is pool_reg_kernel in m6a_pool_reg.hip: bags in registers, no LDS at all.)
+//   sampled_noisy_or_kernel, mean_over_passes_kernel: the validation-style forward.
 //   bag_noisy_or_kernel, iota_off_kernel, bag_minmax_kernel: small helpers.
 //
 // Reference lines each kernel restates are cited at the kernel.  Wave = 64 lanes throughout.
@@ -19,13 +23,6 @@
 #include "m6a_kernels.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-__device__ __forceinline__ float wave_sum_f32(float v)
-{
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
-    return v;
-}
 
 // sum over each group of 8 consecutive lanes, in NumPy's pairwise-leaf order
 // ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)); every lane of the group gets it.  DPP only (no LDS traffic):
@@ -819,7 +816,7 @@ __global__ __launch_bounds__(256) void pool_scan_start_kernel(PoolArgs a)
 
 // =====================================================================================
 // Site pooling, uniform bags (every site has the same n <= 32 reads), K = 20.
-// Same arithmetic as pool_scan_kernel; because every site consumes the stream identically,
+// Same arithmetic as the scan kernels; because every site consumes the stream identically,
 // the accepted indices of "the j-th site of a flush group" are the same in every group:
 // tab[j][round][plane][lane] packs, for iteration t = 64*round + lane, byte offsets 8*idx of
 // its 20 draws (5 dwords).
