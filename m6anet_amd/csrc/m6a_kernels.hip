@@ -23,6 +23,7 @@
 #include "m6a_kernels.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // sum over each group of 8 consecutive lanes, in NumPy's pairwise-leaf order
 // ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)); every lane of the group gets it.  DPP only (no LDS traffic):
@@ -269,6 +270,9 @@ __global__ __launch_bounds__(256, 2) void enc_csite_kernel(EncArgs a)
     __shared__ float s_w1e[35 * 32];             // [m*7 + e][col]: W1'[32m+col][9+e] (e<6), b1'[32m+col] (e=6)
     for (int i = threadIdx.x; i < 132; i += 256) s_emb[i] = a.emb[i];
     for (int i = threadIdx.x; i < 35 * 32; i += 256) s_w1e[i] = a.w1e_tab[i];
+    // W3 in the order the layer-2 accumulator holds the 32 units: [half][q] (16 VGPRs the tile loop needs more)
+    __shared__ float s_w3[32];
+    if (threadIdx.x < 64) s_w3[(threadIdx.x >> 5) * 16 + (threadIdx.x & 15)] = a.wfrag[(120 + (threadIdx.x & 15)) * 64 + (threadIdx.x & 32)];
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
@@ -280,15 +284,13 @@ __global__ __launch_bounds__(256, 2) void enc_csite_kernel(EncArgs a)
     const int64_t tile1 = (tile0 + a.tiles_per_wave < a.n_tiles) ? tile0 + a.tiles_per_wave : a.n_tiles;
 
     // static weight fragments: w1x[m*4+st] = W1'[32m+col][2st+half], w8[m] = W1'[32m+col][8]
-    float w1x[20], w8[5], w2[80], w3[16];
+    float w1x[20], w8[5], w2[80];
 #pragma unroll
     for (int i = 0; i < 20; i++) w1x[i] = a.wfrag2[i * 64 + lane];
 #pragma unroll
     for (int i = 0; i < 5; i++) w8[i] = a.wfrag2[(20 + i) * 64 + lane];
 #pragma unroll
     for (int i = 0; i < 80; i++) w2[i] = a.wfrag[(40 + i) * 64 + lane];
-#pragma unroll
-    for (int i = 0; i < 16; i++) w3[i] = a.wfrag[(120 + i) * 64 + lane];
 
     int64_t s_base;
     {
@@ -335,25 +337,33 @@ __global__ __launch_bounds__(256, 2) void enc_csite_kernel(EncArgs a)
     // (x8 is the value loaded for slot 4 on half 0; in place: a4/a5/x[4..5] of the running tile are
     // dead once layer 1 of its last unit tile has issued)
     auto link3 = [&](float ev, int rel, float x8, float (&x)[6], float (&a4)[5], float (&a5)[5]) {
-        float e[18];
+        // lanes 0..17 hold the 18 embedding floats of sites a, a+1, a+2.  A lane needs two c vectors: that
+        // of site a (its step-4 operand when half = 1) and that of site a+1 (half 0) / a+2 (half 1) for step
+        // 5.  The floats come over the LDS crossbar (ds_bpermute: not a VALU instruction, and the VALU
+        // shares its datapath with the f32 MFMAs) straight into (x, y) pairs, so both vectors advance with
+        // one v_pk_fma_f32 per term -- 30 per tile, no register shuffling.
+        const int ebits = __builtin_bit_cast(int, ev);
+        const int lane_b = half ? 48 : 24;                                    // byte address of lane 12 / 6
+        int lane_a;                                                           // 0, but opaque: a constant address
+        asm("v_mov_b32 %0, 0" : "=v"(lane_a));                                // would become v_readlane + v_mov
+        f32x2 e2[6];
 #pragma unroll
-        for (int q = 0; q < 18; q++)
-            e[q] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ev), q));
-        float eP[6];
-#pragma unroll
-        for (int q = 0; q < 6; q++) eP[q] = half ? e[q] : e[6 + q];          // h=1: site a, h=0: site a+1
+        for (int q = 0; q < 6; q++) {
+            e2[q].x = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(lane_a + 4 * q, ebits));
+            e2[q].y = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(lane_b + 4 * q, ebits));
+        }
 #pragma unroll
         for (int m = 0; m < 5; m++) {
             const float *wr = s_w1e + (m * 7) * 32 + col;
-            float cP = wr[6 * 32], cQ = wr[6 * 32];
+            f32x2 c = {wr[6 * 32], wr[6 * 32]};
 #pragma unroll
             for (int q = 0; q < 6; q++) {
                 const float wq = wr[q * 32];
-                cP = fmaf(wq, eP[q], cP);
-                cQ = fmaf(wq, e[12 + q], cQ);                                 // site a+2
+                const f32x2 w2v = {wq, wq};
+                c = __builtin_elementwise_fma(w2v, e2[q], c);
             }
-            a4[m] = half ? cP : w8[m];           // step 4: h=0 x8, h=1 I(a)
-            a5[m] = half ? cQ : cP;              // step 5: h=0 I(a+1), h=1 I(a+2)
+            a4[m] = half ? c.x : w8[m];          // step 4: h=0 x8, h=1 I(a)
+            a5[m] = c.y;                         // step 5: h=0 I(a+1), h=1 I(a+2)
         }
         x[4] = half ? (rel == 0 ? 1.0f : 0.0f) : x8;
         x[5] = (rel == (half ? 2 : 1)) ? 1.0f : 0.0f;
@@ -416,7 +426,7 @@ __global__ __launch_bounds__(256, 2) void enc_csite_kernel(EncArgs a)
         }
         float z = 0.0f;
 #pragma unroll
-        for (int q = 0; q < 16; q++) z = fmaf(relu_bits(acc2[q]), w3[q], z);
+        for (int q = 0; q < 16; q++) z = fmaf(relu_bits(acc2[q]), s_w3[half * 16 + q], z);
         z += __shfl_xor(z, 32, 64);
         z += a.b3;
         const float p = 1.0f / (1.0f + expf(-z));
