@@ -138,17 +138,37 @@ __global__ __launch_bounds__(64) void pool_reg_kernel(PoolArgs a)
         "v_mov_b32 v34, %[b2]\n"
         "v_mov_b32 v35, %[b3]\n"
         "s_sub_u32 s79, %[n], 1\n"
+        // site-major: the 32 loads of one site hit the same one or two cache lines back to back (entry-major
+        // order cycled through 256 lines per wavefront and thrashed the 32 KB L1: 4x the HBM traffic)
         ".set m6a_e, 0\n"
         ".rept 32\n"
         "global_load_dword v[128+2*m6a_e], v32, %[rp]\n"
-        "global_load_dword v[129+2*m6a_e], v33, %[rp]\n"
-        "global_load_dword v[192+2*m6a_e], v34, %[rp]\n"
-        "global_load_dword v[193+2*m6a_e], v35, %[rp]\n"
         "s_cmp_lt_u32 m6a_e, s79\n"
         "s_cselect_b32 s76, 4, 0\n"
         "v_add_u32 v32, s76, v32\n"
+        ".set m6a_e, m6a_e+1\n"
+        ".endr\n"
+        ".set m6a_e, 0\n"
+        ".rept 32\n"
+        "global_load_dword v[129+2*m6a_e], v33, %[rp]\n"
+        "s_cmp_lt_u32 m6a_e, s79\n"
+        "s_cselect_b32 s76, 4, 0\n"
         "v_add_u32 v33, s76, v33\n"
+        ".set m6a_e, m6a_e+1\n"
+        ".endr\n"
+        ".set m6a_e, 0\n"
+        ".rept 32\n"
+        "global_load_dword v[192+2*m6a_e], v34, %[rp]\n"
+        "s_cmp_lt_u32 m6a_e, s79\n"
+        "s_cselect_b32 s76, 4, 0\n"
         "v_add_u32 v34, s76, v34\n"
+        ".set m6a_e, m6a_e+1\n"
+        ".endr\n"
+        ".set m6a_e, 0\n"
+        ".rept 32\n"
+        "global_load_dword v[193+2*m6a_e], v35, %[rp]\n"
+        "s_cmp_lt_u32 m6a_e, s79\n"
+        "s_cselect_b32 s76, 4, 0\n"
         "v_add_u32 v35, s76, v35\n"
         ".set m6a_e, m6a_e+1\n"
         ".endr\n"
