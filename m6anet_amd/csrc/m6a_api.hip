@@ -486,7 +486,10 @@ int launch_encode(m6a_ctx *c, const float *X, const uint8_t *km, const int64_t *
     const unsigned blocks = (unsigned)((waves + 3) / 4);
     // every bag >= 16 reads: a 32-read tile spans <= 3 sites -> 12-slot layer 1 (106 MFMAs per tile);
     // otherwise the general 16-slot kernel (116)
-    const bool csite = c->enc_variant ? c->enc_variant == 2 : c->bag_min >= M6A_CSITE_MIN_BAG;
+    // the 12-slot kernel keeps tile and site indices in 32 bits (wave-uniform SALU arithmetic)
+    const bool fits32 = S < 0x7ffffff0LL && a.n_tiles < 0x7ffffff0LL;
+    if (c->enc_variant == 2 && !fits32) return fail(c, M6A_EUNSUPPORTED, "12-slot encoder: more than 2^31 sites or tiles");
+    const bool csite = c->enc_variant ? c->enc_variant == 2 : (c->bag_min >= M6A_CSITE_MIN_BAG && fits32);
     c->enc_variant_used = csite ? "csite12" : "general16";
     prof_begin(c, 0);
     if (csite) hipLaunchKernelGGL(enc_csite_kernel, dim3(blocks), dim3(256), 0, c->stream, a);

@@ -278,10 +278,16 @@ __global__ __launch_bounds__(256, 2) void enc_csite_kernel(EncArgs a)
     const int lane = threadIdx.x & 63;
     const int col = lane & 31;
     const int half = lane >> 5;
-    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int64_t tile0 = wave * a.tiles_per_wave;
-    if (tile0 >= a.n_tiles) return;
-    const int64_t tile1 = (tile0 + a.tiles_per_wave < a.n_tiles) ? tile0 + a.tiles_per_wave : a.n_tiles;
+    // Tile and site indices are 32-bit here (the host sends jobs beyond 2^31 sites or tiles to enc_kernel)
+    // and wave-uniform: the SALU has 32-bit ordered compares but no 64-bit ones, so 64-bit indices would put
+    // every clamp and loop test on the VALU -- at half rate, on the datapath the MFMAs need.
+    const int wave = (int)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int n_tiles = (int)a.n_tiles, tpw = (int)a.tiles_per_wave;
+    const int tile0 = wave * tpw;
+    if (tile0 >= n_tiles) return;
+    const int tile1 = (tile0 + tpw < n_tiles) ? tile0 + tpw : n_tiles;
+    const int n_sites = (int)a.n_sites;
+    const int last_lim = (int)(a.n_reads - 1 - (int64_t)(n_tiles - 1) * 32);   // last valid column of the last tile
 
     // static weight fragments: w1x[m*4+st] = W1'[32m+col][2st+half], w8[m] = W1'[32m+col][8]
     float w1x[20], w8[5], w2[80];
@@ -292,41 +298,46 @@ __global__ __launch_bounds__(256, 2) void enc_csite_kernel(EncArgs a)
 #pragma unroll
     for (int i = 0; i < 80; i++) w2[i] = a.wfrag[(40 + i) * 64 + lane];
 
-    int64_t s_base;
+    int s_base;
     {
-        const int64_t r = tile0 * 32;
-        int64_t lo = 0, hi = a.n_sites;          // invariant: off[lo] <= r < off[hi]
+        const int64_t r = (int64_t)tile0 * 32;
+        int lo = 0, hi = n_sites;                // invariant: off[lo] <= r < off[hi]
         while (hi - lo > 1) {
-            int64_t mid = (lo + hi) >> 1;
+            const int mid = (int)(((int64_t)lo + hi) >> 1);
             if (a.off[mid] <= r) lo = mid; else hi = mid;
         }
         s_base = lo;
     }
-    const int64_t last_site = a.n_sites - 1;
+    const int last_site = n_sites - 1;
 
     // ---- input chain of one tile ----------------------------------------------------------------
     // link0: the three CSR offsets after the base site -- scalar loads (base is uniform)
-    auto link0 = [&](int64_t base, int64_t (&o)[3]) {
+    auto link0 = [&](int base, int64_t (&o)[3]) {
 #pragma unroll
         for (int i = 0; i < 3; i++) {
-            const int64_t si = base + 1 + i;
-            o[i] = a.off[si <= a.n_sites ? si : a.n_sites];
+            const int si = base + 1 + i;
+            o[i] = a.off[si <= n_sites ? si : n_sites];
         }
     };
     // link1: the lane's site relative to base; lanes 0..17 fetch the k-mer id their embedding
     // float belongs to (float q of site base + q/6 is E[kmer (q%6)/2][q&1]); THEN the x loads
     // (4 per lane, + x8 on half 0) -- vector loads retire in order, the k-mer ids must not queue
     // behind the x stream
-    auto link1 = [&](int64_t tile, int64_t base, const int64_t (&o)[3], int &rel, int &kid, float (&x)[5]) {
-        const int64_t r = tile * 32 + col;
-        const int64_t rc = r < a.n_reads ? r : a.n_reads - 1;
-        rel = (rc >= o[0] ? 1 : 0) + (rc >= o[1] ? 1 : 0);
-        if (__any(rc >= o[2])) atomicExch(a.err, 2);         // would need a 4th site: precondition broken
-        const int q = lane < 18 ? lane : 17;                 // every lane loads a valid byte: no merge
-        int64_t ks = base + q / 6;
-        ks = ks < last_site ? ks : last_site;
-        kid = (int)a.site_kmers[ks * 3 + (q % 6) / 2];
-        const float *xp = a.X + rc * 9 + half;
+    const int kq = lane < 18 ? lane : 17;                    // every lane loads a valid byte: no merge
+    const int kq_site = kq / 6, kq_byte = (kq % 6) / 2;
+    auto link1 = [&](int tile, int base, const int64_t (&o)[3], int &rel, int &kid, float (&x)[5]) {
+        const int64_t rbase = (int64_t)tile * 32;                                 // uniform
+        const int lim = tile == n_tiles - 1 ? last_lim : 31;                      // last valid column of this tile
+        const int crel = col < lim ? col : lim;                                   // the lane's read, clamped into the job
+        // site boundaries relative to the tile: o[i] > rbase (base holds the tile's first read) and a bag is
+        // far smaller than 2^31 reads, so the low words are enough
+        const int d0 = (int)o[0] - (int)rbase, d1 = (int)o[1] - (int)rbase, d2 = (int)o[2] - (int)rbase;
+        rel = (crel >= d0 ? 1 : 0) + (crel >= d1 ? 1 : 0);
+        if (__any(crel >= d2)) atomicExch(a.err, 2);         // would need a 4th site: precondition broken
+        const int room = last_site - base;                                        // sites after the base site
+        const int ksr = kq_site < room ? kq_site : room;
+        kid = (int)(a.site_kmers + (int64_t)base * 3)[ksr * 3 + kq_byte];
+        const float *xp = a.X + rbase * 9 + (crel * 9 + half);
 #pragma unroll
         for (int i = 0; i < 4; i++) x[i] = xp[2 * i];
         x[4] = xp[half ? 6 : 8];                             // x8 on half 0 (half 1: a valid dummy)
@@ -371,7 +382,7 @@ __global__ __launch_bounds__(256, 2) void enc_csite_kernel(EncArgs a)
 
     // prologue: first tile, unpipelined
     float f[6], a4[5], a5[5];
-    s_base = uniform_i64(s_base);
+    s_base = __builtin_amdgcn_readfirstlane(s_base);
     {
         int64_t o[3];
         int rel, kid;
@@ -385,9 +396,9 @@ __global__ __launch_bounds__(256, 2) void enc_csite_kernel(EncArgs a)
         s_base += __builtin_amdgcn_readfirstlane(__shfl(rel, 31, 64));
     }
 
-    for (int64_t tile = tile0; tile < tile1; ++tile) {
+    for (int tile = tile0; tile < tile1; ++tile) {
         // the chain always runs (for the last tile it refetches that tile): no guard, no merge
-        const int64_t tn = tile + 1 < tile1 ? tile + 1 : tile;
+        const int tn = tile + 1 < tile1 ? tile + 1 : tile;
         float fn[5], evn;
         int64_t o[3];
         int reln, kidn;
@@ -430,8 +441,7 @@ __global__ __launch_bounds__(256, 2) void enc_csite_kernel(EncArgs a)
         z += __shfl_xor(z, 32, 64);
         z += a.b3;
         const float p = 1.0f / (1.0f + expf(-z));
-        const int64_t r = tile * 32 + col;
-        if (half == 0 && r < a.n_reads) a.read_prob[r] = p;
+        if (half == 0 && col <= (tile == n_tiles - 1 ? last_lim : 31)) (a.read_prob + (int64_t)tile * 32)[col] = p;
         if (tn != tile) s_base += __builtin_amdgcn_readfirstlane(__shfl(reln, 31, 64));
 #pragma unroll
         for (int i = 0; i < 4; i++) f[i] = fn[i];
