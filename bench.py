@@ -200,8 +200,9 @@ def main():
                          "algorithmic_flop_per_read": ENC_FLOP_PER_READ, "reads_per_launch": R,
                          "hbm_view": {"achieved": enc_gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                                       "frac": enc_gbps / PEAK_HBM_GBPS, "algorithmic_bytes_per_read": ENC_BYTES_PER_READ}},
-            "kernels": {"enc_kernel": {"avg_ms": enc_avg_ms, "launches": enc_n},
-                        "pool_%s_kernel" % eng.last_pool_variant: {
+            "kernels": {{"csite12": "enc_csite_kernel", "general16": "enc_kernel"}.get(eng.last_encoder_variant, "enc_kernel"):
+                            {"avg_ms": enc_avg_ms, "launches": enc_n},
+                        {"table-reg": "pool_reg_kernel", "table": "pool_table_kernel"}.get(eng.last_pool_variant, "pool_scan_kernels"): {
                             "avg_ms": pool_avg_ms, "launches": pool_n,
                             "Gdraws_per_s": Sr * T * 20 / (pool_avg_ms * 1e-3) / 1e9 if pool_avg_ms else None}},
         }
