@@ -337,6 +337,37 @@ def test_pool_uniform_random_configurations(eng, orc):
             assert np.array_equal(mod, want_mod), (n, T, bs, spb, S, seed, name)
 
 
+def test_pool_ragged_random_configurations(eng, orc):
+    """Random ragged jobs (bag sizes from 1 to a few thousand, mixed), iteration counts and batch geometry:
+    both scan drivers against the oracle, bit for bit."""
+    g = np.random.Generator(np.random.PCG64(77))
+    for _ in range(12):
+        S = int(g.integers(2, 120))
+        kind = int(g.integers(0, 3))
+        if kind == 0:
+            bags = g.integers(1, 40, size=S)
+        elif kind == 1:
+            bags = g.integers(20, 700, size=S)
+        else:
+            bags = np.where(g.random(S) < 0.1, g.integers(1000, 3000, size=S), g.integers(20, 64, size=S))
+        bags[int(g.integers(0, S))] += 1                                   # never uniform
+        T = int(g.choice([1, 5, 8, 33, 130, 257, 1000]))
+        bs, spb = int(g.choice([1, 4, 16])), int(g.choice([1, 2, 3]))
+        seed = int(g.integers(0, 2 ** 32))
+        off = np.concatenate([[0], np.cumsum(bags)]).astype(np.int64)
+        p = rand_probs(seed % 997, off)
+        want_site, want_mod = orc.site_pool(p, off, T, THR, seed=seed, batch_size=bs, save_per_batch=spb, n_threads=8)
+        try:
+            for driver in (1, 2):
+                eng.set_scan_driver(driver)
+                site, mod = eng.calculate_site_proba(p, off, T, 20, THR, seed=seed, batch_size=bs, save_per_batch=spb)
+                assert eng.last_pool_variant.startswith("scan")
+                assert same_sites(site, want_site), (S, kind, T, bs, spb, seed, driver)
+                assert np.array_equal(mod, want_mod), (S, kind, T, bs, spb, seed, driver)
+        finally:
+            eng.set_scan_driver(0)
+
+
 def test_pool_seeds_differ_and_repeat(eng):
     off = np.arange(101, dtype=np.int64) * 20
     p = rand_probs(1, off)
