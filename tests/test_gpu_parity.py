@@ -288,11 +288,12 @@ def test_pool_group_geometry(eng, orc, bs, spb):
         assert same_sites(site, want_site), (bs, spb, n, mode)
 
 
-@pytest.mark.parametrize("T", [1024, 1025, 1500, 3000, 10000])
+@pytest.mark.parametrize("T", [1024, 1025, 1500, 3000, 10000, 16385, 40003])
 def test_pool_long_iterations(eng, orc, T):
     """num_iterations beyond one 16-round LDS chunk of the index row (table kernel, T > 1024) and
-    long replays in the scan kernels; 10000 is what the reference's own test uses."""
-    S = 70 if T < 10000 else 40
+    long replays in the scan kernels; 10000 is what the reference's own test uses.  Beyond 16384 the
+    pairwise-sum tree is deeper than the register kernel's 8-entry stack: it must hand over to the LDS kernel."""
+    S = 70 if T < 10000 else 40 if T < 16000 else 10
     for bags, mode, variant in (([20] * S, 1, "table"), ([20] * S, 2, "table"), ([20, 27, 33, 64, 100] * (S // 5), 0, "scan")):
         off = np.concatenate([[0], np.cumsum(bags)]).astype(np.int64)
         p = rand_probs(T, off)
