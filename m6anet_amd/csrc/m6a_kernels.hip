@@ -508,6 +508,9 @@ __device__ __forceinline__ bool scan_site(const PoolArgs &a, int64_t s, uint32_t
                                           int lane, int K)
 {
     float *stack = ring + (64 * K) * 5 / 4 + 32; // merge stack of the pairwise sum when it outgrows the registers
+    // the stream position is wave-uniform (every lane read the same start): say so, and the block loop, its
+    // bounds checks and the stream addresses run on the SALU instead of as an exec-masked 64-bit VALU loop
+    pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos);
     const int bag_cap = a.bag_cap;
     const int CH = 32 * K;                       // slots per window
     const int A = a.T * K;                       // accepted draws per site
@@ -730,7 +733,7 @@ __global__ __launch_bounds__(256) void pool_scan_group_kernel(PoolArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int K = KT ? KT : a.K;
-    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     float *bag = smem + wib * scan_wave_floats(a.bag_cap, K);
     float *ring = bag + a.bag_cap;
     const int64_t n_waves = (int64_t)gridDim.x * 4;
@@ -747,7 +750,7 @@ __global__ __launch_bounds__(256) void pool_scan_site_kernel(PoolArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int K = KT ? KT : a.K;
-    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     float *bag = smem + wib * scan_wave_floats(a.bag_cap, K);
     float *ring = bag + a.bag_cap;
     const int64_t n_waves = (int64_t)gridDim.x * 4;
@@ -773,7 +776,9 @@ __global__ __launch_bounds__(256) void pool_scan_start_kernel(PoolArgs a)
     const int A = a.T * a.K;
     const uint32_t STEP = 64 * M6A_SCAN_A_LOADS;
     const int64_t n_waves = (int64_t)gridDim.x * 4;
-    for (int64_t g = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); g < a.n_groups; g += n_waves) {
+    // group, site, position and the running totals are wave-uniform: kept scalar so the loops and bounds checks
+    // run on the SALU
+    for (int64_t g = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); g < a.n_groups; g += n_waves) {
         uint32_t pos = 0;
         const int64_t s_end = a.goff[g + 1];
         for (int64_t s = a.goff[g]; s < s_end; ++s) {
@@ -800,8 +805,8 @@ __global__ __launch_bounds__(256) void pool_scan_start_kernel(PoolArgs a)
                 if (scanned < (uint32_t)A) {             // uniform: cannot be the last step yet
                     carry += cl;
                 } else {
-                    if (scanned - STEP < (uint32_t)A) { acc += wave_sum_i32(carry); carry = 0; }   // first total
-                    const int tot = wave_sum_i32(cl);
+                    if (scanned - STEP < (uint32_t)A) { acc += __builtin_amdgcn_readfirstlane(wave_sum_i32(carry)); carry = 0; }   // first total
+                    const int tot = __builtin_amdgcn_readfirstlane(wave_sum_i32(cl));
                     if (acc + tot >= A) {
                         // the site's last accepted draw is in this step: walk its loads in stream order
                         // (fully unrolled so w[] stays in registers; the early exit is a flag, not a break)
