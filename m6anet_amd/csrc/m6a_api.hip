@@ -558,7 +558,11 @@ int launch_pool(m6a_ctx *c, const float *rp, const int64_t *off, int64_t S, int 
         HIPCHK(c, c->start_pos.ensure((size_t)S * sizeof(uint32_t)));
         a.start_pos = (uint32_t *)c->start_pos.p;
         // LDS bag sized to the largest bag of this call (bags beyond M6A_BAG_LDS gather from global)
-        a.bag_cap = (int)std::min<int64_t>(M6A_BAG_LDS, std::max<int64_t>(64, (nmax + 63) / 64 * 64));
+        // a power of two: a masked stream word (< 2^ceil(log2 n)) is then always a valid LDS bag index, so the
+        // fast path gathers without clamping
+        int64_t cap = 64;
+        while (cap < nmax && cap < M6A_BAG_LDS) cap *= 2;
+        a.bag_cap = (int)cap;
         const size_t lds = (size_t)4 * (a.bag_cap + (64 * K) * 5 / 4 + 32 + M6A_MEAN_STACK) * sizeof(float);
         const int64_t wg_per_cu = std::max<int64_t>(1, std::min<int64_t>(8, (160 * 1024) / (int64_t)lds));
         const int64_t wave_slots = (int64_t)c->n_cu * wg_per_cu * 4;

@@ -613,7 +613,7 @@ __device__ __forceinline__ bool scan_site(const PoolArgs &a, int64_t s, uint32_t
     if ((uint64_t)pos + 512 > (uint64_t)a.raw_len) { if (lane == 0) atomicExch(a.err, 1); return false; }
     uint32_t w[4], wn[4];
 #pragma unroll
-    for (int i = 0; i < 4; i++) w[i] = a.raw[pos + 64 * i + lane];
+    for (int i = 0; i < 4; i++) w[i] = (a.raw + pos)[64 * i + lane];            // scalar base + lane offset
 
     // one accepted word -> ring: gather 1-p, store at slot base+rank (two-window ring, wrapped)
     auto put = [&](uint32_t v, int base_plus_rank) {
@@ -655,13 +655,13 @@ __device__ __forceinline__ bool scan_site(const PoolArgs &a, int64_t s, uint32_t
             const int cb = c[0] + c[1] + c[2] + c[3];
             if (acc + cb >= A) break;            // the site's last draw is in this block: exact tail below
 #pragma unroll
-            for (int i = 0; i < 4; i++) wn[i] = a.raw[pos + 256 + 64 * i + lane];   // next block in flight
+            for (int i = 0; i < 4; i++) wn[i] = (a.raw + pos)[256 + 64 * i + lane];   // next block in flight
             int base = wbase + cnt;
             float val[4];
             int addr[4];
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                val[i] = bag[min(v[i], rng)];
+                val[i] = bag[v[i]];              // v <= mask < bag_cap (a power of two >= the largest bag): in bounds unclamped
                 const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal[i] >> 32),
                                  __builtin_amdgcn_mbcnt_lo((uint32_t)bal[i], 0));
                 uint32_t slot = (uint32_t)(base + rank);
@@ -708,7 +708,7 @@ __device__ __forceinline__ bool scan_site(const PoolArgs &a, int64_t s, uint32_t
         if (!done) {
             pos += 256;
 #pragma unroll
-            for (int i = 0; i < 4; i++) w[i] = a.raw[pos + 64 * i + lane];
+            for (int i = 0; i < 4; i++) w[i] = (a.raw + pos)[64 * i + lane];            // scalar base + lane offset
         }
     }
     wave_lds_fence();
@@ -790,14 +790,14 @@ __global__ __launch_bounds__(256) void pool_scan_start_kernel(PoolArgs a)
             if ((uint64_t)pos + 2 * STEP > (uint64_t)a.raw_len) { if (lane == 0) atomicExch(a.err, 1); return; }
             uint32_t w[M6A_SCAN_A_LOADS], wn[M6A_SCAN_A_LOADS];
 #pragma unroll
-            for (int i = 0; i < M6A_SCAN_A_LOADS; i++) w[i] = a.raw[pos + 64 * i + lane];
+            for (int i = 0; i < M6A_SCAN_A_LOADS; i++) w[i] = (a.raw + pos)[64 * i + lane];
             int acc = 0;             // wave total of accepted words in steps already folded in
             int carry = 0;           // per-lane count of steps not folded in yet
             uint32_t scanned = 0;
             for (;;) {
                 if ((uint64_t)pos + 2 * STEP > (uint64_t)a.raw_len) { if (lane == 0) atomicExch(a.err, 1); return; }
 #pragma unroll
-                for (int i = 0; i < M6A_SCAN_A_LOADS; i++) wn[i] = a.raw[pos + STEP + 64 * i + lane];
+                for (int i = 0; i < M6A_SCAN_A_LOADS; i++) wn[i] = (a.raw + pos)[STEP + 64 * i + lane];
                 int cl = 0;
 #pragma unroll
                 for (int i = 0; i < M6A_SCAN_A_LOADS; i++) cl += ((w[i] & mask) <= rng) ? 1 : 0;
