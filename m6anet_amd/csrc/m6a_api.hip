@@ -563,8 +563,10 @@ int launch_pool(m6a_ctx *c, const float *rp, const int64_t *off, int64_t S, int 
         int64_t cap = 64;
         while (cap < nmax && cap < M6A_BAG_LDS) cap *= 2;
         a.bag_cap = (int)cap;
-        const size_t lds = (size_t)4 * (a.bag_cap + (64 * K) * 5 / 4 + 32 + M6A_MEAN_STACK) * sizeof(float);
-        const int64_t wg_per_cu = std::max<int64_t>(1, std::min<int64_t>(8, (160 * 1024) / (int64_t)lds));
+        const size_t lds = (size_t)4 * (a.bag_cap + (32 * K + 256) * 5 / 4 + 32 + M6A_MEAN_STACK) * sizeof(float);
+        // resident workgroups per CU: what LDS allows, but with big bags (random gathers over >= 1 KB per wave) five
+        // measured best -- 4.19 ms against 4.6 ms at six on the 50..500-read shape; small bags keep gaining up to 6-8
+        const int64_t wg_per_cu = std::max<int64_t>(1, std::min<int64_t>(a.bag_cap >= 256 ? 5 : 8, (160 * 1024) / (int64_t)lds));
         const int64_t wave_slots = (int64_t)c->n_cu * wg_per_cu * 4;
         // enough flush groups to fill the chip several times over: walk each group's sites in
         // sequence (the stream is scanned once); otherwise buy 32x the parallelism with a counting

@@ -507,7 +507,7 @@ template <int KT>
 __device__ __forceinline__ bool scan_site(const PoolArgs &a, int64_t s, uint32_t &pos, float *bag, float *ring,
                                           int lane, int K)
 {
-    float *stack = ring + (64 * K) * 5 / 4 + 32; // merge stack of the pairwise sum when it outgrows the registers
+    float *stack = ring + (32 * K + 256) * 5 / 4 + 32;   // merge stack of the pairwise sum (lane 0)
     // the stream position is wave-uniform (every lane read the same start): say so, and the block loop, its
     // bounds checks and the stream addresses run on the SALU instead of as an exec-masked 64-bit VALU loop
     pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos);
@@ -554,7 +554,7 @@ __device__ __forceinline__ bool scan_site(const PoolArgs &a, int64_t s, uint32_t
     }
     const uint32_t mask = pow2_mask(rng);
     const bool in_lds = n <= bag_cap;            // wave-uniform: no per-lane test on the fast path
-    int acc = 0, cnt = 0, wbase = 0;
+    int acc = 0, cnt = 0;
     // mean over iterations = NumPy's pairwise sum (see MeanPlan in m6a_api.hip).  A window hands over
     // 32 consecutive iterations in lanes 0..31; leaf starts are multiples of 8, so each group of 8 lanes is
     // one round of the current leaf's 8 accumulator chains: lanes 0..7 carry the chains (`chain`), groups are
@@ -615,31 +615,40 @@ __device__ __forceinline__ bool scan_site(const PoolArgs &a, int64_t s, uint32_t
 #pragma unroll
     for (int i = 0; i < 4; i++) w[i] = (a.raw + pos)[64 * i + lane];            // scalar base + lane offset
 
-    // one accepted word -> ring: gather 1-p, store at slot base+rank (two-window ring, wrapped)
-    auto put = [&](uint32_t v, int base_plus_rank) {
+    // one accepted word -> window buffer: gather 1-p, store at slot cnt+rank
+    auto put = [&](uint32_t v, int slot) {
         float val;
         if (in_lds) val = bag[v];
         else val = v < (uint32_t)bag_cap ? bag[v] : 1.0f - a.read_prob[r0 + v];
-        uint32_t slot = (uint32_t)base_plus_rank;                    // < 2*CH + 256
-        slot = min(slot, slot - (uint32_t)(2 * CH));                 // wrap
-        ring[ring_addr((int)slot)] = val;
+        ring[ring_addr(slot)] = val;
     };
+    // The buffer is ONE window (CH slots) plus room for the draws that arrive before the window check
+    // (<= 255 per 256-word block).  Closing the window multiplies it out and moves that overhang down to slot
+    // 0 -- CH is a multiple of 4, so the overhang is one contiguous run of dwords: five reads and five writes
+    // per lane, instead of a wrap-around test on every stored draw.
     auto close_window = [&]() {
         wave_lds_fence();
         float v = 0.0f;
-        if (lane < 32) v = 1.0f - window_product<KT>(ring, wbase, lane, K);
-        wbase = CH - wbase;                      // other window
+        if (lane < 32) v = 1.0f - window_product<KT>(ring, 0, lane, K);
+        const int ov_dw = ring_addr(cnt - CH);   // dwords of the overhang (<= 319)
+        const float *src = ring + ring_addr(CH);
+        float mv[5];
+#pragma unroll
+        for (int j = 0; j < 5; j++) mv[j] = src[lane + 64 * j];              // inside the buffer's slack
+        wave_lds_fence();
+#pragma unroll
+        for (int j = 0; j < 5; j++)
+            if (lane + 64 * j < ov_dw) ring[lane + 64 * j] = mv[j];
         cnt -= CH;
         wave_lds_fence();
         feed(v, 32);
     };
 
-    // ---- whole 256-word blocks, branch-free inside: the gather index is clamped so every lane
-    // may gather, rejected lanes store to a trash slot (one v_cndmask instead of a branch), all
-    // four gathers are in flight together, one window check per block (the ring absorbs the
-    // <= 255 overflow slots as long as CH >= 256, i.e. K >= 8).  Bags beyond the LDS bag take
-    // the tail path.
-    const int trash = ring_addr(2 * CH) + 1;
+    // ---- whole 256-word blocks, branch-free inside: every lane gathers (a masked word is a valid bag index),
+    // rejected lanes store to a trash slot (one v_cndmask instead of a branch), the slot is cnt + rank with cnt
+    // folded into the mbcnt accumulator, all four gathers are in flight together, one window check per block
+    // (needs CH >= 256, i.e. K >= 8).  Bags beyond the LDS bag take the tail path.
+    const int trash = ring_addr(CH + 256) + 1;
     if (K >= 8 && in_lds) {
         for (;;) {
             if ((uint64_t)pos + 512 > (uint64_t)a.raw_len) { if (lane == 0) atomicExch(a.err, 1); return false; }
@@ -656,17 +665,15 @@ __device__ __forceinline__ bool scan_site(const PoolArgs &a, int64_t s, uint32_t
             if (acc + cb >= A) break;            // the site's last draw is in this block: exact tail below
 #pragma unroll
             for (int i = 0; i < 4; i++) wn[i] = (a.raw + pos)[256 + 64 * i + lane];   // next block in flight
-            int base = wbase + cnt;
+            int base = cnt;
             float val[4];
             int addr[4];
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 val[i] = bag[v[i]];              // v <= mask < bag_cap (a power of two >= the largest bag): in bounds unclamped
-                const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal[i] >> 32),
-                                 __builtin_amdgcn_mbcnt_lo((uint32_t)bal[i], 0));
-                uint32_t slot = (uint32_t)(base + rank);
-                slot = min(slot, slot - (uint32_t)(2 * CH));
-                addr[i] = v[i] <= rng ? ring_addr((int)slot) : trash;
+                const int slot = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal[i] >> 32),
+                                 __builtin_amdgcn_mbcnt_lo((uint32_t)bal[i], (uint32_t)base));
+                addr[i] = v[i] <= rng ? ring_addr(slot) : trash;
                 base += c[i];
             }
 #pragma unroll
@@ -700,10 +707,10 @@ __device__ __forceinline__ bool scan_site(const PoolArgs &a, int64_t s, uint32_t
                 c = remaining;
                 done = true;
             }
-            if (ok) put(v, wbase + cnt + rank);
+            if (ok) put(v, cnt + rank);
             cnt += c;
             acc += c;
-            if (cnt >= CH) close_window();
+            while (cnt >= CH) close_window();  // K = 1: a 64-word step can fill two windows
         }
         if (!done) {
             pos += 256;
@@ -715,7 +722,7 @@ __device__ __forceinline__ bool scan_site(const PoolArgs &a, int64_t s, uint32_t
     const int t_rem = cnt / K;                   // iterations left in the current window (< 32)
     {
         float v = 0.0f;
-        if (lane < t_rem) v = 1.0f - window_product<KT>(ring, wbase, lane, K);
+        if (lane < t_rem) v = 1.0f - window_product<KT>(ring, 0, lane, K);
         feed(v, t_rem);                          // it_base == T now
         if (leaf < a.n_leaves) leaf_done(chain8_sum(chain));
     }
@@ -724,9 +731,9 @@ __device__ __forceinline__ bool scan_site(const PoolArgs &a, int64_t s, uint32_t
     return true;
 }
 
-// LDS per wavefront: the bag, the ring (2 windows of 32*K slots at 5/4 dwords per slot, + trash) and the
-// pairwise-sum stack for very long T
-__device__ __forceinline__ int scan_wave_floats(int bag_cap, int K) { return bag_cap + (64 * K) * 5 / 4 + 32 + M6A_MEAN_STACK; }
+// LDS per wavefront: the bag, the window buffer (32*K slots + 256 of overhang at 5/4 dwords per slot, + trash)
+// and the pairwise-sum stack
+__device__ __forceinline__ int scan_wave_floats(int bag_cap, int K) { return bag_cap + (32 * K + 256) * 5 / 4 + 32 + M6A_MEAN_STACK; }
 
 template <int KT>
 __global__ __launch_bounds__(256) void pool_scan_group_kernel(PoolArgs a)
