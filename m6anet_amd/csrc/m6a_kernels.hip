@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256, 2) void enc_kernel(EncArgs a)
     const int lane = threadIdx.x & 63;
     const int col = lane & 31;
     const int half = lane >> 5;
-    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t wave = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // scalar tile loop
     const int64_t tile0 = wave * a.tiles_per_wave;
     if (tile0 >= a.n_tiles) return;
     const int64_t tile1 = (tile0 + a.tiles_per_wave < a.n_tiles) ? tile0 + a.tiles_per_wave : a.n_tiles;
