@@ -595,6 +595,41 @@ def test_full_size_properties(eng, orc, weights):
     assert site[-1] > 0
 
 
+def test_beyond_4GiB_of_features(eng, orc, weights):
+    """A job whose feature array crosses 2^32 bytes (3.4 M sites x 37 reads = 126 M reads, 4.5 GB of X): every
+    byte offset on the path must be 64-bit (the 12-slot encoder and the register pooling kernel keep 32-bit tile /
+    site indices and lane offsets only).  Random flush groups, including the last ones, against the oracle."""
+    import torch
+    S, n, T = 3_400_000, 37, 6
+    g = np.random.Generator(np.random.PCG64(5))
+    X = g.standard_normal((S * n, 9), dtype=np.float32)
+    np.clip(X, -6, 6, out=X)
+    km = g.integers(0, 66, size=(S, 3)).astype(np.uint8)
+    off = np.arange(S + 1, dtype=np.int64) * n
+    assert X.nbytes > 2 ** 32
+    dev = torch.device("cuda:0")
+    tX, tk, to = torch.from_numpy(X).to(dev), torch.from_numpy(km).to(dev), torch.from_numpy(off).to(dev)
+    eng.use_torch_stream()
+    try:
+        rp, site, mod = eng.infer(tX, tk, to, T)
+        eng.sync()
+    finally:
+        eng.set_stream(None)
+    assert eng.last_encoder_variant == "csite12" and eng.last_pool_variant.startswith("scan")   # n = 37 > 32
+    rp, site, mod = rp.cpu().numpy(), site.cpu().numpy(), mod.cpu().numpy()
+    del tX
+    n_groups = (S - 16) // 32
+    for grp in [0, 1, n_groups - 1, n_groups] + list(g.integers(2, n_groups - 1, size=12)):
+        a = 0 if grp == 0 else 16 + 32 * (grp - 1)
+        b = min(S, 16 if grp == 0 else 16 + 32 * grp)
+        sl = slice(a * n, b * n)
+        p = orc.encode_reads(weights["hct116"], X[sl], km[a:b], off[a:b + 1] - a * n)
+        assert np.allclose(rp[sl], p, rtol=1e-5, atol=1e-8), grp
+        w_site, w_mod = orc.site_pool(rp[sl], off[a:b + 1] - a * n, T, THR, batch_size=b - a, save_per_batch=2)
+        assert same_sites(site[a:b], w_site), grp
+        assert np.array_equal(mod[a:b], w_mod), grp
+
+
 # ------------------------------------------------------------------ CLI, config #1 --------------
 def _run_cli(tmp_path, extra):
     import os
