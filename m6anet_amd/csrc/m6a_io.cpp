@@ -832,7 +832,7 @@ extern "C" int m6a_io_dataprep(const char *eventalign_path, const char *out_dir,
         for (const auto &r : o.recs)
             fprintf(fi, "%s,%lld,%lld,%lld,%lld\n", tx_order[(size_t)t].c_str(), r[0], off + r[1], off + r[1] + r[2], r[3]);
         off += (long long)o.json.size();
-        if (!o.recs.empty() || !o.json.empty() || true) fprintf(fl, "%s: Data preparation ... Done.\n", tx_order[(size_t)t].c_str());
+        fprintf(fl, "%s: Data preparation ... Done.\n", tx_order[(size_t)t].c_str());   // every processed transcript is logged
     }
     int bad = 0;
     bad |= fclose(fj); bad |= fclose(fi); bad |= fclose(fl);
