@@ -568,10 +568,11 @@ int launch_pool(m6a_ctx *c, const float *rp, const int64_t *off, int64_t S, int 
         // measured best -- 4.19 ms against 4.6 ms at six on the 50..500-read shape; small bags keep gaining up to 6-8
         const int64_t wg_per_cu = std::max<int64_t>(1, std::min<int64_t>(a.bag_cap >= 256 ? 5 : 8, (160 * 1024) / (int64_t)lds));
         const int64_t wave_slots = (int64_t)c->n_cu * wg_per_cu * 4;
-        // enough flush groups to fill the chip several times over: walk each group's sites in
-        // sequence (the stream is scanned once); otherwise buy 32x the parallelism with a counting
-        // pass that finds every site's start position first
-        const bool by_group = c->scan_driver ? c->scan_driver == 1 : a.n_groups >= 3 * wave_slots;
+        // enough flush groups to fill most of the chip: walk each group's sites in sequence (the stream is
+        // scanned once); otherwise buy 32x the parallelism with a counting pass that finds every site's start
+        // position first.  Measured on 50..500-read bags: at 0.3 x the wave slots the per-site driver wins
+        // (1.3 vs 1.9 ms), at 0.6 x they tie, at 1.2 x the per-group driver is 11 % ahead, at 5 x 22 %.
+        const bool by_group = c->scan_driver ? c->scan_driver == 1 : a.n_groups * 5 >= wave_slots * 3;
         c->pool_variant = by_group ? "scan-group" : "scan-site";
         prof_begin(c, 1);
         if (by_group) {
