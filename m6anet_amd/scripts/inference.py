@@ -63,7 +63,18 @@ def main(args):
         args.read_proba_threshold = PRETRAINED_CONFIGS[args.pretrained_model][1]
         args.norm_path = PRETRAINED_CONFIGS[args.pretrained_model][2]
 
-    engine = M6ANetEngine(weights=weights, device=_device_index(args.device))
+    # the GPU context (HIP initialisation, weights) comes up on a thread while the loader parses data.json
+    import threading
+    made = {}
+
+    def make_engine():
+        try:
+            made["engine"] = M6ANetEngine(weights=weights, device=_device_index(args.device))
+        except BaseException as exc:        # re-raised on the main thread below
+            made["error"] = exc
+
+    starter = threading.Thread(target=make_engine)
+    starter.start()
     pathlib.Path(args.out_dir).mkdir(parents=True, exist_ok=True)
     with open(os.path.join(args.out_dir, "data.site_proba.csv"), "w", encoding="utf-8") as f:
         f.write(SITE_HEADER)
@@ -74,5 +85,9 @@ def main(args):
         batch = load_sites_native(args.input_dir, DEFAULT_MIN_READS, args.norm_path, n_threads=args.n_processes)
     except ImportError:
         batch = load_sites(args.input_dir, DEFAULT_MIN_READS, args.norm_path)   # libm6a_io.so not built
+    starter.join()
+    if "error" in made:
+        raise made["error"]
+    engine = made["engine"]
     run_inference(engine, batch, args)
     engine.close()
