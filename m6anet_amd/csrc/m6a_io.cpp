@@ -21,6 +21,7 @@
 #include <mutex>
 #include <set>
 #include <string>
+#include <memory>
 #include <thread>
 #include <unordered_map>
 #include <vector>
@@ -92,8 +93,9 @@ struct SiteRef {
     std::vector<Part> parts;
 };
 
+// `index` = nullptr for a single directory: every row is a new site, no union over replicates to build
 int parse_info(const std::string &dir, int rep, std::vector<SiteRef> &sites,
-               std::unordered_map<std::string, size_t> &index)
+               std::unordered_map<std::string, size_t> *index)
 {
     const std::string path = dir + "/data.info";
     FILE *f = fopen(path.c_str(), "r");
@@ -118,15 +120,20 @@ int parse_info(const std::string &dir, int rep, std::vector<SiteRef> &sites,
             rc = fail(M6A_IO_EFORMAT, "%s: bad row '%s'", path.c_str(), line);
             break;
         }
-        const std::string key = tx + ":" + std::to_string(pos);
-        auto it = index.find(key);
         size_t i;
-        if (it == index.end()) {
+        if (!index) {
             i = sites.size();
-            index.emplace(key, i);
             sites.push_back(SiteRef{tx, pos, 0, {}});
         } else {
-            i = it->second;
+            const std::string key = tx + ":" + std::to_string(pos);
+            auto it = index->find(key);
+            if (it == index->end()) {
+                i = sites.size();
+                index->emplace(key, i);
+                sites.push_back(SiteRef{tx, pos, 0, {}});
+            } else {
+                i = it->second;
+            }
         }
         sites[i].n_reads += n;
         sites[i].parts.push_back(Part{rep, start, end});
@@ -200,13 +207,25 @@ struct Cursor {
 
 }  // namespace
 
+// a big per-read array, allocated WITHOUT a zero-filling pass: the loader's worker threads write every
+// element, so the first touch (page faults included) happens in parallel
+template <class T>
+struct RawBuf {
+    std::unique_ptr<T[]> p;
+    size_t n = 0;
+    void resize(size_t k) { p.reset(new T[k]); n = k; }
+    T *data() const { return p.get(); }
+    size_t size() const { return n; }
+    T &operator[](size_t i) const { return p[i]; }
+};
+
 struct m6a_sites {
     int n_rep = 1;
-    std::vector<float> X;
+    RawBuf<float> X;
     std::vector<uint8_t> site_kmers;
     std::vector<int64_t> off, tx_pos;
-    std::vector<double> read_ids;
-    std::vector<int32_t> read_rep;
+    RawBuf<double> read_ids;
+    RawBuf<int32_t> read_rep;
     std::vector<std::string> tx_ids, kmer5;
 };
 
@@ -287,11 +306,21 @@ int m6a_io_load_sites(const char *const *input_dirs, int n_dirs, int min_reads, 
     std::vector<SiteRef> all;
     std::unordered_map<std::string, size_t> index;
     std::vector<Mapped> json((size_t)n_dirs);
-    for (int r = 0; r < n_dirs; r++) {
-        int rc = parse_info(input_dirs[r], r, all, index);
+    {
+        // map (and pre-fault) the data.json files on a thread while the data.info files are parsed here
+        int map_rc = 0;
+        std::string map_err;
+        std::thread mapper([&] {
+            for (int r = 0; r < n_dirs && !map_rc; r++) {
+                map_rc = json[(size_t)r].open(std::string(input_dirs[r]) + "/data.json");
+                if (map_rc) map_err = g_err;                       // g_err is thread-local
+            }
+        });
+        int rc = 0;
+        for (int r = 0; r < n_dirs && !rc; r++) rc = parse_info(input_dirs[r], r, all, n_dirs > 1 ? &index : nullptr);
+        mapper.join();
         if (rc) return rc;
-        rc = json[(size_t)r].open(std::string(input_dirs[r]) + "/data.json");
-        if (rc) return rc;
+        if (map_rc) { g_err = map_err; return map_rc; }
     }
     std::vector<SiteRef> sites;
     for (auto &s : all) if (s.n_reads >= min_reads) sites.push_back(std::move(s));

@@ -29,8 +29,9 @@ def load_norm_factors(path):
     if not os.path.exists(path) and os.path.exists(asset_path(path)):
         path = asset_path(path)
     if path.endswith(".npz"):
-        z = np.load(path, allow_pickle=False)
-        return {str(k): (z["mean"][i], z["std"][i]) for i, k in enumerate(z["kmers"])}
+        with np.load(path, allow_pickle=False) as z:
+            kmers, mean, std = z["kmers"], z["mean"], z["std"]     # one read each (an NpzFile re-reads a member per access)
+        return {str(k): (mean[i], std[i]) for i, k in enumerate(kmers)}
     import joblib
     d = joblib.load(path)
     return {k: (np.asarray(v[0], np.float64), np.asarray(v[1], np.float64)) for k, v in d.items()}
