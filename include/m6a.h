@@ -85,7 +85,8 @@ int m6a_encode_reads(m6a_ctx *ctx, const float *X, const uint8_t *site_kmers, co
  * from `seed` at every flush group (groups follow batch_size/save_per_batch exactly as the
  * loop at inference_utils.py:33,47 forms them -- see m6a_flush_groups), sites inside a group
  * consume it sequentially, indices come from masked rejection, the 20-term product is float32
- * left-to-right, the mean over iterations float32.
+ * left-to-right, the mean over iterations is NumPy's float32 pairwise sum and one divide -- given the
+ * same read probabilities the site probabilities are bit-identical to the reference's.
  *   site_prob [S] float32 out;  mod_ratio [S] float64 out = mean(read_prob >= thr)
  *   n_samples <= M6A_MAX_SAMPLES (the reference passes 20, inference_utils.py:54). */
 int m6a_site_pool(m6a_ctx *ctx, const float *read_prob, const int64_t *off, int64_t n_sites,
