@@ -391,6 +391,22 @@ def test_bad_arguments(eng):
         eng.calculate_site_proba(p, off, 10, batch_size=0)
     with pytest.raises(M6AError):
         eng.calculate_site_proba(p, np.array([0, 30, 20], np.int64), 10)
+    for knob in (eng.set_table_variant, eng.set_scan_driver, eng.set_encoder_variant):
+        with pytest.raises(M6AError):
+            knob(7)
+        with pytest.raises(M6AError):
+            knob(-1)
+    with pytest.raises(M6AError):
+        eng.validate_pool(p, off, 0)
+    # the 12-slot encoder forced onto bags it cannot take: reported at the next sync, not a wrong answer
+    d = synthetic.make_sites(50, 5, seed=3)
+    eng.set_encoder_variant(2)
+    try:
+        with pytest.raises(M6AError):
+            eng.get_read_probability(d["X"], d["site_kmers"], d["off"])
+    finally:
+        eng.set_encoder_variant(0)
+    assert np.all(np.isfinite(eng.get_read_probability(d["X"], d["site_kmers"], d["off"])))
 
 
 # ------------------------------------------------------------------ end to end -----------------
