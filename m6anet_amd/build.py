@@ -25,7 +25,7 @@ def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     # -ffp-contract=off: the pooling arithmetic must round where NumPy rounds (a fused 1 - a*b would
     # not); the encoder's FMAs are explicit fmaf()
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-Wall", "-Wextra", "-fPIC", "-shared",
            "-I" + INCLUDE, "-I" + CSRC] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)

@@ -896,7 +896,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
 
     if (n_chunks == 1) {
         for (int i = threadIdx.x; i < rows * 5 * 64; i += 256) s_idx[i] = row[i];
-        if (threadIdx.x < rows * 4) s_meta[threadIdx.x] = a.row_meta[threadIdx.x];
+        if ((int)threadIdx.x < rows * 4) s_meta[threadIdx.x] = a.row_meta[threadIdx.x];
         __syncthreads();
     }
     for (int64_t it = 0; it < n_iter; ++it) {
@@ -936,7 +936,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
             if (n_chunks > 1) {
                 __syncthreads();
                 for (int i = threadIdx.x; i < nr * 5 * 64; i += 256) s_idx[i] = row[rd0 * 5 * 64 + i];
-                if (threadIdx.x < nr * 4) s_meta[threadIdx.x] = a.row_meta[rd0 * 4 + threadIdx.x];
+                if ((int)threadIdx.x < nr * 4) s_meta[threadIdx.x] = a.row_meta[rd0 * 4 + threadIdx.x];
                 __syncthreads();
             }
             if (!active) continue;
