@@ -9,8 +9,6 @@ Tolerances:
     oracle replays MT19937 + masked rejection + sequential float32 product + NumPy pairwise
     mean; with the oracle's own read probabilities: 1e-6 abs.
 """
-import gzip
-import io
 import os
 
 import numpy as np

@@ -18,8 +18,7 @@ def main():
         size = measure_io.replicate(n, d)
         out = os.path.join(d, "out")
         from m6anet_amd.__main__ import main as cli
-        from m6anet_amd import data_utils, engine, inference_utils
-        import types
+        from m6anet_amd import data_utils, engine
         t0 = time.perf_counter()
         cli(["inference", "--input_dir", d, "--out_dir", out, "--num_iterations", "1000", "--n_processes", "0"])
         wall = time.perf_counter() - t0
