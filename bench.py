@@ -79,8 +79,8 @@ def cpu_baseline(d, T, thr, weights, budget_s=15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--sites", type=int, default=1_000_000, help="sites per GPU")
     ap.add_argument("--reads", type=int, default=20, help="reads per site")
     ap.add_argument("--iters", type=int, default=1000, help="num_iterations")
