@@ -1,19 +1,32 @@
 #!/usr/bin/env python3
 """bench.py -- DRACH sites/s of the m6A inference hot path on MI355X.
 
-Workload (BASELINE.json configs[2], the config the metric is quoted on): per GPU 1,000,000
-synthetic DRACH sites x 20 reads, HCT116_RNA002 weights, num_iterations=1000, exact
-NumPy-stream replay (batch_size 16, save_per_batch 2, seed 0).  One step = one pass of the hot
-path (read encoder -> site pooling; read_prob, site_prob, mod_ratio all produced) over that
-batch, inputs resident in HBM.  With N GPUs every rank holds its own 1M-site shard of an
-N x 1M-site job (weak scaling; shards are flush-group aligned so the job's results do not depend
-on N) and each step ends with one gather of site_prob + mod_ratio to rank 0 over RCCL.
+Workloads
+  uniform (default; BASELINE.json configs[2], the config the metric is quoted on): per GPU
+      1,000,000 synthetic DRACH sites x 20 reads, HCT116_RNA002 weights, num_iterations=1000.
+      With N GPUs: configs[3]'s shape (N x 1M sites, site-sharded).
+  ragged (BASELINE.json configs[4], per-GPU shape): per GPU 125,000 sites x 50..500 reads,
+      HEK293T_RNA004 weights, num_iterations=1000.
+Both: exact NumPy-stream replay (batch_size 16, save_per_batch 2, seed 0).  One step = one pass of the
+hot path (read encoder -> site pooling; read_prob, site_prob, mod_ratio all produced) over the rank's
+sites, inputs resident in HBM.  With N GPUs every rank holds its own shard of an N-times-larger job
+(weak scaling; shards are flush-group aligned and carry the job offset, so the job's results do not
+depend on N) and each step ends with ONE gather of site_prob + mod_ratio to rank 0 over RCCL.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--sites S] [--iters T]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload uniform|ragged] [--sites S] [--iters T]
+
+`--gpus N` without a launcher starts its own N ranks (re-executes under torch.distributed.run on
+127.0.0.1); under torch.distributed.run (RANK/WORLD_SIZE set) it runs as one rank.  The 8-GPU run is
+    python bench.py --gpus 8        (or: python -m torch.distributed.run --nnodes=1 --nproc-per-node 8
+                                      --master-addr 127.0.0.1 --master-port 29500 bench.py --gpus 8)
+M6A_BENCH_BACKEND=gloo is a debugging aid: ranks may then share one GPU and the gather is staged
+through host memory.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -26,11 +39,19 @@ ENC_FLOP_PER_READ = 14164      # 2*(15*150 + 150*32 + 32)           SURVEY.md se
 ENC_BYTES_PER_READ = 40        # 9 f32 in + 1 f32 out               SURVEY.md section 8(d)
 PEAK_F32_TFLOPS = 157.3        # MI355X_MICROARCH.md: f32 MFMA = f32 vector peak
 PEAK_HBM_GBPS = 8000.0
+# ds_read_b32 gathers, conflict-free: 64 lanes per 2 LDS cycles per CU (MI355X_MICROARCH.md, LDS table)
+PEAK_LDS_GATHERS = 256 * 2.4e9 * 32
+
+WORKLOADS = {
+    "uniform": dict(model="HCT116_RNA002", sites=1_000_000, bag=20, config="BASELINE.json configs[2]"),
+    "ragged": dict(model="HEK293T_RNA004", sites=125_000, bag=(50, 500), config="BASELINE.json configs[4] per-GPU shape"),
+}
 
 
-def measured_traffic(S, n):
-    """HBM bytes per enc_kernel launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
-    WRITE_SIZE, separate runs; profiles/*_enc_traffic.json), when they were taken on this workload."""
+def measured_traffic(S, bag):
+    """HBM bytes per encoder launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE, separate runs; profiles/*_enc_traffic.json), when they were taken on this workload.
+    The newest profile wins; the bench line names the file so a stale figure is visible."""
     import glob
     best = None
     for f in sorted(glob.glob(os.path.join(REPO, "profiles", "*_enc_traffic.json"))):
@@ -38,42 +59,125 @@ def measured_traffic(S, n):
             d = json.load(open(f))
         except (OSError, ValueError):
             continue
-        if d.get("workload") == {"sites": S, "reads_per_site": n}:
-            best = d
+        w = d.get("workload", {})
+        if w.get("sites") == S and w.get("reads_per_site") == (list(bag) if isinstance(bag, tuple) else bag):
+            best = dict(d, file=os.path.relpath(f, REPO))
     return best
 
 
-def cpu_baseline(d, T, thr, weights, budget_s=15.0):
-    """The oracle (a port of the reference's algorithm) on this host's cores, bounded sample."""
+# ---------------------------------------------------------------------------------------------
+# CPU baseline (runs in its own process: it forks worker pools, which must not happen after HIP is up)
+# ---------------------------------------------------------------------------------------------
+def _pool_site_worker(job):
+    """One site of a flush group, as a Pool task (the reference's imap over sites, inference_utils.py:103-104)."""
+    from oracle import m6a_oracle as orc
+    p, T, thr = job
+    off = np.array([0, len(p)], np.int64)
+    site, _ = orc.site_pool(p, off, T, thr, batch_size=1, save_per_batch=1)
+    return float(site[0])
+
+
+def cpu_baseline_main(workload, T, budget_s):
+    """The oracle (a port of the reference's algorithm, oracle/m6a_oracle.c) on this host's cores, on a
+    bounded sample of the bench workload.  Three figures, as BASELINE.md section 3 asks:
+      reference_shaped  the loop `m6anet inference` runs: encoder per 16-site batch, then per flush group
+                        of <= 32 sites a NEW multiprocessing.Pool(n) and one task per site
+                        (inference_utils.py:33-54,102-104), at n = 1, 25 (the reference's default) and all cores;
+      best_case         the same arithmetic with one persistent set of threads over all sites (what the
+                        reference could do at best) -- `value`, the figure most favourable to the CPU;
+      single_thread     one thread in-process."""
+    import multiprocessing as mp
+    from m6anet_amd import synthetic
+    from m6anet_amd.constants import DEFAULT_READ_THRESHOLD
+    from m6anet_amd.engine import load_weights
     from oracle import m6a_oracle as orc
     orc.build()
+    spec = WORKLOADS[workload]
     cores = os.cpu_count() or 1
-    S = len(d["off"]) - 1
+    thr = np.float32(DEFAULT_READ_THRESHOLD)
+    weights = load_weights(spec["model"])
+    n_sample = 600_000 if workload == "uniform" else 60_000
+    d = synthetic.make_sites(n_sample, spec["bag"], seed=20250328)
+    S = n_sample
 
-    def run(n):
+    def run(n, threads):
         off = d["off"][:n + 1]
-        X = d["X"][:off[-1]]
         t0 = time.perf_counter()
-        p = orc.encode_reads(weights, X, d["site_kmers"][:n], off, n_threads=cores)
-        orc.site_pool(p, off, T, thr, n_threads=cores)
+        p = orc.encode_reads(weights, d["X"][:off[-1]], d["site_kmers"][:n], off, n_threads=threads)
+        orc.site_pool(p, off, T, thr, n_threads=threads)
         return time.perf_counter() - t0
 
-    # single-thread rate on a small sample, for scale
-    t1 = time.perf_counter()
-    off1 = d["off"][:257]
-    p1 = orc.encode_reads(weights, d["X"][:off1[-1]], d["site_kmers"][:256], off1)
-    orc.site_pool(p1, off1, T, thr)
-    single = 256 / (time.perf_counter() - t1)
-
+    # (iii) one thread in-process
+    n1 = 256 if workload == "uniform" else 64
+    t1 = run(n1, 1)
+    single = n1 / t1
+    # (ii) persistent threads over all sites
     probe = min(S, 64 * cores)
-    t = run(probe)
-    n = int(min(S, max(probe, probe * budget_s / max(t, 1e-6)), 600_000))
+    t = run(probe, cores)
+    n = int(min(S, max(probe, probe * (budget_s * 0.5) / max(t, 1e-6))))
     n -= n % 32
     n = max(n, min(S, 32))
-    t = run(n)
-    return {"value": n / t, "unit": "sites/s", "cores": cores, "kind": "port", "single_thread_value": single,
-            "sample": "first %d sites of the same workload (encoder + T=%d sampling), %d host threads, %.1f s"
-                      % (n, T, cores, t)}
+    t = run(n, cores)
+    best = n / t
+
+    # (i) reference-shaped: per batch of 16 sites the encoder, per flush group a fresh Pool
+    def ref_shaped(n_proc, n_groups):
+        ctx = mp.get_context("fork")
+        bs, gsz = 16, 32
+        done = 0
+        t0 = time.perf_counter()
+        for g in range(n_groups):
+            a, b = g * gsz, min(S, (g + 1) * gsz)
+            probs = []
+            for s0 in range(a, b, bs):
+                s1 = min(b, s0 + bs)
+                off = d["off"][s0:s1 + 1] - d["off"][s0]
+                p = orc.encode_reads(weights, d["X"][d["off"][s0]:d["off"][s1]], d["site_kmers"][s0:s1], off)
+                probs.extend(p[off[i]:off[i + 1]] for i in range(s1 - s0))
+            with ctx.Pool(n_proc) as pool:
+                list(pool.imap(_pool_site_worker, [(p, T, thr) for p in probs]))
+            done += b - a
+        return done / (time.perf_counter() - t0)
+
+    shaped = {}
+    for n_proc, groups in ((1, 12), (25, 8), (cores, 3)):
+        if n_proc > cores:
+            continue
+        shaped["n_processes=%d" % n_proc] = ref_shaped(n_proc, groups)
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": best, "unit": "sites/s", "cores": cores, "kind": "port", "cpu_model": model,
+            "per_core_value": best / cores, "single_thread_value": single,
+            "reference_shaped_value": shaped,
+            "sample": "first %d sites of the same workload (encoder + T=%d sampling) on %d host threads, %.1f s; "
+                      "single thread: %d sites; reference-shaped (fresh Pool per 32-site flush): 3-12 flush groups "
+                      "per setting" % (n, T, cores, t, n1)}
+
+
+def run_cpu_baseline_subprocess(workload, T):
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--workload", workload, "--iters", str(T)]
+    try:
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, HIP_VISIBLE_DEVICES=""))
+        for line in reversed(out.stdout.strip().splitlines()):
+            if line.startswith("{"):
+                return json.loads(line)
+        return {"error": (out.stderr or out.stdout)[-400:]}
+    except (subprocess.SubprocessError, OSError, ValueError) as e:
+        return {"error": repr(e)}
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
 
 
 def main():
@@ -81,12 +185,25 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--sites", type=int, default=1_000_000, help="sites per GPU")
-    ap.add_argument("--reads", type=int, default=20, help="reads per site")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="uniform")
+    ap.add_argument("--sites", type=int, default=None, help="sites per GPU (default: the workload's)")
+    ap.add_argument("--reads", type=int, default=None, help="uniform workload: reads per site (default 20)")
     ap.add_argument("--iters", type=int, default=1000, help="num_iterations")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--enc-variant", type=int, default=0, help="0 auto, 1 general 16-slot, 2 12-slot encoder kernel")
+    ap.add_argument("--scan-driver", type=int, default=0, help="ragged bags: 0 auto, 1 per group, 2 per site, 3 index tables")
     args = ap.parse_args()
+
+    if args.cpu_baseline_only:
+        print(json.dumps(cpu_baseline_main(args.workload, args.iters, budget_s=20.0)))
+        return
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: start our own ranks, one per GPU, rendezvous on 127.0.0.1
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
 
     import torch
     from m6anet_amd import dist as mdist, synthetic
@@ -97,9 +214,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
-    # M6A_BENCH_BACKEND=gloo is a debugging aid (ranks may then share a GPU, the gather is staged
-    # through host memory); the real multi-GPU run is RCCL: backend "nccl", one GPU per rank
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     backend = os.environ.get("M6A_BENCH_BACKEND", "nccl")
     if backend != "nccl":
         local_rank %= max(torch.cuda.device_count(), 1)
@@ -110,15 +225,20 @@ def main():
         import torch.distributed as dist
         mdist.init_from_env(backend, device_id=dev if backend == "nccl" else None)
 
-    S, n, T = args.sites, args.reads, args.iters
+    spec = WORKLOADS[args.workload]
+    S = args.sites or spec["sites"]
+    bag = spec["bag"] if args.workload == "ragged" else (args.reads or spec["bag"])
+    T = args.iters
     thr = np.float32(DEFAULT_READ_THRESHOLD)
-    weights = load_weights("HCT116_RNA002")
+    weights = load_weights(spec["model"])
 
-    # this rank's shard of the N*S-site job: group-aligned cut of the global site range
-    off_global = np.arange(world * S + 1, dtype=np.int64) * n
-    cuts = shard_plan(off_global, world)
+    # this rank's shard of the world*S-site job: flush-group-aligned cut of the global site range, balanced by reads
+    n_reads_job = synthetic.bag_sizes(world * S, bag)
+    off_job = np.zeros(world * S + 1, np.int64)
+    np.cumsum(n_reads_job, out=off_job[1:])
+    cuts = shard_plan(off_job, world)
     a, b = int(cuts[rank]), int(cuts[rank + 1])
-    d = synthetic.make_sites(b - a, n, seed=20250328 + rank)
+    d = synthetic.make_sites(b - a, seed=20250328 + rank, n_reads=n_reads_job[a:b])
     X = torch.from_numpy(d["X"]).to(dev)
     km = torch.from_numpy(d["site_kmers"]).to(dev)
     off = torch.from_numpy(d["off"]).to(dev)
@@ -127,6 +247,8 @@ def main():
     eng = M6ANetEngine(weights=weights, device=local_rank)
     if args.enc_variant:
         eng.set_encoder_variant(args.enc_variant)
+    if args.scan_driver:
+        eng.set_scan_driver(args.scan_driver)
     eng.use_torch_stream()
     eng.set_job_offset(a)
     rp = torch.empty(R, dtype=torch.float32, device=dev)
@@ -153,6 +275,12 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
+    # the cold call: MT19937 stream / index tables are built for this (seed, T, bag sizes), then cached
+    fence()
+    t0 = time.perf_counter()
+    step()
+    fence()
+    first_call_ms = (time.perf_counter() - t0) * 1e3
     for _ in range(args.warmup):
         step()
     fence()
@@ -167,9 +295,9 @@ def main():
     eng.profile(False)
     eng.sync()
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt, first_call_ms], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+        dt, first_call_ms = float(tmax[0].item()), float(tmax[1].item())
 
     if rank == 0:
         total_sites = int(cuts[-1])
@@ -177,7 +305,12 @@ def main():
         pool_avg_ms = pool_ms / max(pool_n, 1)
         enc_tflops = ENC_FLOP_PER_READ * R / (enc_avg_ms * 1e-3) / 1e12
         enc_gbps = ENC_BYTES_PER_READ * R / (enc_avg_ms * 1e-3) / 1e9
-        tr = measured_traffic(S, n) if world == 1 else None
+        draws = Sr * T * 20
+        tr = measured_traffic(S, bag) if world == 1 else None
+        bag_txt = "%d reads" % bag if not isinstance(bag, tuple) else "%d..%d reads" % bag
+        enc_kernel = {"csite12": "enc_csite_kernel", "general16": "enc_kernel"}.get(eng.last_encoder_variant, "enc_kernel")
+        pool_kernel = {"table-reg": "pool_reg_kernel", "table": "pool_table_kernel", "ragged-table": "pool_rtab_kernel"}.get(
+            eng.last_pool_variant, "pool_scan_kernels")
         out = {
             "metric": "DRACH sites/sec at num_iterations=%d" % T,
             "value": total_sites * args.steps / dt,
@@ -186,30 +319,38 @@ def main():
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "synthetic %d DRACH sites x %d reads per GPU, HCT116_RNA002 weights, "
-                                   "num_iterations=%d, numpy-stream replay (batch_size 16, save_per_batch 2, seed 0); "
-                                   "BASELINE.json configs[2]%s" % (S, n, T, " x%d GPUs (configs[3] shape)" % world if world > 1 else ""),
-                       "sites_per_gpu": S, "reads_per_site": n, "num_iterations": T,
-                       "pool_kernel": eng.last_pool_variant, "encoder_kernel": eng.last_encoder_variant, "sharding": "site shards, 1 RCCL gather/step" if world > 1 else "none"},
+            "config": {"workload": "synthetic %d DRACH sites x %s per GPU, %s weights, num_iterations=%d, numpy-stream replay "
+                                   "(batch_size 16, save_per_batch 2, seed 0); %s%s"
+                                   % (S, bag_txt, spec["model"], T, spec["config"],
+                                      " x%d GPUs%s" % (world, " (configs[3])" if args.workload == "uniform" else " (configs[4])") if world > 1 else ""),
+                       "sites_per_gpu": S, "reads_per_site": list(bag) if isinstance(bag, tuple) else bag, "reads_rank0": R,
+                       "num_iterations": T, "pool_kernel": eng.last_pool_variant, "encoder_kernel": eng.last_encoder_variant,
+                       "sharding": "contiguous flush-group-aligned site shards balanced by reads, 1 %s gather/step"
+                                   % ("RCCL" if backend == "nccl" else backend) if world > 1 else "none"},
+            "first_call_ms": first_call_ms,
             "roofline": {"kernel": "read encoder (%s)" % eng.last_encoder_variant, "bound": "mfma", "achieved": enc_tflops,
                          "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": enc_tflops / PEAK_F32_TFLOPS,
                          "traffic": tr["traffic_bytes_per_launch"] if tr else None,
-                         "traffic_source": tr["source"] if tr else None,
+                         "traffic_source": "%s (%s)" % (tr["file"], tr["source"]) if tr else None,
                          "algorithmic_bytes_per_launch": ENC_BYTES_PER_READ * R,
                          "avg_launch_ms": enc_avg_ms, "launches": enc_n,
                          "algorithmic_flop_per_read": ENC_FLOP_PER_READ, "reads_per_launch": R,
                          "hbm_view": {"achieved": enc_gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                                       "frac": enc_gbps / PEAK_HBM_GBPS, "algorithmic_bytes_per_read": ENC_BYTES_PER_READ}},
-            "kernels": {{"csite12": "enc_csite_kernel", "general16": "enc_kernel"}.get(eng.last_encoder_variant, "enc_kernel"):
-                            {"avg_ms": enc_avg_ms, "launches": enc_n},
-                        {"table-reg": "pool_reg_kernel", "table": "pool_table_kernel"}.get(eng.last_pool_variant, "pool_scan_kernels"): {
-                            "avg_ms": pool_avg_ms, "launches": pool_n,
-                            "Gdraws_per_s": Sr * T * 20 / (pool_avg_ms * 1e-3) / 1e9 if pool_avg_ms else None}},
+            "pool_roofline": {"kernel": "site pooling (%s)" % eng.last_pool_variant, "bound": "lds-gather",
+                              "achieved": draws / (pool_avg_ms * 1e-3) / 1e12 if pool_avg_ms else None,
+                              "peak": PEAK_LDS_GATHERS / 1e12, "unit": "T draws/s",
+                              "frac": draws / (pool_avg_ms * 1e-3) / PEAK_LDS_GATHERS if pool_avg_ms else None,
+                              "note": "peak = conflict-free ds_read_b32 gather rate (one 4-byte gather per draw); the uniform-bag "
+                                      "register kernel issues no LDS gathers and is bound by VALU issue instead",
+                              "avg_launch_ms": pool_avg_ms, "launches": pool_n, "draws_per_launch": draws},
+            "kernels": {enc_kernel: {"avg_ms": enc_avg_ms, "launches": enc_n},
+                        pool_kernel: {"avg_ms": pool_avg_ms, "launches": pool_n,
+                                      "Gdraws_per_s": draws / (pool_avg_ms * 1e-3) / 1e9 if pool_avg_ms else None}},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(d, T, thr, weights)
-            out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
-        print(json.dumps(out))
+            out["cpu_baseline"] = run_cpu_baseline_subprocess(args.workload, T)
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -132,6 +132,11 @@ int m6a_validate(m6a_ctx *ctx, const float *X, const uint8_t *site_kmers, const 
 int64_t m6a_flush_groups(int64_t n_sites, int64_t batch_size, int64_t save_per_batch,
                          int64_t *group_off, int64_t cap);
 
+/* Sites the REFERENCE writes for this geometry: everything up to its last flush.  Batches after it are computed
+ * by nobody and never reach the CSVs there (an even batch count always loses the last batch at the default
+ * save_per_batch = 2); the reference-compatible CLI mode (--drop_unflushed_tail) cuts its output here. */
+int64_t m6a_reference_written_sites(int64_t n_sites, int64_t batch_size, int64_t save_per_batch);
+
 /* Contiguous, flush-group-aligned site shards balanced by read count for n_shards GPUs
  * (sites are independent; aligning to groups keeps results independent of the GPU count).
  * off is a HOST pointer.  Writes shard_site_off[0..n_shards]. */

@@ -53,6 +53,12 @@ const char *m6a_io_kmer5(const m6a_sites *s, int64_t site);    /* centre 5-mer, 
  * m6anet/scripts/inference.py:94-97).  read_prob [R], site_prob [S], mod_ratio [S]. */
 int m6a_io_write_csv(const m6a_sites *s, const char *out_dir, const float *read_prob,
                      const float *site_prob, const double *mod_ratio, int write_header, int n_threads);
+/* same, but only the first n_sites_limit sites (< 0: all): with m6a_reference_written_sites() (m6a.h) the files
+ * hold exactly the rows the reference writes when its flush test leaves the last batches unwritten
+ * (m6anet/utils/inference_utils.py:47) */
+int m6a_io_write_csv_n(const m6a_sites *s, const char *out_dir, const float *read_prob,
+                       const float *site_prob, const double *mod_ratio, int write_header, int n_threads,
+                       int64_t n_sites_limit);
 
 /* `m6anet dataprep` (m6anet/scripts/dataprep.py:54-70 -> m6anet/utils/dataprep_utils.py):
  * eventalign.txt -> <out_dir>/eventalign.index (parallel_index, :187-266), data.json + data.info +

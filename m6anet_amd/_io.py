@@ -8,7 +8,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libm6a_io.so")
 SYMBOLS = ["m6a_io_last_error", "m6a_io_load_sites", "m6a_io_free", "m6a_io_n_sites", "m6a_io_n_reads",
            "m6a_io_n_replicates", "m6a_io_X", "m6a_io_site_kmers", "m6a_io_off", "m6a_io_tx_pos",
-           "m6a_io_read_ids", "m6a_io_read_rep", "m6a_io_tx_id", "m6a_io_kmer5", "m6a_io_write_csv",
+           "m6a_io_read_ids", "m6a_io_read_rep", "m6a_io_tx_id", "m6a_io_kmer5", "m6a_io_write_csv", "m6a_io_write_csv_n",
            "m6a_io_dataprep"]
 _lib = None
 
@@ -39,6 +39,7 @@ def load():
         getattr(L, name).argtypes = [vp, i64]
         getattr(L, name).restype = C.c_char_p
     L.m6a_io_write_csv.argtypes = [vp, C.c_char_p, vp, vp, vp, i32, i32]
+    L.m6a_io_write_csv_n.argtypes = [vp, C.c_char_p, vp, vp, vp, i32, i32, i64]
     L.m6a_io_dataprep.argtypes = [C.c_char_p, C.c_char_p, i32, i32, i32, i32, i32, i32, i32]
     _lib = L
     return L
@@ -96,13 +97,13 @@ class NativeSites:
     def kmer5(self, i):
         return self._L.m6a_io_kmer5(self._h, i).decode()
 
-    def write_csv(self, out_dir, read_prob, site_prob, mod_ratio, write_header=False, n_threads=0):
+    def write_csv(self, out_dir, read_prob, site_prob, mod_ratio, write_header=False, n_threads=0, n_sites=None):
         rp = np.ascontiguousarray(read_prob, np.float32)
         sp = np.ascontiguousarray(site_prob, np.float32)
         mr = np.ascontiguousarray(mod_ratio, np.float64)
         assert rp.size == self.X.shape[0] and sp.size == self.tx_pos.size == mr.size
-        _chk(self._L.m6a_io_write_csv(self._h, os.fsencode(out_dir), rp.ctypes.data, sp.ctypes.data, mr.ctypes.data,
-                                      1 if write_header else 0, int(n_threads)))
+        _chk(self._L.m6a_io_write_csv_n(self._h, os.fsencode(out_dir), rp.ctypes.data, sp.ctypes.data, mr.ctypes.data,
+                                        1 if write_header else 0, int(n_threads), -1 if n_sites is None else int(n_sites)))
 
     def close(self):
         if getattr(self, "_h", None):

@@ -14,6 +14,7 @@ RNG_NUMPY = 0
 # every symbol include/m6a.h declares (tests check the .so exports exactly these)
 SYMBOLS = ["m6a_create", "m6a_destroy", "m6a_last_error", "m6a_set_stream", "m6a_set_job_offset", "m6a_set_scan_driver", "m6a_set_table_variant", "m6a_set_encoder_variant", "m6a_last_encoder_variant", "m6a_sync",
            "m6a_encode_reads", "m6a_site_pool", "m6a_infer", "m6a_bag_forward", "m6a_validate_pool", "m6a_validate", "m6a_flush_groups",
+           "m6a_reference_written_sites",
            "m6a_shard_plan", "m6a_profile_enable", "m6a_profile_read", "m6a_last_pool_variant",
            "m6a_version"]
 
@@ -74,6 +75,8 @@ def load():
     L.m6a_validate.argtypes = [vp, vp, vp, vp, i64, i32, i32, C.c_uint32, vp, vp, vp]
     L.m6a_flush_groups.argtypes = [i64, i64, i64, vp, i64]
     L.m6a_flush_groups.restype = i64
+    L.m6a_reference_written_sites.argtypes = [i64, i64, i64]
+    L.m6a_reference_written_sites.restype = i64
     L.m6a_shard_plan.argtypes = [vp, i64, i64, i64, i32, vp]
     L.m6a_profile_enable.argtypes = [vp, i32]
     L.m6a_profile_read.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(i64)]
@@ -82,7 +85,7 @@ def load():
     L.m6a_version.restype = C.c_char_p
     for name in SYMBOLS:
         fn = getattr(L, name)
-        if fn.restype is C.c_int and name not in ("m6a_flush_groups",):
+        if fn.restype is C.c_int and name not in ("m6a_flush_groups", "m6a_reference_written_sites"):
             fn.restype = C.c_int
     _lib = L
     return L

@@ -8,7 +8,7 @@ CSRC = os.path.join(PKG, "csrc")
 INCLUDE = os.path.join(os.path.dirname(PKG), "include")
 LIB = os.path.join(PKG, "libm6a_hip.so")
 IO_LIB = os.path.join(PKG, "libm6a_io.so")
-SOURCES = ["m6a_kernels.hip", "m6a_pool_reg.hip", "m6a_api.hip"]
+SOURCES = ["m6a_kernels.hip", "m6a_pool_reg.hip", "m6a_pool_rtab.hip", "m6a_api.hip"]
 DEPS = SOURCES + ["m6a_kernels.h", os.path.join(INCLUDE, "m6a.h")]
 
 

@@ -87,6 +87,18 @@ struct m6a_ctx {
     unsigned long long *d_minmax = nullptr;
     unsigned long long *h_minmax = nullptr;   // pinned
     int *h_err = nullptr;                     // pinned
+    // bag-size histogram of the last query_bags()/host_bag_range() (pinned; bins 0..1024, last = larger) and the
+    // pinned staging of the small control arrays of the index-table path
+    uint32_t *h_hist = nullptr, *d_hist = nullptr;
+    uint32_t *h_ctl = nullptr;                // [cursor HIST_BINS | slot_of_n 1025 | build_n 1024 | build_slot 1024]
+    DevBuf ctl_dev, rt_rank, rt_order;
+    // per-bag-size index tables (m6a_pool_rtab.hip), valid for (seed, T*K, stream length)
+    struct {
+        bool valid = false; uint32_t seed = 0; int64_t A = 0, n_blk = 0;
+        int cap = 0, used = 0;
+        uint16_t *C = nullptr; uint32_t *RS = nullptr;
+        int32_t slot_of_n[M6A_RTAB_MAX_N + 1];
+    } rt;
     // host-pointer staging
     DevBuf sX, sK, sOff, sP, sSite, sMod, val_idx, val_y, val_avg;
     Profiler prof;
@@ -228,19 +240,19 @@ int ensure_groups(m6a_ctx *c, int64_t S, int64_t bs, int64_t spb)
 }
 
 // ---- NumPy legacy stream: np.random.seed(int) == init_genrand == std::mt19937(seed) ------------
+// generated on the device (mt19937_kernel, m6a_pool_rtab.hip): one workgroup, ~0.3 ms for the default 1.3 M words
 int ensure_raw(m6a_ctx *c, uint32_t seed, int64_t len)
 {
     if (c->raw_len >= len && c->raw_seed == seed) return M6A_OK;
     if (len > ((int64_t)1 << 31) - 512)
         return fail(c, M6A_ESTREAM, "a flush group would need %lld MT19937 words (cap 2^31); "
                     "reduce batch_size*save_per_batch or num_iterations", (long long)len);
-    std::vector<uint32_t> h;
-    try { h.resize((size_t)len); } catch (const std::bad_alloc &) { return fail(c, M6A_ENOMEM, "host alloc of MT stream failed"); }
-    std::mt19937 gen(seed);
-    for (int64_t i = 0; i < len; i++) h[(size_t)i] = (uint32_t)gen();
+    len = (len + 1023) / 1024 * 1024;
+    c->raw_len = 0;
+    c->rt.valid = false;                       // the index tables describe the old stream
     HIPCHK(c, c->raw.ensure((size_t)len * 4));
-    HIPCHK(c, hipMemcpyAsync(c->raw.p, h.data(), (size_t)len * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    hipLaunchKernelGGL(mt19937_kernel, dim3(1), dim3(256), 0, c->stream, seed, len, (uint32_t *)c->raw.p);
+    HIPCHK(c, hipGetLastError());
     c->raw_seed = seed; c->raw_len = len;
     return M6A_OK;
 }
@@ -403,29 +415,134 @@ int ensure_table(m6a_ctx *c, uint32_t seed, int n, int T, int K, int jmax)
     return M6A_OK;
 }
 
-// the same accepted indices for pool_reg_kernel: idx2[j][T + 8][K] bytes, 2 x index (a register pair per
-// bag entry), iterations in order, one round of zero padding for the prefetch past the end
+// ---- per-bag-size index tables (m6a_pool_rtab.hip) ------------------------------------------------
+// words of stream a flush group of gmax sites can consume: expected <= 2 per accepted draw, slack for the spread
+int64_t stream_need(int64_t gmax, int T, int K)
+{
+    const int64_t A = (int64_t)T * K;
+    return gmax * (2 * A + A / 16) + 8192;        // incl. the scan kernels' 2 x 1024-word read-ahead
+}
+
+uint32_t *ctl_cursor(m6a_ctx *c) { return c->h_ctl; }
+int32_t *ctl_slot(m6a_ctx *c) { return (int32_t *)(c->h_ctl + M6A_HIST_BINS); }
+int32_t *ctl_build_n(m6a_ctx *c) { return ctl_slot(c) + M6A_RTAB_MAX_N + 1; }
+int32_t *ctl_build_slot(m6a_ctx *c) { return ctl_build_n(c) + M6A_RTAB_MAX_N; }
+constexpr size_t kCtlWords = M6A_HIST_BINS + (M6A_RTAB_MAX_N + 1) + 2 * M6A_RTAB_MAX_N;
+
+// bag sizes (2..1024) of `hist` that have no table yet for (seed, T*K, a stream of >= need words)
+int rtab_missing(const m6a_ctx *c, uint32_t seed, int T, int K, int64_t need, const uint32_t *hist, int *n_distinct)
+{
+    const bool valid = c->rt.valid && c->rt.seed == seed && c->rt.A == (int64_t)T * K && c->raw_seed == seed &&
+                       c->rt.n_blk * 64 >= need && c->rt.n_blk == c->raw_len / 64;
+    int missing = 0, distinct = 0;
+    for (int n = 2; n <= M6A_RTAB_MAX_N; n++)
+        if (hist[n]) { distinct++; if (!valid || c->rt.slot_of_n[n] < 0) missing++; }
+    if (n_distinct) *n_distinct = distinct;
+    return missing;
+}
+
+// Builds the tables of every bag size in `hist` that lacks one.  *usable = false (and M6A_OK) when the tables would
+// not fit the memory budget: the caller then takes the scan kernels.
+int ensure_rtab(m6a_ctx *c, uint32_t seed, int T, int K, int64_t gmax, const uint32_t *hist, bool *usable)
+{
+    *usable = false;
+    const int64_t need = stream_need(gmax, T, K);
+    int rc = ensure_raw(c, seed, need);
+    if (rc) return rc;
+    auto &rt = c->rt;
+    const int64_t n_blk = c->raw_len / 64;
+    if (!(rt.valid && rt.seed == seed && rt.A == (int64_t)T * K && rt.n_blk == n_blk)) {
+        rt.valid = false; rt.used = 0;
+        for (int n = 0; n <= M6A_RTAB_MAX_N; n++) rt.slot_of_n[n] = -1;
+    }
+    std::vector<int> todo;
+    for (int n = 2; n <= M6A_RTAB_MAX_N; n++)
+        if (hist[n] && rt.slot_of_n[n] < 0) todo.push_back(n);
+    const int64_t c_stride = n_blk * 64;
+    const size_t slot_bytes = (size_t)c_stride * 2 + (size_t)(n_blk + 1) * 4;
+    const bool fresh = !rt.valid || rt.n_blk != n_blk;
+    const int want = (fresh ? 1 : rt.used) + (int)todo.size();
+    if (fresh || want > rt.cap) {
+        int new_cap = std::max(want, fresh ? 0 : rt.cap * 2);
+        new_cap = std::min(std::max(new_cap, 32), M6A_RTAB_MAX_N + 1);
+        size_t free_b = 0, total_b = 0;
+        HIPCHK(c, hipMemGetInfo(&free_b, &total_b));
+        const size_t held = fresh ? 0 : (size_t)rt.cap * slot_bytes;
+        const size_t budget = std::min<size_t>((size_t)16 << 30, (free_b + held) / 2);
+        if ((size_t)new_cap * slot_bytes > budget) new_cap = want;
+        if ((size_t)new_cap * slot_bytes > budget) return M6A_OK;          // not usable: scan kernels instead
+        uint16_t *nC = nullptr; uint32_t *nRS = nullptr;
+        if (fresh) {                                                        // old tables are void: free first
+            if (rt.C) (void)hipFree(rt.C);
+            if (rt.RS) (void)hipFree(rt.RS);
+            rt.C = nullptr; rt.RS = nullptr; rt.cap = 0;
+        }
+        HIPCHK(c, hipMalloc((void **)&nC, (size_t)new_cap * c_stride * 2));
+        hipError_t e = hipMalloc((void **)&nRS, (size_t)new_cap * (n_blk + 1) * 4);
+        if (e != hipSuccess) { (void)hipFree(nC); HIPCHK(c, e); }
+        if (!fresh && rt.used) {
+            HIPCHK(c, hipMemcpyAsync(nC, rt.C, (size_t)rt.used * c_stride * 2, hipMemcpyDeviceToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(nRS, rt.RS, (size_t)rt.used * (n_blk + 1) * 4, hipMemcpyDeviceToDevice, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            (void)hipFree(rt.C); (void)hipFree(rt.RS);
+        }
+        rt.C = nC; rt.RS = nRS; rt.cap = new_cap;
+        if (fresh) {
+            // slot 0: a table of zeros for bags of one read (randint(0,1) draws no words, every draw is read 0)
+            HIPCHK(c, hipMemsetAsync(rt.C, 0, (size_t)c_stride * 2, c->stream));
+            HIPCHK(c, hipMemsetAsync(rt.RS, 0, (size_t)(n_blk + 1) * 4, c->stream));
+            rt.used = 1;
+        }
+        rt.valid = true; rt.seed = seed; rt.A = (int64_t)T * K; rt.n_blk = n_blk;
+    }
+    if (!todo.empty()) {
+        int32_t *bn = ctl_build_n(c), *bs = ctl_build_slot(c);
+        for (size_t i = 0; i < todo.size(); i++) { bn[i] = todo[i]; bs[i] = rt.used; rt.slot_of_n[todo[i]] = rt.used++; }
+        HIPCHK(c, c->ctl_dev.ensure(kCtlWords * 4));
+        int32_t *d_bn = (int32_t *)c->ctl_dev.p + (ctl_build_n(c) - (int32_t *)c->h_ctl);
+        HIPCHK(c, hipMemcpyAsync(d_bn, bn, (size_t)2 * M6A_RTAB_MAX_N * 4, hipMemcpyHostToDevice, c->stream));
+        RtabBuild b;
+        b.raw = (const uint32_t *)c->raw.p; b.n_blk = (uint32_t)n_blk; b.build_n = d_bn; b.build_slot = d_bn + M6A_RTAB_MAX_N;
+        b.C = rt.C; b.RS = rt.RS; b.c_stride = c_stride;
+        const unsigned gx = (unsigned)((n_blk + 63) / 64);                  // 4 waves x 16 blocks per workgroup
+        hipLaunchKernelGGL(rtab_count_kernel, dim3(gx, (unsigned)todo.size()), dim3(256), 0, c->stream, b);
+        hipLaunchKernelGGL(rtab_scan_kernel, dim3((unsigned)todo.size()), dim3(256), 0, c->stream, b);
+        hipLaunchKernelGGL(rtab_fill_kernel, dim3(gx, (unsigned)todo.size()), dim3(256), 0, c->stream, b);
+        HIPCHK(c, hipGetLastError());
+        // the pinned build list is reused by the next call: it must have been consumed
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    *usable = true;
+    return M6A_OK;
+}
+
+// accepted indices for pool_reg_kernel: idx2[j][T + 8][K] bytes, 2 x index (a register pair per bag entry),
+// iterations in order, one round of zero padding for the prefetch past the end.  Row j = draws
+// [j*T*K, (j+1)*T*K) of the stream's accepted sequence for bags of n reads, taken from the index table C_n.
 int ensure_table_reg(m6a_ctx *c, uint32_t seed, int n, int T, int K, int jmax)
 {
     auto &k = c->tab_reg_key;
     if (k.valid && k.seed == seed && k.n == n && k.T == T && k.K == K && k.jmax >= jmax) return M6A_OK;
     const size_t per_j = (size_t)(T + 8) * K;              // K = 20: a multiple of 4 bytes
-    std::vector<uint8_t> tab((size_t)jmax * per_j + 256, 0);
-    std::mt19937 gen(seed);
-    const uint32_t rng = (uint32_t)(n - 1);
-    uint32_t mask = rng;
-    mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
-    for (int j = 0; j < jmax; j++) {
-        uint8_t *row = &tab[(size_t)j * per_j];
-        for (size_t i = 0; i < (size_t)T * K; i++) {       // stream order: iteration-major, then sample
-            uint32_t v = 0;
-            if (rng) do { v = (uint32_t)gen() & mask; } while (v > rng);
-            row[i] = (uint8_t)(2u * v);
-        }
+    const size_t bytes = (size_t)jmax * per_j + 256;
+    HIPCHK(c, c->tab_reg.ensure(bytes));
+    HIPCHK(c, hipMemsetAsync(c->tab_reg.p, 0, bytes, c->stream));
+    if (n >= 2) {
+        std::vector<uint32_t> hist(M6A_HIST_BINS, 0u);
+        hist[n] = 1;
+        bool usable = false;
+        int rc = ensure_rtab(c, seed, T, K, jmax, hist.data(), &usable);
+        if (rc) return rc;
+        if (!usable) return fail(c, M6A_ENOMEM, "no device memory for the index table of bag size %d", n);
+        const int64_t slot = c->rt.slot_of_n[n], A = (int64_t)T * K;
+        uint32_t total = 0;
+        HIPCHK(c, hipMemcpyAsync(&total, c->rt.RS + slot * (c->rt.n_blk + 1) + c->rt.n_blk, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if ((int64_t)total < A * jmax) return fail(c, M6A_ESTREAM, "MT19937 stream too short for a flush group");
+        hipLaunchKernelGGL(rtab_to_reg_table_kernel, dim3((unsigned)((A * jmax + 255) / 256)), dim3(256), 0, c->stream,
+                           (const uint16_t *)(c->rt.C + slot * c->rt.n_blk * 64), A, (int64_t)per_j, jmax, (uint8_t *)c->tab_reg.p);
+        HIPCHK(c, hipGetLastError());
     }
-    HIPCHK(c, c->tab_reg.ensure(tab.size()));
-    HIPCHK(c, hipMemcpyAsync(c->tab_reg.p, tab.data(), tab.size(), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
     k = {seed, n, T, K, jmax, true};
     return M6A_OK;
 }
@@ -453,16 +570,18 @@ void prof_end(m6a_ctx *c, int kind)
 
 void host_bag_range(m6a_ctx *c, const int64_t *off, int64_t S);
 
-// bag-size range (decides the pooling kernel) and total reads: one 24-byte read-back, which
-// blocks on the stream
+// bag-size range and histogram (they decide the pooling kernel) and total reads: one 4 KB read-back,
+// which blocks on the stream
 int query_bags(m6a_ctx *c, const int64_t *d_off, int64_t S)
 {
     c->h_minmax[0] = ~0ull; c->h_minmax[1] = 0ull; c->h_minmax[2] = 0ull;
     HIPCHK(c, hipMemcpyAsync(c->d_minmax, c->h_minmax, 24, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_hist, 0, M6A_HIST_BINS * 4, c->stream));
     hipLaunchKernelGGL(bag_minmax_kernel, dim3((unsigned)std::min<int64_t>((S + 255) / 256, 512)), dim3(256), 0,
-                       c->stream, d_off, S, c->d_minmax);
+                       c->stream, d_off, S, c->d_minmax, c->d_hist);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(c->h_minmax, c->d_minmax, 24, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->h_hist, c->d_hist, M6A_HIST_BINS * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->bag_min = (int64_t)c->h_minmax[0];
     c->bag_max = (int64_t)c->h_minmax[1];
@@ -548,9 +667,52 @@ int launch_pool(m6a_ctx *c, const float *rp, const int64_t *off, int64_t S, int 
         hipLaunchKernelGGL(pool_table_kernel, dim3(blocks), dim3(256), mean_lds, c->stream, a);
         prof_end(c, 1);
     } else {
-        // expected words per accepted draw <= 2; slack covers the rejection-count spread
-        const int64_t A = (int64_t)T * K;
-        const int64_t need = gmax * (2 * A + A / 16) + 8192;     // incl. the kernels' 2 x 1024-word read-ahead
+        // Ragged bags.  Default: per-bag-size index tables (pool_rtab_kernel) when every bag fits one (n <= 1024)
+        // and the job is large enough to pay for the tables it still lacks (a table = one pass over the stream,
+        // about what 50 sites cost the scan kernels); otherwise the scan kernels replay the stream per site.
+        const int64_t need = stream_need(gmax, T, K);
+        bool use_rtab = false;
+        if (nmax <= M6A_RTAB_MAX_N && c->scan_driver != 1 && c->scan_driver != 2) {
+            int distinct = 0;
+            const int missing = rtab_missing(c, seed, T, K, need, c->h_hist, &distinct);
+            use_rtab = c->scan_driver == 3 || (missing == 0 ? S >= 64 : S >= (int64_t)16 * missing);
+            if (use_rtab) {
+                rc = ensure_rtab(c, seed, T, K, gmax, c->h_hist, &use_rtab);      // false: over the memory budget
+                if (rc) return rc;
+            }
+        } else if (c->scan_driver == 3) {
+            return fail(c, M6A_EUNSUPPORTED, "index-table pooling needs every bag <= %d reads (largest: %lld)", M6A_RTAB_MAX_N, (long long)nmax);
+        }
+        if (use_rtab) {
+            plan_args(c, a);
+            a.raw = (const uint32_t *)c->raw.p; a.raw_len = c->raw_len;
+            HIPCHK(c, c->rt_rank.ensure((size_t)S * 4));
+            HIPCHK(c, c->rt_order.ensure((size_t)S * 4));
+            HIPCHK(c, c->ctl_dev.ensure(kCtlWords * 4));
+            // sites in bag-size order: cursor[n] = first position of size n (the histogram came with the bag range)
+            uint32_t *cur = ctl_cursor(c);
+            uint32_t run = 0;
+            for (int n = 0; n < M6A_HIST_BINS; n++) { cur[n] = run; run += c->h_hist[n]; }
+            std::memcpy(ctl_slot(c), c->rt.slot_of_n, sizeof c->rt.slot_of_n);
+            HIPCHK(c, hipMemcpyAsync(c->ctl_dev.p, c->h_ctl, (size_t)(M6A_HIST_BINS + M6A_RTAB_MAX_N + 1) * 4, hipMemcpyHostToDevice, c->stream));
+            RtabUse u;
+            u.C = c->rt.C; u.RS = c->rt.RS; u.slot_of_n = (const int32_t *)c->ctl_dev.p + M6A_HIST_BINS;
+            u.rank = (uint32_t *)c->rt_rank.p; u.order = (const uint32_t *)c->rt_order.p;
+            u.c_stride = c->rt.n_blk * 64; u.n_blk = (uint32_t)c->rt.n_blk;
+            u.bag_cap = (int)std::max<int64_t>(64, (nmax + 63) / 64 * 64);
+            c->pool_variant = "ragged-table";
+            prof_begin(c, 1);
+            hipLaunchKernelGGL(rtab_chain_kernel, dim3((unsigned)std::min<int64_t>((a.n_groups + 3) / 4, (int64_t)c->n_cu * 16)), dim3(256), 0, c->stream, a, u);
+            hipLaunchKernelGGL(rtab_order_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, c->stream, off, S,
+                               (uint32_t *)c->ctl_dev.p, (uint32_t *)c->rt_order.p);
+            const size_t lds = (size_t)4 * (u.bag_cap + 16 + M6A_MEAN_STACK) * sizeof(float);
+            const unsigned blocks = (unsigned)(((S + 3) / 4 + 7) / 8 * 8);
+            if (K == 20) hipLaunchKernelGGL(pool_rtab_kernel<20>, dim3(blocks), dim3(256), lds, c->stream, a, u);
+            else hipLaunchKernelGGL(pool_rtab_kernel<0>, dim3(blocks), dim3(256), lds, c->stream, a, u);
+            prof_end(c, 1);
+            HIPCHK(c, hipGetLastError());
+            return M6A_OK;
+        }
         rc = ensure_raw(c, seed, need);
         if (rc) return rc;
         plan_args(c, a);
@@ -595,7 +757,12 @@ int launch_pool(m6a_ctx *c, const float *rp, const int64_t *off, int64_t S, int 
 void host_bag_range(m6a_ctx *c, const int64_t *off, int64_t S)
 {
     int64_t mn = INT64_MAX, mx = 0;
-    for (int64_t s = 0; s < S; s++) { const int64_t n = off[s + 1] - off[s]; mn = std::min(mn, n); mx = std::max(mx, n); }
+    std::memset(c->h_hist, 0, M6A_HIST_BINS * 4);
+    for (int64_t s = 0; s < S; s++) {
+        const int64_t n = off[s + 1] - off[s];
+        mn = std::min(mn, n); mx = std::max(mx, n);
+        c->h_hist[n < 0 ? 0 : n > M6A_RTAB_MAX_N ? M6A_RTAB_MAX_N + 1 : n]++;
+    }
     c->bag_min = mn; c->bag_max = mx; c->n_reads = off[S];
 }
 
@@ -696,6 +863,10 @@ int m6a_create(m6a_ctx **out, const float *weights, size_t n_floats, int device_
     CRCHK(hipHostMalloc((void **)&c->h_minmax, 24, hipHostMallocDefault));
     CRCHK(hipHostMalloc((void **)&c->h_err, sizeof(int), hipHostMallocDefault));
     *c->h_err = 0;
+    CRCHK(hipMalloc((void **)&c->d_hist, M6A_HIST_BINS * 4));
+    CRCHK(hipHostMalloc((void **)&c->h_hist, M6A_HIST_BINS * 4, hipHostMallocDefault));
+    CRCHK(hipHostMalloc((void **)&c->h_ctl, kCtlWords * 4, hipHostMallocDefault));
+    for (int n = 0; n <= M6A_RTAB_MAX_N; n++) c->rt.slot_of_n[n] = -1;
 #undef CRCHK
     *out = c;
     return M6A_OK;
@@ -720,6 +891,12 @@ void m6a_destroy(m6a_ctx *c)
     if (c->d_minmax) (void)hipFree(c->d_minmax);
     if (c->h_minmax) (void)hipHostFree(c->h_minmax);
     if (c->h_err) (void)hipHostFree(c->h_err);
+    if (c->d_hist) (void)hipFree(c->d_hist);
+    if (c->h_hist) (void)hipHostFree(c->h_hist);
+    if (c->h_ctl) (void)hipHostFree(c->h_ctl);
+    if (c->rt.C) (void)hipFree(c->rt.C);
+    if (c->rt.RS) (void)hipFree(c->rt.RS);
+    for (DevBuf *b : {&c->ctl_dev, &c->rt_rank, &c->rt_order}) b->release();
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -752,7 +929,7 @@ const char *m6a_last_encoder_variant(const m6a_ctx *c) { return c ? c->enc_varia
 int m6a_set_scan_driver(m6a_ctx *c, int mode)
 {
     if (!c) return M6A_EINVAL;
-    if (mode < 0 || mode > 2) return fail(c, M6A_EINVAL, "scan driver must be 0 (auto), 1 (group) or 2 (site)");
+    if (mode < 0 || mode > 3) return fail(c, M6A_EINVAL, "scan driver must be 0 (auto), 1 (group), 2 (site) or 3 (index tables)");
     c->scan_driver = mode;
     return M6A_OK;
 }
@@ -1082,6 +1259,15 @@ int64_t m6a_flush_groups(int64_t S, int64_t bs, int64_t spb, int64_t *group_off,
     if (cap < G + 1) return M6A_EINVAL;
     std::copy(g.begin(), g.end(), group_off);
     return G;
+}
+
+int64_t m6a_reference_written_sites(int64_t S, int64_t bs, int64_t spb)
+{
+    if (S < 0 || bs < 1 || spb < 1) return M6A_EINVAL;
+    const int64_t nb = (S + bs - 1) / bs;
+    for (int64_t b = nb - 1; b >= 0; b--)
+        if ((b + 1) % spb) return std::min((b + 1) * bs, S);     // the last batch that flushes (inference_utils.py:47)
+    return 0;
 }
 
 int m6a_shard_plan(const int64_t *off, int64_t S, int64_t bs, int64_t spb, int n_shards, int64_t *shard_off)

@@ -439,8 +439,14 @@ const char *m6a_io_kmer5(const m6a_sites *s, int64_t i) { return s->kmer5[(size_
 int m6a_io_write_csv(const m6a_sites *s, const char *out_dir, const float *read_prob, const float *site_prob,
                      const double *mod_ratio, int write_header, int n_threads)
 {
+    return m6a_io_write_csv_n(s, out_dir, read_prob, site_prob, mod_ratio, write_header, n_threads, -1);
+}
+
+int m6a_io_write_csv_n(const m6a_sites *s, const char *out_dir, const float *read_prob, const float *site_prob,
+                       const double *mod_ratio, int write_header, int n_threads, int64_t n_sites_limit)
+{
     if (!s || !out_dir || !read_prob || !site_prob || !mod_ratio) return fail(M6A_IO_EINVAL, "null argument");
-    const int64_t S = m6a_io_n_sites(s);
+    const int64_t S = n_sites_limit >= 0 ? std::min<int64_t>(n_sites_limit, m6a_io_n_sites(s)) : m6a_io_n_sites(s);
     const std::string fs = std::string(out_dir) + "/data.site_proba.csv", fi = std::string(out_dir) + "/data.indiv_proba.csv";
     FILE *f = fopen(fs.c_str(), write_header ? "w" : "a");
     if (!f) return fail(M6A_IO_EIO, "cannot open %s", fs.c_str());
@@ -452,7 +458,7 @@ int m6a_io_write_csv(const m6a_sites *s, const char *out_dir, const float *read_
     }
     // rows are formatted in parallel into per-chunk strings, written in order
     const int nw = n_workers(n_threads, S);
-    const int64_t R = m6a_io_n_reads(s);
+    const int64_t R = s->off[(size_t)S];
     int rc = 0;
     // one chunk per worker per round; chunks of at most 2^20 reads bound the text held in memory
     // (~64 MB per worker), at least 2^14 so tiny jobs do not spawn idle threads

@@ -12,6 +12,8 @@
 #define M6A_CSITE_MIN_BAG 16          // enc_csite_kernel: a 32-read tile must span <= 3 sites
 #define M6A_TABLE_MAX_N 32        // pool_table_kernel: byte offsets 8*idx must fit a byte; pool_reg_kernel: 32 register pairs
 #define M6A_REG_STACK 8           // pool_reg_kernel: merge stack entries held in registers
+#define M6A_RTAB_MAX_N 1024       // pool_rtab_kernel: bag sizes with an index table (u16 byte offsets, LDS bag)
+#define M6A_HIST_BINS (M6A_RTAB_MAX_N + 2)   // bag-size histogram: n = 0..1024, last bin = larger
 
 struct EncArgs {
     const float *X;               // [R][9]
@@ -51,6 +53,28 @@ struct PoolArgs {
     float thr;
 };
 
+// per-bag-size index tables (m6a_pool_rtab.hip): slot k holds C (accepted draws of the whole stream as u16 byte
+// offsets 4*v) and RS (number of accepted words before every 64-word block, n_blk + 1 entries)
+struct RtabBuild {
+    const uint32_t *raw;
+    uint32_t n_blk;               // stream blocks of 64 words covered by the tables
+    const int32_t *build_n;       // [n_build] bag sizes to build
+    const int32_t *build_slot;    // [n_build] their slots
+    uint16_t *C;
+    uint32_t *RS;
+    int64_t c_stride;             // entries per slot in C (= 64 * n_blk)
+};
+struct RtabUse {
+    const uint16_t *C;
+    const uint32_t *RS;
+    const int32_t *slot_of_n;     // [M6A_RTAB_MAX_N + 1]
+    uint32_t *rank;               // [S] rank of each site's first draw in its C row (0xffffffff: stream too short)
+    const uint32_t *order;        // [S] sites ordered by bag size
+    int64_t c_stride;
+    uint32_t n_blk;
+    int bag_cap;                  // floats of LDS bag per wavefront
+};
+
 __global__ void enc_kernel(EncArgs a);
 __global__ void enc_csite_kernel(EncArgs a);
 __global__ void pool_scan_start_kernel(PoolArgs a);
@@ -62,6 +86,14 @@ __global__ void bag_noisy_or_kernel(const float *read_prob, int64_t n_bags, int 
 __global__ void iota_off_kernel(int64_t *off, int64_t n_plus_1, int64_t step);
 __global__ void sampled_noisy_or_kernel(const float *read_prob, const int32_t *gidx, int64_t n_bags, int k, float *y);
 __global__ void mean_over_passes_kernel(const float *y, int n_iters, int64_t n_sites, float *avg);
-__global__ void bag_minmax_kernel(const int64_t *off, int64_t n_sites, unsigned long long *out);
+__global__ void bag_minmax_kernel(const int64_t *off, int64_t n_sites, unsigned long long *out, uint32_t *hist);
+__global__ void mt19937_kernel(uint32_t seed, int64_t n_words, uint32_t *raw);
+__global__ void rtab_count_kernel(RtabBuild a);
+__global__ void rtab_scan_kernel(RtabBuild a);
+__global__ void rtab_fill_kernel(RtabBuild a);
+__global__ void rtab_to_reg_table_kernel(const uint16_t *C, int64_t A, int64_t row_bytes, int jmax, uint8_t *tab);
+__global__ void rtab_chain_kernel(PoolArgs a, RtabUse u);
+__global__ void rtab_order_kernel(const int64_t *off, int64_t n_sites, uint32_t *cursor, uint32_t *order);
+template <int KT> __global__ void pool_rtab_kernel(PoolArgs a, RtabUse u);
 
 #endif

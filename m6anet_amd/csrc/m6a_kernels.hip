@@ -1099,16 +1099,21 @@ __global__ void iota_off_kernel(int64_t *off, int64_t n_plus_1, int64_t step)
 }
 
 // min / max bag size over all sites -> out[0], out[1] (initialised by the host to UINT64_MAX, 0);
-// out[2] = off[n_sites] (total reads).  One atomic pair per workgroup.
-__global__ __launch_bounds__(256) void bag_minmax_kernel(const int64_t *off, int64_t n_sites, unsigned long long *out)
+// out[2] = off[n_sites] (total reads); hist[n] += sites with n reads (n <= M6A_RTAB_MAX_N, the last bin takes
+// the larger ones; zeroed by the host).  One atomic pair + the touched bins per workgroup.
+__global__ __launch_bounds__(256) void bag_minmax_kernel(const int64_t *off, int64_t n_sites, unsigned long long *out, uint32_t *hist)
 {
     __shared__ int64_t s_mn[4], s_mx[4];
+    __shared__ uint32_t s_hist[M6A_HIST_BINS];
+    for (int i = threadIdx.x; i < M6A_HIST_BINS; i += 256) s_hist[i] = 0;
+    __syncthreads();
     int64_t mn = INT64_MAX, mx = 0;
     for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < n_sites;
          s += (int64_t)gridDim.x * blockDim.x) {
         const int64_t n = off[s + 1] - off[s];
         mn = n < mn ? n : mn;
         mx = n > mx ? n : mx;
+        atomicAdd(&s_hist[n < 0 ? 0 : n > M6A_RTAB_MAX_N ? M6A_RTAB_MAX_N + 1 : n], 1u);
     }
 #pragma unroll
     for (int m = 1; m < 64; m <<= 1) {
@@ -1118,6 +1123,8 @@ __global__ __launch_bounds__(256) void bag_minmax_kernel(const int64_t *off, int
     }
     if ((threadIdx.x & 63) == 0) { s_mn[threadIdx.x >> 6] = mn; s_mx[threadIdx.x >> 6] = mx; }
     __syncthreads();
+    for (int i = threadIdx.x; i < M6A_HIST_BINS; i += 256)
+        if (s_hist[i]) atomicAdd(&hist[i], s_hist[i]);
     if (threadIdx.x == 0) {
         for (int w = 1; w < 4; w++) { mn = s_mn[w] < mn ? s_mn[w] : mn; mx = s_mx[w] > mx ? s_mx[w] : mx; }
         atomicMin(&out[0], (unsigned long long)mn);

@@ -1,0 +1,373 @@
+// m6a_pool_rtab.hip -- site pooling for RAGGED bags through per-bag-size index tables, and the
+// device-side generators they stand on (MT19937 word stream, accepted-index compaction).
+//
+// What the reference does per site (m6anet/utils/inference_utils.py:85-86):
+//     proba = np.random.choice(proba, n_iters*n_samples, replace=True).reshape(n_iters, n_samples)
+//     (1 - np.prod(1 - proba, axis=1)).mean()
+// with every flush group's worker starting from the same seeded MT19937 state (:102-104), i.e. all
+// groups read ONE word stream `raw` from word 0, the sites of a group back to back, each by legacy
+// randint's masked rejection (v = w & mask; accept iff v < n).
+//
+// Whether a word is accepted depends only on (word, n).  So for every bag size n that occurs, the
+// accepted draws of the WHOLE stream are one fixed sequence
+//     C_n = [ w & mask_n  for w in raw  if (w & mask_n) < n ]
+// and a site of size n that starts at stream word p simply uses C_n[r .. r + T*K) with
+// r = rank_n(p) = #accepted words before p; it ends at the word after the (r + T*K - 1)-th accepted
+// one, where the group's next site starts.  That splits the job into
+//   rtab_count/scan/fill   C_n (as u16 byte offsets 4*v) + RS_n (rank at every 64-word block) for
+//                          each new bag size -- built once per (seed, T*K), kept across calls;
+//   rtab_chain_kernel      one wavefront per flush group walks its <= 32 sites: rank lookup, jump
+//                          T*K ranks ahead, select -- three dependent L2 round trips per site,
+//                          no stream scanning at all;
+//   pool_rtab_kernel       one wavefront per site, sites ordered by bag size (a table of 2-3 MB
+//                          stays in one XCD's L2 while its sites run): lane = iteration, a lane
+//                          loads its 20 indices as one 40-byte row, gathers 1-p from the LDS bag
+//                          (one ds_read_b32 per draw, no compaction, no ballots) and multiplies
+//                          left to right.  Bound: LDS gather rate under random bank conflicts.
+// The mean over iterations follows NumPy's pairwise sum exactly as the other pooling kernels do
+// (MeanPlan, m6a_api.hip): lane = accumulator chain (lane & 7) of leaf 8*pass + lane/8.
+#include "m6a_kernels.h"
+
+namespace {
+
+__device__ __forceinline__ uint32_t pow2_mask_u32(uint32_t rng)
+{
+    uint32_t mask = rng;
+    mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+    return mask;
+}
+
+__device__ __forceinline__ float chain8_sum_r(float r)
+{
+    r += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, r), 0xB1, 0xf, 0xf, false));
+    r += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, r), 0x4E, 0xf, 0xf, false));
+    r += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, r), 0x141, 0xf, 0xf, false));
+    return r;
+}
+
+__device__ __forceinline__ void wave_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+__device__ __forceinline__ int64_t uni64(int64_t v)
+{
+    return ((int64_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+
+}  // namespace
+
+// =====================================================================================
+// MT19937 raw word stream on the device: np.random.seed(int) == init_genrand == std::mt19937(seed)
+// (m6anet/scripts/inference.py:86).  The recurrence x[k+624] = x[k+397] ^ twist(x[k], x[k+1]) is
+// sequential over 624-word blocks but 227-wide inside one: new[0..227) needs only old words,
+// new[227..454) needs new[0..227), new[454..624) needs new[227..397) (and new[0] for the last
+// word).  One workgroup, two state buffers in LDS, three barriers per block.
+// =====================================================================================
+__device__ __forceinline__ uint32_t mt_twist(uint32_t a, uint32_t b)
+{
+    const uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
+    return (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+}
+
+__global__ __launch_bounds__(256) void mt19937_kernel(uint32_t seed, int64_t n_words, uint32_t *raw)
+{
+    __shared__ uint32_t st[2][624];
+    const int k = threadIdx.x;
+    if (k == 0) {
+        uint32_t x = seed;
+        st[0][0] = x;
+        for (uint32_t i = 1; i < 624; i++) { x = 1812433253u * (x ^ (x >> 30)) + i; st[0][i] = x; }
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int64_t base = 0; base < n_words; base += 624) {
+        const uint32_t *o = st[cur];
+        uint32_t *n = st[cur ^ 1];
+        if (k < 227) n[k] = o[k + 397] ^ mt_twist(o[k], o[k + 1]);
+        __syncthreads();
+        if (k < 227) { const int i = 227 + k; n[i] = n[i - 227] ^ mt_twist(o[i], o[i + 1]); }
+        __syncthreads();
+        if (k < 170) { const int i = 454 + k; n[i] = n[i - 227] ^ mt_twist(o[i], i == 623 ? n[0] : o[i + 1]); }
+        __syncthreads();
+        for (int i = k; i < 624; i += 256) {
+            uint32_t y = n[i];
+            y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
+            if (base + i < n_words) raw[base + i] = y;
+        }
+        cur ^= 1;
+    }
+}
+
+// =====================================================================================
+// Table build.  One wavefront = (one new bag size, one chunk of 16 blocks of 64 stream words).
+//   count: accepted words per block -> RS[slot][b]
+//   scan:  exclusive prefix per slot, total in RS[slot][n_blk]
+//   fill:  C[slot][RS[b] + rank] = 4 * (w & mask)     (byte offset into the float bag)
+// =====================================================================================
+#define RTAB_CHUNK 16
+
+__global__ __launch_bounds__(256) void rtab_count_kernel(RtabBuild a)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t chunk = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int n = a.build_n[blockIdx.y];
+    const int64_t slot = a.build_slot[blockIdx.y];
+    const uint32_t b0 = chunk * RTAB_CHUNK;
+    if (b0 >= a.n_blk) return;
+    const uint32_t mask = pow2_mask_u32((uint32_t)(n - 1));
+    uint32_t mine = 0;
+#pragma unroll
+    for (int i = 0; i < RTAB_CHUNK; i++) {
+        const uint32_t b = b0 + i;
+        uint32_t c = 0;
+        if (b < a.n_blk) {
+            const uint32_t w = a.raw[(int64_t)b * 64 + lane];
+            c = (uint32_t)__popcll(__ballot((w & mask) < (uint32_t)n));
+        }
+        if (lane == i) mine = c;
+    }
+    if (lane < RTAB_CHUNK && b0 + lane < a.n_blk) a.RS[slot * ((int64_t)a.n_blk + 1) + b0 + lane] = mine;
+}
+
+__global__ __launch_bounds__(256) void rtab_scan_kernel(RtabBuild a)
+{
+    __shared__ uint32_t s_part[256];
+    uint32_t *rs = a.RS + (int64_t)a.build_slot[blockIdx.x] * ((int64_t)a.n_blk + 1);
+    const uint32_t per = (a.n_blk + 255) / 256;
+    const uint32_t lo = threadIdx.x * per, hi = lo + per < a.n_blk ? lo + per : a.n_blk;
+    uint32_t sum = 0;
+    for (uint32_t b = lo; b < hi; b++) sum += rs[b];
+    s_part[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (int i = 0; i < 256; i++) { const uint32_t t = s_part[i]; s_part[i] = run; run += t; }
+        rs[a.n_blk] = run;
+    }
+    __syncthreads();
+    uint32_t run = s_part[threadIdx.x];
+    for (uint32_t b = lo; b < hi; b++) { const uint32_t t = rs[b]; rs[b] = run; run += t; }
+}
+
+__global__ __launch_bounds__(256) void rtab_fill_kernel(RtabBuild a)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t chunk = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int n = a.build_n[blockIdx.y];
+    const int64_t slot = a.build_slot[blockIdx.y];
+    const uint32_t b0 = chunk * RTAB_CHUNK;
+    if (b0 >= a.n_blk) return;
+    const uint32_t mask = pow2_mask_u32((uint32_t)(n - 1));
+    const uint32_t *rs = a.RS + slot * ((int64_t)a.n_blk + 1);
+    uint16_t *C = a.C + slot * a.c_stride;
+    uint32_t pre = 0;
+    if (lane < RTAB_CHUNK && b0 + lane < a.n_blk) pre = rs[b0 + lane];
+#pragma unroll
+    for (int i = 0; i < RTAB_CHUNK; i++) {
+        const uint32_t b = b0 + i;
+        if (b >= a.n_blk) break;
+        const uint32_t w = a.raw[(int64_t)b * 64 + lane];
+        const uint32_t v = w & mask;
+        const bool ok = v < (uint32_t)n;
+        const unsigned long long bal = __ballot(ok);
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0));
+        const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)pre, i);
+        if (ok) C[(int64_t)base + rank] = (uint16_t)(4u * v);
+    }
+}
+
+// accepted-index table of pool_reg_kernel from a C_n row: idx2[j][T+8][K] bytes = 2 * index, row j =
+// draws [j*T*K, (j+1)*T*K) of the stream (site j of every flush group of uniform bags)
+__global__ __launch_bounds__(256) void rtab_to_reg_table_kernel(const uint16_t *C, int64_t A, int64_t row_bytes, int jmax, uint8_t *tab)
+{
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= A * jmax) return;
+    const int64_t j = e / A, w = e - j * A;
+    tab[j * row_bytes + w] = (uint8_t)(C[e] >> 1);
+}
+
+// =====================================================================================
+// Where each site starts: one wavefront per flush group, its sites in order.
+//   rank r of the site's first draw in C_n  ->  rank_out[s]
+//   p' = (stream word of accepted draw number r + T*K - 1) + 1   -> next site
+// =====================================================================================
+__global__ __launch_bounds__(256) void rtab_chain_kernel(PoolArgs a, RtabUse u)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t n_waves = (int64_t)gridDim.x * 4;
+    const uint32_t A = (uint32_t)(a.T * a.K);
+    const uint32_t n_blk = u.n_blk;
+    for (int64_t g = (int64_t)blockIdx.x * 4 + uni((int)(threadIdx.x >> 6)); g < a.n_groups; g += n_waves) {
+        uint32_t p = 0;
+        const int64_t s_end = a.goff[g + 1];
+        for (int64_t s = a.goff[g]; s < s_end; ++s) {
+            const int64_t nn = a.off[s + 1] - a.off[s];
+            if (nn <= 1) { if (lane == 0) u.rank[s] = 0; continue; }     // randint(0,1) draws no words
+            const uint32_t n = (uint32_t)nn;
+            const int64_t slot = u.slot_of_n[n];
+            const uint32_t *rs = u.RS + slot * ((int64_t)n_blk + 1);
+            const uint32_t mask = pow2_mask_u32(n - 1);
+            const uint32_t total = rs[n_blk];
+            // rank of stream word p
+            uint32_t r;
+            {
+                const uint32_t b = p >> 6;
+                if (b >= n_blk) { if (lane == 0) { atomicExch(a.err, 1); } for (int64_t q = s; q < s_end; ++q) if (lane == 0) u.rank[q] = 0xffffffffu; break; }
+                const uint32_t w = a.raw[(int64_t)b * 64 + lane];
+                const unsigned long long bal = __ballot((w & mask) < n);
+                const unsigned long long below = (1ull << (p & 63)) - 1ull;
+                r = rs[b] + (uint32_t)__popcll(bal & below);
+            }
+            const uint64_t e64 = (uint64_t)r + A - 1;                   // rank of the site's last draw
+            if (e64 >= total) {                                         // the stream proved too short
+                if (lane == 0) atomicExch(a.err, 1);
+                for (int64_t q = s; q < s_end; ++q) if (lane == 0) u.rank[q] = 0xffffffffu;
+                break;
+            }
+            if (lane == 0) u.rank[s] = r;
+            const uint32_t e = (uint32_t)e64;
+            // block b2 with RS[b2] <= e < RS[b2+1]: linear guess, then a 64-entry window of the directory
+            uint32_t b0 = (uint32_t)(((uint64_t)e * n_blk) / total);
+            b0 = b0 > 32 ? b0 - 32 : 0;
+            uint32_t b2, rs_b2;
+            for (;;) {
+                if (b0 + 63 > n_blk) b0 = n_blk >= 63 ? n_blk - 63 : 0;
+                const uint32_t idx = b0 + lane;
+                const uint32_t v = idx <= n_blk ? rs[idx] : 0xffffffffu;
+                const int c = __popcll(__ballot(v <= e));               // a prefix of the lanes: RS is non-decreasing
+                if (c == 0) { b0 = b0 > 62 ? b0 - 62 : 0; continue; }   // b0 == 0 cannot get here: RS[0] = 0 <= e
+                if (c == 64) { b0 += 62; continue; }                    // e < total guarantees the search ends
+                b2 = b0 + (uint32_t)c - 1;
+                rs_b2 = (uint32_t)__builtin_amdgcn_readlane((int)v, c - 1);
+                break;
+            }
+            const uint32_t kth = e - rs_b2;                             // 0-based among block b2's accepted words
+            const uint32_t w2 = a.raw[(int64_t)b2 * 64 + lane];
+            const bool ok2 = (w2 & mask) < n;
+            const unsigned long long bal2 = __ballot(ok2);
+            const uint32_t rank2 = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal2, 0));
+            const unsigned long long hit = __ballot(ok2 && rank2 == kth);
+            p = uni((int)(b2 * 64 + (uint32_t)__builtin_ctzll(hit) + 1));
+        }
+    }
+}
+
+// sites ordered by bag size: cursor[n] starts at the exclusive prefix of the bag-size histogram
+__global__ __launch_bounds__(256) void rtab_order_kernel(const int64_t *off, int64_t n_sites, uint32_t *cursor, uint32_t *order)
+{
+    const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (s >= n_sites) return;
+    int64_t n = off[s + 1] - off[s];
+    n = n < 0 ? 0 : n > M6A_RTAB_MAX_N ? M6A_RTAB_MAX_N + 1 : n;
+    order[atomicAdd(&cursor[n], 1u)] = (uint32_t)s;
+}
+
+// =====================================================================================
+// The pooling proper: one wavefront per site.
+// =====================================================================================
+struct __attribute__((packed, aligned(2))) IdxRow20 { uint32_t w[10]; };
+
+template <int KT>
+__device__ __forceinline__ float rtab_product(const uint16_t *row, const char *bagb, int K)
+{
+    float prod = 1.0f;
+    if (KT == 20) {
+        const IdxRow20 r = *(const IdxRow20 *)row;
+        float g[20];
+#pragma unroll
+        for (int j = 0; j < 10; j++) {
+            g[2 * j] = *(const float *)(bagb + (r.w[j] & 0xffffu));
+            g[2 * j + 1] = *(const float *)(bagb + (r.w[j] >> 16));
+        }
+#pragma unroll
+        for (int k = 0; k < 20; k++) prod *= g[k];
+    } else {
+        for (int k = 0; k < K; k++) prod *= *(const float *)(bagb + row[k]);
+    }
+    return prod;
+}
+
+template <int KT>
+__global__ __launch_bounds__(256) void pool_rtab_kernel(PoolArgs a, RtabUse u)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int K = KT ? KT : a.K;
+    const int lane = threadIdx.x & 63, wib = uni((int)(threadIdx.x >> 6));
+    // per wave: bag | stage[8] leaf sums of a pass | tail[8] | merge stack
+    float *bag = smem + wib * (u.bag_cap + 16 + M6A_MEAN_STACK);
+    float *stage = bag + u.bag_cap, *tail = stage + 8, *stack = tail + 8;
+    // blockIdx -> position in the bag-size order, XCD-aware: workgroups go round-robin over the 8 XCDs, so XCD x
+    // walks the contiguous eighth x of the order and the tables of "its" bag sizes stay in its L2
+    const uint32_t chunk = gridDim.x >> 3;                 // gridDim.x is a multiple of 8
+    const int64_t si = ((int64_t)(blockIdx.x & 7) * chunk + (blockIdx.x >> 3)) * 4 + wib;
+    if (si >= a.n_sites) return;
+    const int64_t s = (int64_t)(uint32_t)uni((int)u.order[si]);
+    const int64_t r0 = uni64(a.off[s]);
+    const int n = uni((int)(a.off[s + 1] - r0));
+    int cge = 0;
+    for (int i = lane; i < n; i += 64) {
+        const float v = a.read_prob[r0 + i];
+        cge += (v >= a.thr) ? 1 : 0;
+        bag[i] = 1.0f - v;
+    }
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) cge += __shfl_xor(cge, m, 64);
+    if (lane == 0) a.mod_ratio[s] = n > 0 ? (double)cge / (double)n : __builtin_nan("");
+    if (n <= 0) { if (lane == 0) a.site_prob[s] = __builtin_nanf(""); return; }
+    const uint32_t rank = (uint32_t)uni((int)u.rank[s]);
+    if (rank == 0xffffffffu) return;                       // stream too short: the chain kernel raised the flag
+    wave_fence();
+    // bags of one read draw no words: slot 0 is a table of zeros (every draw is read 0)
+    const uint16_t *tb = n >= 2 ? u.C + (int64_t)u.slot_of_n[n] * u.c_stride + rank : u.C;
+    const char *bagb = (const char *)bag;
+    const int T = a.T;
+
+    // the last leaf's n % 8 tail iterations first; their values wait in LDS
+    if (a.n_rem) {
+        const int t = lane < a.n_rem ? T - a.n_rem + lane : 0;
+        const float v = 1.0f - rtab_product<KT>(tb + (int64_t)t * K, bagb, K);
+        if (lane < 8) tail[lane] = v;
+    }
+    int sp = 0;                                            // merge-stack height (lane 0's view)
+    const int n_pass = (a.n_leaves + 7) >> 3;
+    for (int ps = 0; ps < n_pass; ++ps) {
+        const int b = 8 * ps + (lane >> 3);
+        const bool has = b < a.n_leaves;
+        const int ls = has ? a.leaf_start[b] : 0;
+        const int my_rounds = has ? (a.leaf_start[b + 1] - ls) >> 3 : 0;
+        int rounds = my_rounds;
+#pragma unroll
+        for (int m = 8; m < 64; m <<= 1) { const int o = __shfl_xor(rounds, m, 64); rounds = o > rounds ? o : rounds; }
+        rounds = uni(rounds);
+        const uint16_t *row = tb + (int64_t)(ls + (lane & 7)) * K;
+        float sum = 0.0f;
+        for (int i = 0; i < rounds; ++i) {
+            const bool live = i < my_rounds;
+            const float v = 1.0f - rtab_product<KT>(live ? row : tb, bagb, K);
+            sum += live ? v : 0.0f;
+            row += 8 * K;
+        }
+        const float lsum = chain8_sum_r(sum);
+        if ((lane & 7) == 0) stage[lane >> 3] = lsum;
+        wave_fence();
+        if (lane == 0) {
+            const int nl = a.n_leaves - 8 * ps < 8 ? a.n_leaves - 8 * ps : 8;
+            for (int bl = 0; bl < nl; bl++) {
+                float x = stage[bl];
+                if (8 * ps + bl == a.n_leaves - 1)
+                    for (int i = 0; i < a.n_rem; i++) x += tail[i];
+                for (int m = a.merge_after[8 * ps + bl]; m > 0; --m) x = stack[--sp] + x;
+                stack[sp++] = x;
+            }
+        }
+        wave_fence();
+    }
+    if (lane == 0) a.site_prob[s] = stack[0] / (float)T;
+}
+
+template __global__ void pool_rtab_kernel<20>(PoolArgs, RtabUse);
+template __global__ void pool_rtab_kernel<0>(PoolArgs, RtabUse);

@@ -33,7 +33,7 @@ def my_shard(cuts, rank):
 
 class SiteGather:
     """The job's one exchange: every rank's (site_prob float32 [S_r], mod_ratio float64 [S_r]) to rank
-    `dst`, as ONE collective on a packed 12-byte-per-site buffer padded to the largest shard (so a
+    `dst`, as ONE collective on a packed 12-byte-per-site buffer (mod_ratio block, then site_prob block) padded to the largest shard (so a
     plain gather works for ragged cuts).  Double-buffered: `start()` may be called for the next step
     while the previous gather is still in flight (async_op), which lets the exchange of step i
     overlap the compute of step i+1; `finish()` waits and returns the tensors on rank `dst`."""
@@ -60,8 +60,10 @@ class SiteGather:
             self.work[k].wait()
         buf = self.send[k]
         assert site.numel() == self.n and mod.numel() == self.n
-        buf[:4 * self.n].view(self.torch.float32).copy_(site)
-        buf[4 * self.smax:4 * self.smax + 8 * self.n].view(self.torch.float64).copy_(mod)
+        # float64 block first: a .view(float64) needs a storage offset that is a multiple of 8, which
+        # 4 * smax is not when the largest shard has an odd site count
+        buf[:8 * self.n].view(self.torch.float64).copy_(mod)
+        buf[8 * self.smax:8 * self.smax + 4 * self.n].view(self.torch.float32).copy_(site)
         self.work[k] = self.dist.gather(buf, self.recv[k], dst=self.dst, group=self.group, async_op=True)
         self.slot ^= 1
         return k
@@ -76,9 +78,9 @@ class SiteGather:
         if self.rank != self.dst:
             return None, None
         t = self.torch
-        site = t.cat([self.recv[k][r][:4 * self.sizes[r]].view(t.float32) for r in range(self.world)])
-        mod = t.cat([self.recv[k][r][4 * self.smax:4 * self.smax + 8 * self.sizes[r]].view(t.float64)
-                     for r in range(self.world)])
+        mod = t.cat([self.recv[k][r][:8 * self.sizes[r]].view(t.float64) for r in range(self.world)])
+        site = t.cat([self.recv[k][r][8 * self.smax:8 * self.smax + 4 * self.sizes[r]].view(t.float32)
+                      for r in range(self.world)])
         return site, mod
 
     def drain(self):

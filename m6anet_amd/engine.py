@@ -258,6 +258,15 @@ def flush_groups(n_sites, batch_size=16, save_per_batch=2):
     return g[:G + 1].copy()
 
 
+def reference_written_sites(n_sites, batch_size=16, save_per_batch=2):
+    """How many (leading) sites the reference writes for this geometry: its inverted flush test
+    (inference_utils.py:47) never writes the batches after the last flush."""
+    n = _lib.load().m6a_reference_written_sites(int(n_sites), int(batch_size), int(save_per_batch))
+    if n < 0:
+        raise _lib.M6AError(int(n), "m6a_reference_written_sites")
+    return int(n)
+
+
 def shard_plan(off, n_shards, batch_size=16, save_per_batch=2):
     """Flush-group-aligned contiguous site shards balanced by read count -> int64 [n_shards+1]."""
     L = _lib.load()

@@ -10,13 +10,15 @@ CSVs are written once, in the reference's exact row formats:
 
 Deliberate divergence: the reference's inverted flush test (`if (it + 1) % save_per_batch`,
 inference_utils.py:47) never writes the batches after the last flush (every run with an even number
-of batches loses its final batch); every site is written here.
+of batches loses its final batch); every site is written here by default.  `--drop_unflushed_tail`
+(args.drop_unflushed_tail) is the reference-compatible mode: the CSVs then hold exactly the reference's rows.
 """
 import os
 
 import numpy as np
 
 from .constants import N_SAMPLES
+from .engine import reference_written_sites
 
 SITE_HEADER = "transcript_id,transcript_position,n_reads,probability_modified,kmer,mod_ratio\n"
 INDIV_HEADER = "transcript_id,transcript_position,read_index,probability_modified\n"
@@ -34,16 +36,17 @@ def calculate_site_proba(engine, read_probs, n_iters, n_samples=N_SAMPLES, n_pro
     return list(site)
 
 
-def format_site_rows(batch, site_prob, mod_ratio):
+def format_site_rows(batch, site_prob, mod_ratio, n_sites=None):
     n_reads = batch.n_reads
     return ["%s,%d,%s,%.16f,%s,%.16f\n" % (batch.tx_ids[s], batch.tx_pos[s], n_reads[s], site_prob[s],
-                                           batch.kmer5[s], mod_ratio[s]) for s in range(batch.n_sites)]
+                                           batch.kmer5[s], mod_ratio[s])
+            for s in range(batch.n_sites if n_sites is None else n_sites)]
 
 
-def format_indiv_rows(batch, read_prob):
+def format_indiv_rows(batch, read_prob, n_sites=None):
     rows = []
     off = batch.off
-    for s in range(batch.n_sites):
+    for s in range(batch.n_sites if n_sites is None else n_sites):
         tx, pos, ids = batch.tx_ids[s], batch.tx_pos[s], batch.read_ids[s]
         p = read_prob[off[s]:off[s + 1]]
         rows.extend("%s,%d,%s,%.16f\n" % (tx, pos, ids[i], p[i]) for i in range(len(ids)))
@@ -56,11 +59,14 @@ def run_inference(engine, batch, args):
     read_prob, site_prob, mod_ratio = engine.infer(
         batch.X, batch.site_kmers, batch.off, args.num_iterations, N_SAMPLES, args.read_proba_threshold,
         args.seed, args.batch_size, args.save_per_batch)
+    n_write = None
+    if getattr(args, "drop_unflushed_tail", False):       # the reference's row set (inference_utils.py:47)
+        n_write = reference_written_sites(batch.n_sites, args.batch_size, args.save_per_batch)
     if batch.native is not None:          # native writer: same bytes, formatted on all host threads
-        batch.native.write_csv(args.out_dir, read_prob, site_prob, mod_ratio, write_header=False)
+        batch.native.write_csv(args.out_dir, read_prob, site_prob, mod_ratio, write_header=False, n_sites=n_write)
         return read_prob, site_prob, mod_ratio
     with open(os.path.join(args.out_dir, "data.site_proba.csv"), "a", encoding="utf-8") as f:
-        f.writelines(format_site_rows(batch, site_prob, mod_ratio))
+        f.writelines(format_site_rows(batch, site_prob, mod_ratio, n_write))
     with open(os.path.join(args.out_dir, "data.indiv_proba.csv"), "a", encoding="utf-8") as g:
-        g.writelines(format_indiv_rows(batch, read_prob))
+        g.writelines(format_indiv_rows(batch, read_prob, n_write))
     return read_prob, site_prob, mod_ratio

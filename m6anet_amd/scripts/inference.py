@@ -6,7 +6,7 @@ import warnings
 from argparse import ArgumentDefaultsHelpFormatter, ArgumentParser
 
 from ..constants import (DEFAULT_MIN_READS, DEFAULT_PRETRAINED_MODEL, DEFAULT_PRETRAINED_MODELS,
-                         DEFAULT_READ_THRESHOLD, PRETRAINED_CONFIGS)
+                         DEFAULT_READ_THRESHOLD, N_WEIGHT_FLOATS, PRETRAINED_CONFIGS)
 from ..data_utils import load_sites, load_sites_native
 from ..engine import M6ANetEngine, load_weights, weights_from_state_dict
 from ..inference_utils import INDIV_HEADER, SITE_HEADER, run_inference
@@ -36,6 +36,9 @@ def argparser():
     parser.add_argument("--seed", default=0, type=int, help="random seed for sampling.")
     parser.add_argument("--read_proba_threshold", default=DEFAULT_READ_THRESHOLD, type=float,
                         help="default probability threshold for a read to be considered modified.")
+    parser.add_argument("--drop_unflushed_tail", action="store_true",
+                        help="reference-compatible output: omit the batches after the reference's last flush, which "
+                             "`m6anet inference` never writes (its flush test is inverted); default: write every site.")
     return parser
 
 
@@ -46,15 +49,35 @@ def _device_index(device):
     return int(d.split(":")[1]) if ":" in d else 0
 
 
+def _check_model_config(path):
+    """Only the m6anet.toml topology exists here (m6anet/model/configs/model_configs/m6anet.toml); any other
+    block list would silently run the wrong network."""
+    import tomli
+    with open(path, "rb") as f:
+        blocks = tomli.load(f).get("block", [])
+    want = ["DeaggregateNanopolish", "KmerMultipleEmbedding", "ConcatenateFeatures", "Linear", "Linear", "SigmoidProdPooling"]
+    got = [b.get("block_type") for b in blocks]
+    dims = [(b.get("input_channel"), b.get("output_channel")) for b in blocks if b.get("block_type") == "Linear"]
+    if got != want or dims != [(15, 150), (150, 32)]:
+        raise ValueError("--model_config %s is not the m6anet.toml topology (blocks %s): not supported" % (path, got))
+
+
 def main(args):
+    if not 0 <= int(args.seed) <= 0xffffffff:
+        raise ValueError("Seed must be between 0 and 2**32 - 1")        # what np.random.seed raises
+    if args.model_config is not None:
+        _check_model_config(args.model_config)
     if args.model_state_dict is not None:
         warnings.warn("--model_state_dict is specified, overwriting default model weights")
         if str(args.model_state_dict).endswith(".bin"):
             import numpy as np
             weights = np.fromfile(args.model_state_dict, np.float32)
+            if weights.size != N_WEIGHT_FLOATS:
+                raise ValueError("%s holds %d floats, expected %d (layout in include/m6a.h)"
+                                 % (args.model_state_dict, weights.size, N_WEIGHT_FLOATS))
         else:
             import torch
-            weights = weights_from_state_dict(torch.load(args.model_state_dict, map_location="cpu"))
+            weights = weights_from_state_dict(torch.load(args.model_state_dict, map_location="cpu", weights_only=True))
     else:
         if args.pretrained_model not in DEFAULT_PRETRAINED_MODELS:
             raise ValueError("Invalid pretrained model {}, must be one of {}".format(

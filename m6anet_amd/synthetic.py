@@ -12,11 +12,23 @@ from .constants import ALL_7MERS, kmer7_to_ids
 _IDS_288 = np.array([kmer7_to_ids(k) for k in ALL_7MERS], dtype=np.uint8)   # [288,3]
 
 
-def make_sites(n_sites, bag=20, seed=20250328, chunk_reads=1 << 22):
-    """Returns dict(X f32 [R,9], site_kmers u8 [S,3], off i64 [S+1])."""
+def bag_sizes(n_sites, bag=20, seed=20250328):
+    """int64 [n_sites] reads per site: fixed, or integers(lo, hi+1) for bag = (lo, hi)."""
+    if isinstance(bag, (tuple, list)):
+        g = np.random.Generator(np.random.PCG64([seed, 7]))
+        return g.integers(bag[0], bag[1] + 1, size=n_sites).astype(np.int64)
+    return np.full(n_sites, int(bag), np.int64)
+
+
+def make_sites(n_sites, bag=20, seed=20250328, chunk_reads=1 << 22, n_reads=None):
+    """Returns dict(X f32 [R,9], site_kmers u8 [S,3], off i64 [S+1]).  `n_reads` (int64 [n_sites])
+    fixes the bag sizes explicitly -- a rank's slice of a job-wide bag_sizes() array."""
     g = np.random.Generator(np.random.PCG64(seed))
     site_kmers = _IDS_288[g.integers(0, len(ALL_7MERS), size=n_sites)]
-    if isinstance(bag, (tuple, list)):
+    if n_reads is not None:
+        n_reads = np.ascontiguousarray(n_reads, np.int64)
+        assert n_reads.shape == (n_sites,)
+    elif isinstance(bag, (tuple, list)):
         n_reads = g.integers(bag[0], bag[1] + 1, size=n_sites).astype(np.int64)
     else:
         n_reads = np.full(n_sites, int(bag), np.int64)

@@ -21,7 +21,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, bag, out_path):
+def _worker(rank, world, port, bag, n_sites, out_path):
     sys.path.insert(0, REPO)
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import torch
@@ -30,7 +30,7 @@ def _worker(rank, world, port, bag, out_path):
     from oracle import m6a_oracle as orc
     r, w = mdist.init_from_env("gloo")
     assert (r, w) == (rank, world)
-    d = synthetic.make_sites(1500, bag, seed=4)          # every rank sees the same job description
+    d = synthetic.make_sites(n_sites, bag, seed=4)          # every rank sees the same job description
     weights = load_weights()
     thr = np.float32(0.033379376)
     cuts = mdist.shard_plan(d["off"], world)
@@ -54,9 +54,27 @@ def _worker(rank, world, port, bag, out_path):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("bag", [20, (20, 120)])
-def test_two_rank_shards_equal_the_whole_job(tmp_path, bag):
+# 1501 sites: the last shard is the larger one and has an odd site count (the packed gather buffer must
+# keep its float64 block 8-byte aligned)
+@pytest.mark.parametrize("bag,n_sites", [(20, 1500), ((20, 120), 1500), (20, 1501), ((20, 120), 1489)])
+def test_two_rank_shards_equal_the_whole_job(tmp_path, bag, n_sites):
     out = str(tmp_path / "res.npy")
-    mp.spawn(_worker, args=(2, _free_port(), bag, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), bag, n_sites, out), nprocs=2, join=True)
     ok, n, cut = np.load(out)
-    assert ok == 1 and n == 1500 and 0 < cut < 1500
+    assert ok == 1 and n == n_sites and 0 < cut < n_sites
+
+
+def test_site_gather_single_rank_odd_count():
+    """world = 1 with an odd site count: the float64 view of the packed buffer must stay aligned."""
+    import torch
+    import torch.distributed as dist
+    from m6anet_amd import dist as mdist
+    os.environ.update(RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    mdist.init_from_env("gloo")
+    try:
+        site = torch.arange(1009, dtype=torch.float32)
+        mod = torch.arange(1009, dtype=torch.float64) * 0.5
+        s_all, m_all = mdist.gather_sites(site, mod, np.array([0, 1009]))
+        assert torch.equal(s_all, site) and torch.equal(m_all, mod)
+    finally:
+        dist.destroy_process_group()

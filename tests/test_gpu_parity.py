@@ -4,9 +4,9 @@ oracle and the golden vectors captured from the reference.
 Tolerances (stated per assertion):
   * read probabilities: rtol=1e-5, atol=1e-8 -- the reference's own bar for
     data.indiv_proba.csv (m6anet/tests/test_inference.py:32, np.allclose defaults);
-  * site probabilities from identical read probabilities: 1e-6 abs (indices, product order and
-    product values are exact replays; only the float32 summation tree of the mean differs from
-    NumPy's pairwise order); north_star asks for 1e-5;
+  * site probabilities from identical read probabilities: BIT-exact (np.array_equal) -- indices are
+    exact replays of the NumPy stream, the 20-term product runs left to right like np.prod and the
+    mean follows ndarray.mean's float32 pairwise tree; north_star asks for 1e-5;
   * mod_ratio, flush groups, which sites get which draws: exact.
 """
 import numpy as np
@@ -222,10 +222,15 @@ def test_pool_scan_vs_oracle(eng, orc, bags):
     try:
         for T in (7, 100):
             want_site, want_mod = orc.site_pool(p, off, T, THR, seed=11)
-            for driver, name in ((1, "scan-group"), (2, "scan-site"), (0, None)):
+            for driver, name in ((1, "scan-group"), (2, "scan-site"), (3, "ragged-table"), (0, None)):
                 eng.set_scan_driver(driver)
+                if driver == 3 and max(bags) > 1024:          # index tables exist for bags of <= 1024 reads
+                    with pytest.raises(Exception, match="M6A_EUNSUPPORTED"):
+                        eng.calculate_site_proba(p, off, T, 20, THR, seed=11)
+                    continue
                 site, mod = eng.calculate_site_proba(p, off, T, 20, THR, seed=11)
-                assert eng.last_pool_variant == (name or eng.last_pool_variant) and eng.last_pool_variant.startswith("scan")
+                assert eng.last_pool_variant == (name or eng.last_pool_variant)
+                assert eng.last_pool_variant.startswith("scan") or eng.last_pool_variant == "ragged-table"
                 assert same_sites(site, want_site), (T, driver)
                 assert np.array_equal(mod, want_mod)
     finally:
@@ -239,7 +244,7 @@ def test_pool_other_sample_counts(eng, orc, K):
     p = rand_probs(K, off)
     want_site, want_mod = orc.site_pool(p, off, 50, THR, seed=5, n_samples=K)
     try:
-        for driver in (1, 2):
+        for driver in (1, 2, 3):
             eng.set_scan_driver(driver)
             site, mod = eng.calculate_site_proba(p, off, 50, K, THR, seed=5)
             assert same_sites(site, want_site), driver
@@ -260,15 +265,16 @@ def test_pool_mean_is_numpy_pairwise_sum(eng, orc, T):
         off = np.concatenate([[0], np.cumsum(bags)]).astype(np.int64)
         p = rand_probs(T + len(bags), off)
         want_site, want_mod = orc.site_pool(p, off, T, THR, seed=6)
-        for driver in (1, 2):                    # table: LDS / register kernel; scan: per group / per site
+        # table: LDS / register kernel; scan: per group / per site / per-bag-size index tables
+        for driver in (1, 2) if variant == "table" else (1, 2, 3):
             eng.set_scan_driver(driver)
-            eng.set_table_variant(driver)
+            eng.set_table_variant(min(driver, 2))
             try:
                 site, mod = eng.calculate_site_proba(p, off, T, 20, THR, seed=6)
             finally:
                 eng.set_scan_driver(0)
                 eng.set_table_variant(0)
-            assert eng.last_pool_variant.startswith(variant)
+            assert eng.last_pool_variant.startswith(variant if driver < 3 else "ragged-table")
             if variant == "table":
                 assert eng.last_pool_variant == TABLE_VARIANTS[driver - 1][1]
             assert same_sites(site, want_site), (T, bags[:3], driver, np.abs(site - want_site).max())
@@ -294,11 +300,16 @@ def test_pool_long_iterations(eng, orc, T):
     long replays in the scan kernels; 10000 is what the reference's own test uses.  Beyond 16384 the
     pairwise-sum tree is deeper than the register kernel's 8-entry stack: it must hand over to the LDS kernel."""
     S = 70 if T < 10000 else 40 if T < 16000 else 10
-    for bags, mode, variant in (([20] * S, 1, "table"), ([20] * S, 2, "table"), ([20, 27, 33, 64, 100] * (S // 5), 0, "scan")):
+    for bags, mode, variant in (([20] * S, 1, "table"), ([20] * S, 2, "table"), ([20, 27, 33, 64, 100] * (S // 5), 0, "scan"),
+                                ([20, 27, 33, 64, 100] * (S // 5), 3, "ragged-table")):
         off = np.concatenate([[0], np.cumsum(bags)]).astype(np.int64)
         p = rand_probs(T, off)
-        with table_variant(eng, mode):
-            site, mod = eng.calculate_site_proba(p, off, T, 20, THR, seed=2)
+        eng.set_scan_driver(mode if variant == "ragged-table" else 1 if variant == "scan" else 0)
+        try:
+            with table_variant(eng, mode if variant == "table" else 0):
+                site, mod = eng.calculate_site_proba(p, off, T, 20, THR, seed=2)
+        finally:
+            eng.set_scan_driver(0)
         assert eng.last_pool_variant.startswith(variant)
         want_site, want_mod = orc.site_pool(p, off, T, THR, seed=2, n_threads=8)
         assert same_sites(site, want_site), (T, variant, mode, eng.last_pool_variant)
@@ -340,7 +351,7 @@ def test_pool_uniform_random_configurations(eng, orc):
 
 def test_pool_ragged_random_configurations(eng, orc):
     """Random ragged jobs (bag sizes from 1 to a few thousand, mixed), iteration counts and batch geometry:
-    both scan drivers against the oracle, bit for bit."""
+    both scan drivers and the index-table kernel against the oracle, bit for bit."""
     g = np.random.Generator(np.random.PCG64(77))
     for _ in range(12):
         S = int(g.integers(2, 120))
@@ -359,14 +370,61 @@ def test_pool_ragged_random_configurations(eng, orc):
         p = rand_probs(seed % 997, off)
         want_site, want_mod = orc.site_pool(p, off, T, THR, seed=seed, batch_size=bs, save_per_batch=spb, n_threads=8)
         try:
-            for driver in (1, 2):
+            for driver in (1, 2, 3):
+                if driver == 3 and bags.max() > 1024:
+                    continue
                 eng.set_scan_driver(driver)
                 site, mod = eng.calculate_site_proba(p, off, T, 20, THR, seed=seed, batch_size=bs, save_per_batch=spb)
-                assert eng.last_pool_variant.startswith("scan")
+                assert eng.last_pool_variant.startswith("scan" if driver < 3 else "ragged-table")
                 assert same_sites(site, want_site), (S, kind, T, bs, spb, seed, driver)
                 assert np.array_equal(mod, want_mod), (S, kind, T, bs, spb, seed, driver)
         finally:
             eng.set_scan_driver(0)
+
+
+def test_pool_index_table_cache(eng, orc):
+    """The per-bag-size index tables are kept across calls: new bag sizes are added (the arena grows past its
+    first 32 slots), a new seed / iteration count / longer stream rebuilds them, and coming back gives the
+    same bits.  Every call is checked against the oracle."""
+    g = np.random.Generator(np.random.PCG64(5))
+
+    def run(bags, T, seed, bs=16, spb=2):
+        off = np.concatenate([[0], np.cumsum(bags)]).astype(np.int64)
+        p = rand_probs(int(off[-1]) % 1000, off)
+        site, mod = eng.calculate_site_proba(p, off, T, 20, THR, seed=seed, batch_size=bs, save_per_batch=spb)
+        assert eng.last_pool_variant == "ragged-table"
+        want_site, want_mod = orc.site_pool(p, off, T, THR, seed=seed, batch_size=bs, save_per_batch=spb, n_threads=8)
+        assert same_sites(site, want_site), (len(bags), T, seed, bs, spb)
+        assert np.array_equal(mod, want_mod)
+        return site
+
+    eng.set_scan_driver(3)
+    try:
+        few = list(g.integers(20, 30, size=150))                 # <= 10 bag sizes
+        many = list(g.integers(20, 140, size=400))               # ~120 bag sizes: the arena must grow, old slots survive
+        a = run(few, 100, 0)
+        run(many, 100, 0)
+        assert np.array_equal(run(few, 100, 0), a)
+        run(few + [1, 1, 2, 1024, 3], 100, 0)                    # bags of one read (no table), the largest size
+        run(many, 100, 12345)                                    # new seed: new stream, new tables
+        run(many, 37, 12345)                                     # new T*K
+        run(few, 100, 0, bs=40, spb=3)                           # larger flush groups: a longer stream
+        assert np.array_equal(run(few, 100, 0), a)
+    finally:
+        eng.set_scan_driver(0)
+
+
+def test_pool_auto_picks_tables_for_large_ragged_jobs(eng, orc):
+    bags = list(np.random.Generator(np.random.PCG64(8)).integers(20, 60, size=3000))
+    off = np.concatenate([[0], np.cumsum(bags)]).astype(np.int64)
+    p = rand_probs(3, off)
+    site, mod = eng.calculate_site_proba(p, off, 64, 20, THR, seed=21)
+    assert eng.last_pool_variant == "ragged-table"               # 3000 sites, 40 bag sizes: tables pay
+    want_site, want_mod = orc.site_pool(p, off, 64, THR, seed=21, n_threads=8)
+    assert same_sites(site, want_site) and np.array_equal(mod, want_mod)
+    site2, _ = eng.calculate_site_proba(p[:int(off[40])], off[:41], 64, 20, THR, seed=99)
+    assert eng.last_pool_variant.startswith("scan")              # 40 sites, new seed: replay the stream instead
+    assert same_sites(site2, orc.site_pool(p[:int(off[40])], off[:41], 64, THR, seed=99)[0])
 
 
 def test_pool_seeds_differ_and_repeat(eng):
@@ -423,7 +481,7 @@ def test_infer_end_to_end_vs_oracle(eng, orc, weights):
     assert np.abs(site - o_site).max() <= 1e-5
 
 
-@pytest.mark.parametrize("driver", [1, 2])
+@pytest.mark.parametrize("driver", [1, 2, 3])
 def test_infer_ragged_end_to_end_vs_oracle(engines, orc, weights, driver):
     d = synthetic.make_sites(600, (50, 500), seed=5)
     engines["hek293t_glori"].set_scan_driver(driver)
@@ -608,6 +666,49 @@ def test_full_size_properties(eng, orc, weights):
     closed = 1.0 - q ** 20
     assert np.abs(site - closed).mean() < 0.01
     # last site is written (the reference would drop the final batch when #batches is even)
+    assert site[-1] > 0
+
+
+def test_full_size_ragged_properties(engines, orc, weights):
+    """BASELINE.json configs[4], per-GPU shape (125k sites x 50..500 reads, HEK293T weights, T=1000):
+    the index-table kernel against the stream-replaying scan kernel on EVERY site (bit for bit), determinism,
+    and the oracle on sampled flush groups."""
+    import torch
+    eng = engines["hek293t_glori"]
+    S, T = 125_000, 1000
+    d = synthetic.make_sites(S, (50, 500), seed=20250328)
+    dev = torch.device("cuda:0")
+    X = torch.from_numpy(d["X"]).to(dev)
+    km = torch.from_numpy(d["site_kmers"]).to(dev)
+    off = torch.from_numpy(d["off"]).to(dev)
+    eng.use_torch_stream()
+    try:
+        rp, site, mod = eng.infer(X, km, off, T)
+        eng.sync()
+        assert eng.last_pool_variant == "ragged-table"
+        rp2, site2, mod2 = eng.infer(X, km, off, T)
+        eng.sync()
+        eng.set_scan_driver(1)
+        site3, mod3 = eng.calculate_site_proba(rp, off, T)
+        eng.sync()
+        assert eng.last_pool_variant == "scan-group"
+    finally:
+        eng.set_scan_driver(0)
+        eng.set_stream(None)
+    rp, site, mod = rp.cpu().numpy(), site.cpu().numpy(), mod.cpu().numpy()
+    assert np.array_equal(site, site2.cpu().numpy()) and np.array_equal(mod, mod2.cpu().numpy())
+    assert np.array_equal(site, site3.cpu().numpy()) and np.array_equal(mod, mod3.cpu().numpy())
+    assert np.all(np.isfinite(site)) and site.min() >= 0 and site.max() <= 1
+    g = np.random.Generator(np.random.PCG64(2))
+    o = d["off"]
+    for grp in [0, 1, (S - 16) // 32] + list(g.integers(2, (S - 16) // 32, size=12)):
+        a, b = (0, 16) if grp == 0 else (16 + 32 * (grp - 1), min(S, 16 + 32 * grp))
+        sl = slice(int(o[a]), int(o[b]))
+        p = orc.encode_reads(weights["hek293t_glori"], d["X"][sl], d["site_kmers"][a:b], o[a:b + 1] - o[a])
+        assert np.allclose(rp[sl], p, rtol=1e-5, atol=1e-8)
+        w_site, w_mod = orc.site_pool(rp[sl], o[a:b + 1] - o[a], T, THR, batch_size=b - a, save_per_batch=2)
+        assert same_sites(site[a:b], w_site)
+        assert np.array_equal(mod[a:b], w_mod)
     assert site[-1] > 0
 
 
