@@ -161,8 +161,9 @@ struct Cursor {
     // Correctly rounded decimal -> double, like Python's float().  (libstdc++ 11's
     // std::from_chars(double) switches locale under a global lock -- it serialises the worker
     // threads -- so: Clinger's exact fast path for <= 15 significant digits and |exp10| <= 22,
-    // glibc strtod_l on a cached "C" locale for everything else.  Every number in a dataprep
-    // record is followed by ',' or ']', so strtod never runs off the mapping.)
+    // glibc strtod_l on a cached "C" locale for everything else -- on a NUL-terminated copy of the
+    // token: the mapped file is not NUL-terminated, and only [0-9+-.eE] is a JSON / eventalign number
+    // (strtod alone would also take "inf", "nan" and hex floats).)
     bool num(double &v)
     {
         ws();
@@ -197,10 +198,19 @@ struct Cursor {
             return true;
         }
         static const locale_t c_loc = newlocale(LC_ALL_MASK, "C", (locale_t)0);
+        char tok[96];
+        size_t len = 0;
+        for (const char *t = p; t < e && len + 1 < sizeof tok; ++t, ++len) {
+            const char ch = *t;
+            if (!((ch >= '0' && ch <= '9') || ch == '+' || ch == '-' || ch == '.' || ch == 'e' || ch == 'E')) break;
+            tok[len] = ch;
+        }
+        tok[len] = 0;
+        if (len == 0 || len + 1 >= sizeof tok) return false;
         char *end = nullptr;
-        v = strtod_l(p, &end, c_loc);
-        if (end == p || end > e) return false;
-        p = end;
+        v = strtod_l(tok, &end, c_loc);
+        if (end == tok) return false;
+        p += end - tok;
         return true;
     }
 };
@@ -757,7 +767,7 @@ extern "C" int m6a_io_dataprep(const char *eventalign_path, const char *out_dir,
     // ---- per transcript: combine -> window -> DRACH filter -> group by position (parallel_preprocess_tx + preprocess_tx)
     const int64_t NT = (int64_t)tx_order.size();
     std::vector<TxOut> outs((size_t)NT);
-    std::vector<char> wanted((size_t)NT, 0);
+    std::vector<char> wanted((size_t)NT, 0), logged((size_t)NT, 0);
     auto do_tx = [&](int64_t ti) {
         TxOut &o = outs[(size_t)ti];
         const std::string &tx = tx_order[(size_t)ti];
@@ -806,7 +816,8 @@ extern "C" int m6a_io_dataprep(const char *eventalign_path, const char *out_dir,
                 a = b;
             }
         }
-        if (sites.empty()) return;
+        if (sites.empty()) return;                        // preprocess_tx returns before its log line (dataprep_utils.py:415,431)
+        logged[(size_t)ti] = 1;
         // reference: np.argsort(positions) (unstable, machine-dependent order inside a position);
         // here: stable, i.e. reads stay in index order inside a position
         std::stable_sort(sites.begin(), sites.end(), [](const SiteRow &x, const SiteRow &y) { return x.pos < y.pos; });
@@ -867,7 +878,8 @@ extern "C" int m6a_io_dataprep(const char *eventalign_path, const char *out_dir,
         for (const auto &r : o.recs)
             fprintf(fi, "%s,%lld,%lld,%lld,%lld\n", tx_order[(size_t)t].c_str(), r[0], off + r[1], off + r[1] + r[2], r[3]);
         off += (long long)o.json.size();
-        fprintf(fl, "%s: Data preparation ... Done.\n", tx_order[(size_t)t].c_str());   // every processed transcript is logged
+        // logged like the reference: only transcripts that yielded at least one DRACH window (dataprep_utils.py:415,431,472)
+        if (logged[(size_t)t]) fprintf(fl, "%s: Data preparation ... Done.\n", tx_order[(size_t)t].c_str());
     }
     int bad = 0;
     bad |= fclose(fj); bad |= fclose(fi); bad |= fclose(fl);

@@ -203,33 +203,34 @@ __global__ __launch_bounds__(256) void rtab_chain_kernel(PoolArgs a, RtabUse u)
     const uint32_t n_blk = u.n_blk;
     for (int64_t g = (int64_t)blockIdx.x * 4 + uni((int)(threadIdx.x >> 6)); g < a.n_groups; g += n_waves) {
         uint32_t p = 0;
-        const int64_t s_end = a.goff[g + 1];
-        for (int64_t s = a.goff[g]; s < s_end; ++s) {
-            const int64_t nn = a.off[s + 1] - a.off[s];
-            if (nn <= 1) { if (lane == 0) u.rank[s] = 0; continue; }     // randint(0,1) draws no words
-            const uint32_t n = (uint32_t)nn;
-            const int64_t slot = u.slot_of_n[n];
-            const uint32_t *rs = u.RS + slot * ((int64_t)n_blk + 1);
+        const int64_t s_beg = a.goff[g], s_end = a.goff[g + 1];
+        uint32_t w = a.raw[lane];                     // the stream block that holds word p
+        uint32_t w_blk = 0;
+        int64_t nn = s_beg < s_end ? a.off[s_beg + 1] - a.off[s_beg] : 0;
+        for (int64_t s = s_beg; s < s_end; ++s) {
+            const int64_t n_this = nn;
+            if (s + 1 < s_end) nn = a.off[s + 2] - a.off[s + 1];         // next site's size: off the critical path
+            if (n_this <= 1) { if (lane == 0) u.rank[s] = 0; continue; }  // randint(0,1) draws no words
+            const uint32_t n = (uint32_t)n_this;
+            const uint32_t *rs = u.RS + (int64_t)u.slot_of_n[n] * ((int64_t)n_blk + 1);
             const uint32_t mask = pow2_mask_u32(n - 1);
             const uint32_t total = rs[n_blk];
-            // rank of stream word p
-            uint32_t r;
-            {
-                const uint32_t b = p >> 6;
-                if (b >= n_blk) { if (lane == 0) { atomicExch(a.err, 1); } for (int64_t q = s; q < s_end; ++q) if (lane == 0) u.rank[q] = 0xffffffffu; break; }
-                const uint32_t w = a.raw[(int64_t)b * 64 + lane];
+            // rank of stream word p: directory entry of its block + the accepted words of the block before p
+            const uint32_t b = p >> 6;
+            bool short_stream = b >= n_blk;
+            uint32_t r = 0;
+            if (!short_stream) {
+                if (b != w_blk) { w = a.raw[(int64_t)b * 64 + lane]; w_blk = b; }
                 const unsigned long long bal = __ballot((w & mask) < n);
-                const unsigned long long below = (1ull << (p & 63)) - 1ull;
-                r = rs[b] + (uint32_t)__popcll(bal & below);
+                r = rs[b] + (uint32_t)__popcll(bal & ((1ull << (p & 63)) - 1ull));
+                short_stream = (uint64_t)r + A - 1 >= total;
             }
-            const uint64_t e64 = (uint64_t)r + A - 1;                   // rank of the site's last draw
-            if (e64 >= total) {                                         // the stream proved too short
-                if (lane == 0) atomicExch(a.err, 1);
-                for (int64_t q = s; q < s_end; ++q) if (lane == 0) u.rank[q] = 0xffffffffu;
+            if (short_stream) {                                         // the stream proved too short
+                if (lane == 0) { atomicExch(a.err, 1); for (int64_t q = s; q < s_end; ++q) u.rank[q] = 0xffffffffu; }
                 break;
             }
             if (lane == 0) u.rank[s] = r;
-            const uint32_t e = (uint32_t)e64;
+            const uint32_t e = r + A - 1;                               // rank of the site's last draw
             // block b2 with RS[b2] <= e < RS[b2+1]: linear guess, then a 64-entry window of the directory
             uint32_t b0 = (uint32_t)(((uint64_t)e * n_blk) / total);
             b0 = b0 > 32 ? b0 - 32 : 0;
@@ -246,24 +247,36 @@ __global__ __launch_bounds__(256) void rtab_chain_kernel(PoolArgs a, RtabUse u)
                 break;
             }
             const uint32_t kth = e - rs_b2;                             // 0-based among block b2's accepted words
-            const uint32_t w2 = a.raw[(int64_t)b2 * 64 + lane];
-            const bool ok2 = (w2 & mask) < n;
+            if (b2 != w_blk) { w = a.raw[(int64_t)b2 * 64 + lane]; w_blk = b2; }
+            const bool ok2 = (w & mask) < n;
             const unsigned long long bal2 = __ballot(ok2);
             const uint32_t rank2 = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal2, 0));
             const unsigned long long hit = __ballot(ok2 && rank2 == kth);
-            p = uni((int)(b2 * 64 + (uint32_t)__builtin_ctzll(hit) + 1));
+            p = (uint32_t)uni((int)(b2 * 64 + (uint32_t)__builtin_ctzll(hit) + 1));
         }
     }
 }
 
-// sites ordered by bag size: cursor[n] starts at the exclusive prefix of the bag-size histogram
+// sites ordered by bag size: cursor[n] starts at the exclusive prefix of the bag-size histogram.  A workgroup
+// counts its 256 sites in LDS first and takes ONE global slot range per bag size it holds (uniform bags would
+// otherwise serialise every site on a single atomic).
 __global__ __launch_bounds__(256) void rtab_order_kernel(const int64_t *off, int64_t n_sites, uint32_t *cursor, uint32_t *order)
 {
+    __shared__ uint32_t s_cnt[M6A_HIST_BINS], s_base[M6A_HIST_BINS];
+    for (int i = threadIdx.x; i < M6A_HIST_BINS; i += 256) s_cnt[i] = 0;
+    __syncthreads();
     const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (s >= n_sites) return;
-    int64_t n = off[s + 1] - off[s];
-    n = n < 0 ? 0 : n > M6A_RTAB_MAX_N ? M6A_RTAB_MAX_N + 1 : n;
-    order[atomicAdd(&cursor[n], 1u)] = (uint32_t)s;
+    int64_t n = 0;
+    uint32_t mine = 0;
+    if (s < n_sites) {
+        n = off[s + 1] - off[s];
+        n = n < 0 ? 0 : n > M6A_RTAB_MAX_N ? M6A_RTAB_MAX_N + 1 : n;
+        mine = atomicAdd(&s_cnt[n], 1u);
+    }
+    __syncthreads();
+    if (s < n_sites && mine == 0) s_base[n] = atomicAdd(&cursor[n], s_cnt[n]);
+    __syncthreads();
+    if (s < n_sites) order[s_base[n] + mine] = (uint32_t)s;
 }
 
 // =====================================================================================
@@ -271,23 +284,25 @@ __global__ __launch_bounds__(256) void rtab_order_kernel(const int64_t *off, int
 // =====================================================================================
 struct __attribute__((packed, aligned(2))) IdxRow20 { uint32_t w[10]; };
 
-template <int KT>
-__device__ __forceinline__ float rtab_product(const uint16_t *row, const char *bagb, int K)
+// the K draws of one iteration: gather 1-p at the row's byte offsets, multiply left to right (np.prod's order)
+__device__ __forceinline__ float rtab_product20(const IdxRow20 &r, const char *bagb)
+{
+    float g[20];
+#pragma unroll
+    for (int j = 0; j < 10; j++) {
+        g[2 * j] = *(const float *)(bagb + (r.w[j] & 0xffffu));
+        g[2 * j + 1] = *(const float *)(bagb + (r.w[j] >> 16));
+    }
+    float prod = 1.0f;
+#pragma unroll
+    for (int k = 0; k < 20; k++) prod *= g[k];
+    return prod;
+}
+
+__device__ __forceinline__ float rtab_product_any(const uint16_t *row, const char *bagb, int K)
 {
     float prod = 1.0f;
-    if (KT == 20) {
-        const IdxRow20 r = *(const IdxRow20 *)row;
-        float g[20];
-#pragma unroll
-        for (int j = 0; j < 10; j++) {
-            g[2 * j] = *(const float *)(bagb + (r.w[j] & 0xffffu));
-            g[2 * j + 1] = *(const float *)(bagb + (r.w[j] >> 16));
-        }
-#pragma unroll
-        for (int k = 0; k < 20; k++) prod *= g[k];
-    } else {
-        for (int k = 0; k < K; k++) prod *= *(const float *)(bagb + row[k]);
-    }
+    for (int k = 0; k < K; k++) prod *= *(const float *)(bagb + row[k]);
     return prod;
 }
 
@@ -308,17 +323,30 @@ __global__ __launch_bounds__(256) void pool_rtab_kernel(PoolArgs a, RtabUse u)
     const int64_t s = (int64_t)(uint32_t)uni((int)u.order[si]);
     const int64_t r0 = uni64(a.off[s]);
     const int n = uni((int)(a.off[s + 1] - r0));
+    const uint32_t rank = (uint32_t)uni((int)u.rank[s]);
+    // first pass of the pairwise-sum plan: which leaf and chain this lane is (its loads overlap the bag's)
+    const int b0 = lane >> 3;
+    const bool has0 = b0 < a.n_leaves;
+    const int ls0 = has0 ? a.leaf_start[b0] : 0;
+    const int le0 = has0 ? a.leaf_start[b0 + 1] : 0;
+    if (n <= 0) { if (lane == 0) { a.mod_ratio[s] = __builtin_nan(""); a.site_prob[s] = __builtin_nanf(""); } return; }
+    // the bag: 1-p into LDS, four loads in flight per lane (unconditional: lanes past the end re-read the last
+    // read); p >= thr counted on the way (mod_ratio, inference_utils.py:53)
     int cge = 0;
-    for (int i = lane; i < n; i += 64) {
-        const float v = a.read_prob[r0 + i];
-        cge += (v >= a.thr) ? 1 : 0;
-        bag[i] = 1.0f - v;
+    for (int i0 = 0; i0 < n; i0 += 256) {
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) { const int i = i0 + 64 * j + lane; v[j] = a.read_prob[r0 + (i < n ? i : n - 1)]; }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int i = i0 + 64 * j + lane;
+            cge += (v[j] >= a.thr && i < n) ? 1 : 0;
+            if (i < n) bag[i] = 1.0f - v[j];
+        }
     }
 #pragma unroll
     for (int m = 1; m < 64; m <<= 1) cge += __shfl_xor(cge, m, 64);
-    if (lane == 0) a.mod_ratio[s] = n > 0 ? (double)cge / (double)n : __builtin_nan("");
-    if (n <= 0) { if (lane == 0) a.site_prob[s] = __builtin_nanf(""); return; }
-    const uint32_t rank = (uint32_t)uni((int)u.rank[s]);
+    if (lane == 0) a.mod_ratio[s] = (double)cge / (double)n;
     if (rank == 0xffffffffu) return;                       // stream too short: the chain kernel raised the flag
     wave_fence();
     // bags of one read draw no words: slot 0 is a table of zeros (every draw is read 0)
@@ -329,7 +357,8 @@ __global__ __launch_bounds__(256) void pool_rtab_kernel(PoolArgs a, RtabUse u)
     // the last leaf's n % 8 tail iterations first; their values wait in LDS
     if (a.n_rem) {
         const int t = lane < a.n_rem ? T - a.n_rem + lane : 0;
-        const float v = 1.0f - rtab_product<KT>(tb + (int64_t)t * K, bagb, K);
+        const uint16_t *row = tb + (int64_t)t * K;
+        const float v = 1.0f - (KT == 20 ? rtab_product20(*(const IdxRow20 *)row, bagb) : rtab_product_any(row, bagb, K));
         if (lane < 8) tail[lane] = v;
     }
     int sp = 0;                                            // merge-stack height (lane 0's view)
@@ -337,19 +366,36 @@ __global__ __launch_bounds__(256) void pool_rtab_kernel(PoolArgs a, RtabUse u)
     for (int ps = 0; ps < n_pass; ++ps) {
         const int b = 8 * ps + (lane >> 3);
         const bool has = b < a.n_leaves;
-        const int ls = has ? a.leaf_start[b] : 0;
-        const int my_rounds = has ? (a.leaf_start[b + 1] - ls) >> 3 : 0;
+        const int ls = ps == 0 ? ls0 : has ? a.leaf_start[b] : 0;
+        const int le = ps == 0 ? le0 : has ? a.leaf_start[b + 1] : 0;
+        const int my_rounds = (le - ls) >> 3;
         int rounds = my_rounds;
 #pragma unroll
         for (int m = 8; m < 64; m <<= 1) { const int o = __shfl_xor(rounds, m, 64); rounds = o > rounds ? o : rounds; }
         rounds = uni(rounds);
+        // merges that follow each of the pass's leaves: 8 bytes of the plan, scalar loads (uniform address)
+        const uint32_t mw0 = ((const uint32_t *)a.merge_after)[2 * ps], mw1 = ((const uint32_t *)a.merge_after)[2 * ps + 1];
         const uint16_t *row = tb + (int64_t)(ls + (lane & 7)) * K;
+        const int64_t step = (int64_t)8 * K;
         float sum = 0.0f;
-        for (int i = 0; i < rounds; ++i) {
-            const bool live = i < my_rounds;
-            const float v = 1.0f - rtab_product<KT>(live ? row : tb, bagb, K);
-            sum += live ? v : 0.0f;
-            row += 8 * K;
+        if (KT == 20) {
+            // the index row of round i+1 is in flight while round i gathers and multiplies
+            IdxRow20 nxt = *(const IdxRow20 *)(my_rounds > 0 ? row : tb);
+            for (int i = 0; i < rounds; ++i) {
+                const IdxRow20 cur = nxt;
+                const bool live = i < my_rounds;
+                row += step;
+                nxt = *(const IdxRow20 *)(i + 1 < my_rounds ? row : tb);
+                const float v = 1.0f - rtab_product20(cur, bagb);
+                sum += live ? v : 0.0f;
+            }
+        } else {
+            for (int i = 0; i < rounds; ++i) {
+                const bool live = i < my_rounds;
+                const float v = 1.0f - rtab_product_any(live ? row : tb, bagb, K);
+                sum += live ? v : 0.0f;
+                row += step;
+            }
         }
         const float lsum = chain8_sum_r(sum);
         if ((lane & 7) == 0) stage[lane >> 3] = lsum;
@@ -360,7 +406,8 @@ __global__ __launch_bounds__(256) void pool_rtab_kernel(PoolArgs a, RtabUse u)
                 float x = stage[bl];
                 if (8 * ps + bl == a.n_leaves - 1)
                     for (int i = 0; i < a.n_rem; i++) x += tail[i];
-                for (int m = a.merge_after[8 * ps + bl]; m > 0; --m) x = stack[--sp] + x;
+                const uint32_t mw = bl < 4 ? mw0 : mw1;
+                for (int m = (int)((mw >> (8 * (bl & 3))) & 0xffu); m > 0; --m) x = stack[--sp] + x;
                 stack[sp++] = x;
             }
         }

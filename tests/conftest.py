@@ -14,6 +14,24 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """Plain `pytest` on a box without an MI355X: skip the gpu-marked tests instead of erroring in their fixtures
+    (M6A_ENODEV).  `-m gpu` (the GPU box) keeps them, so a missing device or library still fails loudly there."""
+    if "gpu" in (config.getoption("-m") or ""):
+        return
+    try:
+        import torch
+        have = torch.cuda.is_available()
+    except Exception:
+        have = False
+    if have:
+        return
+    skip = pytest.mark.skip(reason="no HIP device visible (run with -m gpu on an MI355X)")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
 @pytest.fixture(scope="session")
 def golden():
     def load(name):

@@ -104,3 +104,23 @@ def test_synthetic_generator_is_deterministic():
     assert all(np.array_equal(a[k], b[k]) for k in a)
     assert a["X"].dtype == np.float32 and np.abs(a["X"]).max() <= 6.0
     assert a["site_kmers"].max() < 66 and a["off"][0] == 0 and np.diff(a["off"]).min() >= 50
+
+
+def test_reference_written_sites_matches_the_reference_runs(golden):
+    """m6a_reference_written_sites against the rows six real `m6anet inference` runs wrote (the `_written` masks
+    captured by tests/golden/make_golden.py): the reference writes a prefix of the sites -- everything up to its
+    last flush (m6anet/utils/inference_utils.py:47)."""
+    import re
+    g = golden("bundled_site.npz")
+    keys = [k for k in g.files if k.endswith("_written")]
+    assert len(keys) >= 6
+    for k in keys:
+        bs, spb = (int(x) for x in re.match(r"T\d+_bs(\d+)_spb(\d+)_", k).groups())
+        mask = g[k].astype(bool)
+        n = engine.reference_written_sites(mask.size, bs, spb)
+        assert np.array_equal(mask, np.arange(mask.size) < n), (k, n, int(mask.sum()))
+    assert engine.reference_written_sites(101, 51, 2) == 51          # SURVEY section 0.4: batch 51 -> 51 of 101
+    assert engine.reference_written_sites(101, 26, 2) == 78
+    assert engine.reference_written_sites(101, 16, 2) == 101
+    assert engine.reference_written_sites(0, 16, 2) == 0
+    assert engine.reference_written_sites(32, 16, 1) == 0            # save_per_batch 1: the reference never flushes

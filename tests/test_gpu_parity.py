@@ -804,6 +804,66 @@ def test_cli_reference_test_suite_bar(tmp_path):
     assert np.allclose(gs["probability_modified"], ts["probability_modified"], atol=1e-2)
 
 
+def test_cli_replicates_match_reference_csvs(tmp_path):
+    """Replicate inference on the GPU (m6anet/tests/test_inference.py:40-82; NanopolishReplicateDS,
+    m6anet/utils/data_utils.py:293-427): two input directories -> pooled bags, `<read>_<replicate>` ids.
+    Against the CSVs the reference wrote for the same two directories (tests/golden/replicate_*.csv, T=5,
+    n_processes=1): ids and suffixes exact, read probabilities rtol 1e-5, site probabilities <= 1e-5,
+    mod_ratio exact."""
+    import gzip
+    import os
+    import shutil
+    import pandas as pd
+    from m6anet_amd.__main__ import main
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    data = os.path.join(gold, "ref_tests_data")
+    rep = tmp_path / "rep1"
+    rep.mkdir()
+    for fn in ("data.info", "data.json"):
+        shutil.copyfile(os.path.join(data, fn), rep / fn)
+    out = str(tmp_path / "out")
+    main(["inference", "--input_dir", data, str(rep), "--out_dir", out, "--n_processes", "1", "--num_iterations", "5"])
+    site = pd.read_csv(os.path.join(out, "data.site_proba.csv"))
+    ref_site = pd.read_csv(os.path.join(gold, "replicate_site_proba.csv"))
+    assert list(site.columns) == list(ref_site.columns) and len(site) == len(ref_site)
+    for col in ("transcript_id", "transcript_position", "n_reads", "kmer"):
+        assert (site[col] == ref_site[col]).all(), col
+    assert np.array_equal(site["mod_ratio"], ref_site["mod_ratio"])
+    assert np.abs(site["probability_modified"] - ref_site["probability_modified"]).max() <= 1e-5
+    ours = open(os.path.join(out, "data.indiv_proba.csv")).read().splitlines()
+    ref = gzip.open(os.path.join(gold, "replicate_indiv_proba.csv.gz"), "rt").read().splitlines()
+    assert len(ours) == len(ref) and ours[0] == ref[0]
+    ids_ours = [r.rsplit(",", 1)[0] for r in ours[1:]]
+    assert ids_ours == [r.rsplit(",", 1)[0] for r in ref[1:]]                      # `966210_0` / `966210_1` exact
+    assert {i.rsplit("_", 1)[1] for i in ids_ours} == {"0", "1"}
+    pa = np.array([float(r.rsplit(",", 1)[1]) for r in ours[1:]])
+    pb = np.array([float(r.rsplit(",", 1)[1]) for r in ref[1:]])
+    assert np.allclose(pa, pb, rtol=1e-5, atol=1e-8)
+
+
+@pytest.mark.parametrize("T,bs,spb,seed", [(30, 51, 2, 0), (50, 8, 3, 0), (20, 13, 2, 7)])
+def test_cli_drop_unflushed_tail_writes_the_reference_row_set(tmp_path, golden, T, bs, spb, seed):
+    """--drop_unflushed_tail: exactly the rows the reference wrote for this geometry (its inverted flush test,
+    m6anet/utils/inference_utils.py:47, loses the batches after the last flush -- batch 51 writes 51 of the 101
+    sites), with the reference's values; without the flag every site is written."""
+    import os
+    import pandas as pd
+    g = golden("bundled_site.npz")
+    key = "T%d_bs%d_spb%d_seed%d" % (T, bs, spb, seed)
+    written = g[key + "_written"].astype(bool)
+    args = ["--num_iterations", str(T), "--batch_size", str(bs), "--save_per_batch", str(spb), "--seed", str(seed)]
+    out = _run_cli(tmp_path, args + ["--drop_unflushed_tail"])
+    site = pd.read_csv(os.path.join(out, "data.site_proba.csv"))
+    n = int(written.sum())
+    assert len(site) == n and written[:n].all() and not written[n:].any()
+    assert np.abs(site["probability_modified"].values - g[key + "_site"][:n]).max() <= 1e-5
+    assert np.array_equal(site["mod_ratio"].values, g[key + "_mod"][:n])
+    indiv = pd.read_csv(os.path.join(out, "data.indiv_proba.csv"))
+    assert len(indiv) == int(site["n_reads"].sum())
+    full = pd.read_csv(os.path.join(_run_cli(tmp_path / "all", args), "data.site_proba.csv"))
+    assert len(full) == 101 and full.iloc[:n].equals(site)
+
+
 def test_cli_rejects_cpu_device(tmp_path):
     with pytest.raises(ValueError):
         _run_cli(tmp_path, ["--device", "cpu"])
