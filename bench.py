@@ -256,7 +256,12 @@ def main():
     mod = torch.empty(Sr, dtype=torch.float64, device=dev)
     # the job's one exchange: site_prob + mod_ratio to rank 0, one packed gather per step (RCCL);
     # issued async and double-buffered so the exchange of step i overlaps the compute of step i+1
-    gather = mdist.SiteGather(cuts, dev if backend == "nccl" else "cpu", dst=0) if world > 1 else None
+    # (M6A_BENCH_GATHER=native: the same exchange on the C ABI's own RCCL communicator, m6a_gather)
+    native_gather = os.environ.get("M6A_BENCH_GATHER", "torch") == "native" and backend == "nccl"
+    if world > 1 and native_gather:
+        gather = mdist.NativeGather(eng, cuts, dev, dst=0)
+    else:
+        gather = mdist.SiteGather(cuts, dev if backend == "nccl" else "cpu", dst=0) if world > 1 else None
 
     def step():
         eng.infer(X, km, off, T, 20, thr, 0, 16, 2, out=(rp, site, mod))
@@ -326,7 +331,8 @@ def main():
                        "sites_per_gpu": S, "reads_per_site": list(bag) if isinstance(bag, tuple) else bag, "reads_rank0": R,
                        "num_iterations": T, "pool_kernel": eng.last_pool_variant, "encoder_kernel": eng.last_encoder_variant,
                        "sharding": "contiguous flush-group-aligned site shards balanced by reads, 1 %s gather/step"
-                                   % ("RCCL" if backend == "nccl" else backend) if world > 1 else "none"},
+                                   % (("RCCL (m6a_gather)" if native_gather else "RCCL (torch.distributed)") if backend == "nccl" else backend)
+                                   if world > 1 else "none"},
             "first_call_ms": first_call_ms,
             "roofline": {"kernel": "read encoder (%s)" % eng.last_encoder_variant, "bound": "mfma", "achieved": enc_tflops,
                          "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": enc_tflops / PEAK_F32_TFLOPS,

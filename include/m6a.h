@@ -65,6 +65,12 @@ int m6a_set_stream(m6a_ctx *ctx, void *hip_stream);
  * such cuts).  Default 0. */
 int m6a_set_job_offset(m6a_ctx *ctx, int64_t first_site);
 int m6a_sync(m6a_ctx *ctx);    /* waits for the stream; returns a deferred kernel-side error if any */
+/* Optional: set up the host-pointer path now (pinned staging ring + copy threads; tens of milliseconds of page
+ * pinning) instead of inside the first call that passes host buffers -- e.g. while the caller is still parsing
+ * its input.  Host-buffer calls to m6a_infer / m6a_encode_reads cut the job into chunks and overlap the PCIe
+ * transfer of chunk k+1 with the encoder of chunk k (the shape of the reference's batch loop,
+ * m6anet/utils/inference_utils.py:33-41, without its per-batch synchronisation). */
+int m6a_prepare_host_io(m6a_ctx *ctx);
 
 /* Read encoder.  Replaces, for one batch of sites,
  *     model.get_read_representation({'X','kmer'}) + model.pooling_filter.probability_layer(.)
@@ -142,6 +148,26 @@ int64_t m6a_reference_written_sites(int64_t n_sites, int64_t batch_size, int64_t
  * off is a HOST pointer.  Writes shard_site_off[0..n_shards]. */
 int m6a_shard_plan(const int64_t *off, int64_t n_sites, int64_t batch_size, int64_t save_per_batch,
                    int n_shards, int64_t *shard_site_off);
+
+/* The job's one exchange: every rank's site_prob / mod_ratio to rank `dst` over RCCL
+ * (xGMI inside a node) -- the counterpart of nothing in the reference, which has no multi-device path; it is what
+ * a launcher calls after each rank ran m6a_infer on its shard (m6a_shard_plan, m6a_set_job_offset).
+ *   m6a_comm_unique_id   rank 0 makes the 128-byte RCCL id (ncclGetUniqueId); the launcher hands it to every rank
+ *                        by whatever transport it has (its process group, MPI, a file);
+ *   m6a_comm_init        ncclCommInitRank on the context's device -- one communicator per context;
+ *   m6a_gather           device pointers; shard_site_off [world+1] (HOST) are the cuts of m6a_shard_plan;
+ *                        site_prob / mod_ratio hold this rank's shard_site_off[rank+1] - shard_site_off[rank] sites;
+ *                        site_all / mod_all [shard_site_off[world]] are written on rank dst only (may be NULL
+ *                        elsewhere).  ONE grouped send/recv exchange on the context's stream, ragged shards land at
+ *                        their offsets without padding; stream-ordered, the caller synchronises (m6a_sync).
+ * RCCL is bound at run time (dlopen of librccl; M6A_RCCL_LIB names a specific copy): a process that never calls
+ * these needs no RCCL.  M6A_EUNSUPPORTED if the library cannot be found. */
+#define M6A_COMM_ID_BYTES 128
+int m6a_comm_unique_id(void *id_out);
+int m6a_comm_init(m6a_ctx *ctx, const void *unique_id, int rank, int world_size);
+int m6a_gather(m6a_ctx *ctx, const float *site_prob, const double *mod_ratio, const int64_t *shard_site_off,
+               int dst, float *site_all, double *mod_all);
+int m6a_comm_destroy(m6a_ctx *ctx);
 
 /* Per-kernel timing with HIP events on the context's stream (bench.py's live roofline).
  * kind: 0 = read encoder, 1 = site pooling.  m6a_profile_read synchronises the stream. */

@@ -12,10 +12,10 @@ ERRORS = {-1: "M6A_EINVAL", -2: "M6A_ENOMEM", -3: "M6A_EHIP", -4: "M6A_ESTREAM",
 RNG_NUMPY = 0
 
 # every symbol include/m6a.h declares (tests check the .so exports exactly these)
-SYMBOLS = ["m6a_create", "m6a_destroy", "m6a_last_error", "m6a_set_stream", "m6a_set_job_offset", "m6a_set_scan_driver", "m6a_set_table_variant", "m6a_set_encoder_variant", "m6a_last_encoder_variant", "m6a_sync",
+SYMBOLS = ["m6a_create", "m6a_destroy", "m6a_last_error", "m6a_set_stream", "m6a_set_job_offset", "m6a_set_scan_driver", "m6a_set_table_variant", "m6a_set_encoder_variant", "m6a_last_encoder_variant", "m6a_sync", "m6a_prepare_host_io",
            "m6a_encode_reads", "m6a_site_pool", "m6a_infer", "m6a_bag_forward", "m6a_validate_pool", "m6a_validate", "m6a_flush_groups",
            "m6a_reference_written_sites",
-           "m6a_shard_plan", "m6a_profile_enable", "m6a_profile_read", "m6a_last_pool_variant",
+           "m6a_shard_plan", "m6a_comm_unique_id", "m6a_comm_init", "m6a_gather", "m6a_comm_destroy", "m6a_profile_enable", "m6a_profile_read", "m6a_last_pool_variant",
            "m6a_version"]
 
 _lib = None
@@ -38,9 +38,14 @@ def _preload_hip_runtime():
     except (ImportError, ValueError):
         spec = None
     if spec and spec.submodule_search_locations:
-        rt = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+        rt = os.path.join(libdir, "libamdhip64.so")
         if os.path.exists(rt):
             C.CDLL(rt, mode=C.RTLD_GLOBAL)
+        # the same goes for RCCL (m6a_gather binds it at run time): PyTorch's copy is linked to PyTorch's HIP runtime
+        rccl = os.path.join(libdir, "librccl.so")
+        if os.path.exists(rccl):
+            os.environ.setdefault("M6A_RCCL_LIB", rccl)
 
 
 def load():
@@ -61,6 +66,7 @@ def load():
     L.m6a_last_error.restype = C.c_char_p
     L.m6a_set_stream.argtypes = [vp, vp]
     L.m6a_sync.argtypes = [vp]
+    L.m6a_prepare_host_io.argtypes = [vp]
     L.m6a_set_job_offset.argtypes = [vp, i64]
     L.m6a_set_scan_driver.argtypes = [vp, i32]
     L.m6a_set_table_variant.argtypes = [vp, i32]
@@ -78,6 +84,10 @@ def load():
     L.m6a_reference_written_sites.argtypes = [i64, i64, i64]
     L.m6a_reference_written_sites.restype = i64
     L.m6a_shard_plan.argtypes = [vp, i64, i64, i64, i32, vp]
+    L.m6a_comm_unique_id.argtypes = [vp]
+    L.m6a_comm_init.argtypes = [vp, vp, i32, i32]
+    L.m6a_gather.argtypes = [vp, vp, vp, vp, i32, vp, vp]
+    L.m6a_comm_destroy.argtypes = [vp]
     L.m6a_profile_enable.argtypes = [vp, i32]
     L.m6a_profile_read.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(i64)]
     L.m6a_last_pool_variant.argtypes = [vp]

@@ -1,6 +1,7 @@
 // m6a_api.hip -- host side of libm6a_hip.so: the C ABI of include/m6a.h.
 // Context/weights management, MT19937 stream + index-table preparation, launches.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -8,9 +9,14 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <functional>
+#include <memory>
+#include <mutex>
 #include <new>
 #include <random>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "m6a.h"
@@ -46,6 +52,85 @@ struct Profiler {
 };
 
 }  // namespace
+
+// Host threads that move caller memory into / out of the pinned staging slots of the host-pointer path: one
+// thread cannot feed PCIe (memcpy of pageable memory runs at 10-15 GB/s per thread, the link takes ~45 GB/s).
+class CopyPool {
+public:
+    explicit CopyPool(int n_threads)
+    {
+        for (int i = 0; i < n_threads; i++) workers_.emplace_back([this] { loop(); });
+    }
+    ~CopyPool()
+    {
+        { std::lock_guard<std::mutex> g(mu_); stop_ = true; }
+        cv_job_.notify_all();
+        for (auto &t : workers_) t.join();
+    }
+    // memcpy(dst, src, n) split over the workers and the calling thread; returns when all of it is done
+    void copy(void *dst, const void *src, size_t n)
+    {
+        const size_t parts = std::max<size_t>(1, std::min<size_t>(workers_.size() + 1, n / ((size_t)256 << 10)));
+        if (parts == 1) { std::memcpy(dst, src, n); return; }
+        const size_t slice = ((n + parts - 1) / parts + 4095) & ~(size_t)4095;
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            dst_ = (char *)dst; src_ = (const char *)src; n_ = n; slice_ = slice; next_ = 0; pending_ = (n + slice - 1) / slice;
+        }
+        cv_job_.notify_all();
+        work();
+        std::unique_lock<std::mutex> g(mu_);
+        cv_done_.wait(g, [this] { return pending_ == 0; });
+    }
+
+private:
+    bool work()                     // take slices until none is left; true if any was taken
+    {
+        bool any = false;
+        for (;;) {
+            size_t off;
+            {
+                std::lock_guard<std::mutex> g(mu_);
+                if (next_ * slice_ >= n_) return any;
+                off = next_++ * slice_;
+            }
+            std::memcpy(dst_ + off, src_ + off, std::min(slice_, n_ - off));
+            any = true;
+            std::lock_guard<std::mutex> g(mu_);
+            if (--pending_ == 0) cv_done_.notify_all();
+        }
+    }
+    void loop()
+    {
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> g(mu_);
+                cv_job_.wait(g, [this] { return stop_ || next_ * slice_ < n_; });
+                if (stop_) return;
+            }
+            work();
+        }
+    }
+    std::vector<std::thread> workers_;
+    std::mutex mu_;
+    std::condition_variable cv_job_, cv_done_;
+    char *dst_ = nullptr; const char *src_ = nullptr;
+    size_t n_ = 0, slice_ = 1, next_ = 0, pending_ = 0;
+    bool stop_ = false;
+};
+
+// pinned staging ring of the host-pointer path (m6a_infer / m6a_encode_reads with host buffers)
+constexpr int kStageSlots = 3;
+struct Staging {
+    hipStream_t s_h2d = nullptr, s_d2h = nullptr;
+    char *pin_in[kStageSlots] = {nullptr, nullptr, nullptr};
+    char *pin_out[kStageSlots] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_h2d[kStageSlots] = {nullptr, nullptr, nullptr}, ev_enc[kStageSlots] = {nullptr, nullptr, nullptr},
+               ev_d2h[kStageSlots] = {nullptr, nullptr, nullptr};
+    int64_t chunk_reads = 0;
+    std::unique_ptr<CopyPool> pool;
+    bool ready = false;
+};
 
 // NumPy's float32 pairwise sum as a plan (built by build_mean_plan below)
 struct MeanPlan {
@@ -91,7 +176,7 @@ struct m6a_ctx {
     // pinned staging of the small control arrays of the index-table path
     uint32_t *h_hist = nullptr, *d_hist = nullptr;
     uint32_t *h_ctl = nullptr;                // [cursor HIST_BINS | slot_of_n 1025 | build_n 1024 | build_slot 1024]
-    DevBuf ctl_dev, rt_rank, rt_order;
+    DevBuf ctl_dev, rt_rank, rt_order, reg_out;
     // per-bag-size index tables (m6a_pool_rtab.hip), valid for (seed, T*K, stream length)
     struct {
         bool valid = false; uint32_t seed = 0; int64_t A = 0, n_blk = 0;
@@ -100,7 +185,10 @@ struct m6a_ctx {
         int32_t slot_of_n[M6A_RTAB_MAX_N + 1];
     } rt;
     // host-pointer staging
-    DevBuf sX, sK, sOff, sP, sSite, sMod, val_idx, val_y, val_avg;
+    DevBuf sX, sK, sOff, sP, sSite, sMod, val_idx, val_y, val_avg, sOffChunk;
+    Staging stg;
+    void *comm = nullptr;                     // ncclComm_t
+    int comm_rank = 0, comm_world = 0;
     Profiler prof;
     const char *pool_variant = "none";
 };
@@ -240,7 +328,7 @@ int ensure_groups(m6a_ctx *c, int64_t S, int64_t bs, int64_t spb)
 }
 
 // ---- NumPy legacy stream: np.random.seed(int) == init_genrand == std::mt19937(seed) ------------
-// generated on the device (mt19937_kernel, m6a_pool_rtab.hip): one workgroup, ~0.3 ms for the default 1.3 M words
+// generated on the device (mt19937_kernel, m6a_pool_rtab.hip)
 int ensure_raw(m6a_ctx *c, uint32_t seed, int64_t len)
 {
     if (c->raw_len >= len && c->raw_seed == seed) return M6A_OK;
@@ -251,7 +339,7 @@ int ensure_raw(m6a_ctx *c, uint32_t seed, int64_t len)
     c->raw_len = 0;
     c->rt.valid = false;                       // the index tables describe the old stream
     HIPCHK(c, c->raw.ensure((size_t)len * 4));
-    hipLaunchKernelGGL(mt19937_kernel, dim3(1), dim3(256), 0, c->stream, seed, len, (uint32_t *)c->raw.p);
+    hipLaunchKernelGGL(mt19937_kernel, dim3(1), dim3(640), 0, c->stream, seed, len, (uint32_t *)c->raw.p);
     HIPCHK(c, hipGetLastError());
     c->raw_seed = seed; c->raw_len = len;
     return M6A_OK;
@@ -504,10 +592,10 @@ int ensure_rtab(m6a_ctx *c, uint32_t seed, int T, int K, int64_t gmax, const uin
         RtabBuild b;
         b.raw = (const uint32_t *)c->raw.p; b.n_blk = (uint32_t)n_blk; b.build_n = d_bn; b.build_slot = d_bn + M6A_RTAB_MAX_N;
         b.C = rt.C; b.RS = rt.RS; b.c_stride = c_stride;
-        const unsigned gx = (unsigned)((n_blk + 63) / 64);                  // 4 waves x 16 blocks per workgroup
-        hipLaunchKernelGGL(rtab_count_kernel, dim3(gx, (unsigned)todo.size()), dim3(256), 0, c->stream, b);
+        const unsigned gx = (unsigned)std::min<int64_t>((n_blk + 63) / 64, 65535);   // 4 waves x 16 blocks per workgroup
+        hipLaunchKernelGGL(rtab_count_kernel, dim3((unsigned)todo.size(), gx), dim3(256), 0, c->stream, b);
         hipLaunchKernelGGL(rtab_scan_kernel, dim3((unsigned)todo.size()), dim3(256), 0, c->stream, b);
-        hipLaunchKernelGGL(rtab_fill_kernel, dim3(gx, (unsigned)todo.size()), dim3(256), 0, c->stream, b);
+        hipLaunchKernelGGL(rtab_fill_kernel, dim3((unsigned)todo.size(), gx), dim3(256), 0, c->stream, b);
         HIPCHK(c, hipGetLastError());
         // the pinned build list is reused by the next call: it must have been consumed
         HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -569,6 +657,7 @@ void prof_end(m6a_ctx *c, int kind)
 }
 
 void host_bag_range(m6a_ctx *c, const int64_t *off, int64_t S);
+int sync_and_check(m6a_ctx *c);
 
 // bag-size range and histogram (they decide the pooling kernel) and total reads: one 4 KB read-back,
 // which blocks on the stream
@@ -649,7 +738,12 @@ int launch_pool(m6a_ctx *c, const float *rp, const int64_t *off, int64_t S, int 
         // one wavefront = position j of 256 flush groups (4 sites per lane); blockIdx % jmax = j keeps a
         // position's index rows in one XCD's L2
         const int64_t wpj = (a.n_groups + 255) / 256;
+        a.reg_gpad = (a.n_groups + 63) / 64 * 64;
+        HIPCHK(c, c->reg_out.ensure((size_t)a.jmax * a.reg_gpad * 5));
+        a.reg_site = (float *)c->reg_out.p;
+        a.reg_cnt = (uint8_t *)c->reg_out.p + (size_t)a.jmax * a.reg_gpad * 4;
         hipLaunchKernelGGL(pool_reg_kernel, dim3((unsigned)(wpj * a.jmax)), dim3(64), 0, c->stream, a);
+        hipLaunchKernelGGL(pool_reg_finish_kernel, dim3((unsigned)((a.n_groups + 31) / 32), (unsigned)((a.jmax + 31) / 32)), dim3(256), 0, c->stream, a);
         prof_end(c, 1);
     } else if (uniform && c->plan.max_merge <= 15) {
         rc = ensure_table(c, seed, (int)nmin, T, K, (int)gmax);
@@ -753,6 +847,210 @@ int launch_pool(m6a_ctx *c, const float *rp, const int64_t *off, int64_t S, int 
     HIPCHK(c, hipGetLastError());
     return M6A_OK;
 }
+
+// ---- host-pointer path: pinned staging ring, H2D of chunk k+1 under the encoder of chunk k ---------------------
+int ensure_staging(m6a_ctx *c)
+{
+    Staging &g = c->stg;
+    if (g.ready) return M6A_OK;
+    const char *env = getenv("M6A_STAGE_MB");
+    const size_t slot_mb = env && atoi(env) > 0 ? (size_t)atoi(env) : 24;
+    g.chunk_reads = (int64_t)(slot_mb << 20) / (M6A_N_FEATURES * 4);
+    HIPCHK(c, hipStreamCreateWithFlags(&g.s_h2d, hipStreamNonBlocking));
+    HIPCHK(c, hipStreamCreateWithFlags(&g.s_d2h, hipStreamNonBlocking));
+    for (int i = 0; i < kStageSlots; i++) {
+        HIPCHK(c, hipHostMalloc((void **)&g.pin_in[i], (size_t)g.chunk_reads * M6A_N_FEATURES * 4, hipHostMallocDefault));
+        HIPCHK(c, hipHostMalloc((void **)&g.pin_out[i], (size_t)g.chunk_reads * 4, hipHostMallocDefault));
+        HIPCHK(c, hipEventCreateWithFlags(&g.ev_h2d[i], hipEventDisableTiming));
+        HIPCHK(c, hipEventCreateWithFlags(&g.ev_enc[i], hipEventDisableTiming));
+        HIPCHK(c, hipEventCreateWithFlags(&g.ev_d2h[i], hipEventDisableTiming));
+    }
+    const char *et = getenv("M6A_COPY_THREADS");
+    int nt = et && atoi(et) > 0 ? atoi(et) : (int)std::min<unsigned>(16u, std::max(2u, std::thread::hardware_concurrency() / 2));
+    g.pool.reset(new (std::nothrow) CopyPool(nt - 1));
+    if (!g.pool) return fail(c, M6A_ENOMEM, "out of host memory");
+    g.ready = true;
+    return M6A_OK;
+}
+
+void release_staging(m6a_ctx *c)
+{
+    Staging &g = c->stg;
+    g.pool.reset();
+    for (int i = 0; i < kStageSlots; i++) {
+        if (g.pin_in[i]) (void)hipHostFree(g.pin_in[i]);
+        if (g.pin_out[i]) (void)hipHostFree(g.pin_out[i]);
+        if (g.ev_h2d[i]) (void)hipEventDestroy(g.ev_h2d[i]);
+        if (g.ev_enc[i]) (void)hipEventDestroy(g.ev_enc[i]);
+        if (g.ev_d2h[i]) (void)hipEventDestroy(g.ev_d2h[i]);
+    }
+    if (g.s_h2d) (void)hipStreamDestroy(g.s_h2d);
+    if (g.s_d2h) (void)hipStreamDestroy(g.s_d2h);
+    g = Staging();
+}
+
+// Encodes a job whose X / site_kmers / off live in HOST memory: the job is cut at site boundaries into chunks of
+// <= chunk_reads reads; chunk k is copied by the host threads into a pinned slot, DMA'd on its own stream and
+// encoded on the context's stream while chunk k+1 is being copied; read probabilities flow back the same way
+// (rp_host may be null).  On return every kernel is enqueued, sX/sK/sOff/sP hold the job on the device, and --
+// if rp_host -- all read probabilities are in rp_host.  c->bag_min etc. describe `off` (host_bag_range ran).
+int staged_encode(m6a_ctx *c, const float *X, const uint8_t *km, const int64_t *off, int64_t S, int64_t R, float *rp_host)
+{
+    Staging &g = c->stg;
+    HIPCHK(c, c->sX.ensure((size_t)std::max<int64_t>(R, 1) * 9 * 4));
+    HIPCHK(c, c->sK.ensure((size_t)S * 3));
+    HIPCHK(c, c->sOff.ensure((size_t)(S + 1) * 8));
+    HIPCHK(c, c->sP.ensure((size_t)std::max<int64_t>(R, 1) * 4));
+    // small jobs (and single bags larger than a staging slot) are not worth a pinned ring: plain copies
+    const bool small = !g.ready && (size_t)R * 9 * 4 < ((size_t)8 << 20);
+    int rc = small ? M6A_OK : ensure_staging(c);
+    if (rc) return rc;
+    if (small || R == 0 || c->bag_max > g.chunk_reads) {
+        HIPCHK(c, hipMemcpyAsync(c->sK.p, km, (size_t)S * 3, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->sOff.p, off, (size_t)(S + 1) * 8, hipMemcpyHostToDevice, c->stream));
+        if (R == 0) return M6A_OK;
+        HIPCHK(c, hipMemcpyAsync(c->sX.p, X, (size_t)R * 9 * 4, hipMemcpyHostToDevice, c->stream));
+        rc = launch_encode(c, (const float *)c->sX.p, (const uint8_t *)c->sK.p, (const int64_t *)c->sOff.p, S, R, (float *)c->sP.p);
+        if (rc) return rc;
+        if (rp_host) HIPCHK(c, hipMemcpyAsync(rp_host, c->sP.p, (size_t)R * 4, hipMemcpyDeviceToHost, c->stream));
+        return M6A_OK;
+    }
+    const size_t slot_bytes = (size_t)g.chunk_reads * 9 * 4;
+    // ring item 0: the CSR offsets and the k-mer ids, through a pinned slot like everything else
+    const size_t off_bytes = (size_t)(S + 1) * 8, km_bytes = (size_t)S * 3;
+    int item = 0;
+    if (off_bytes + km_bytes <= slot_bytes) {
+        g.pool->copy(g.pin_in[0], off, off_bytes);
+        std::memcpy(g.pin_in[0] + off_bytes, km, km_bytes);
+        HIPCHK(c, hipMemcpyAsync(c->sOff.p, g.pin_in[0], off_bytes, hipMemcpyHostToDevice, g.s_h2d));
+        HIPCHK(c, hipMemcpyAsync(c->sK.p, g.pin_in[0] + off_bytes, km_bytes, hipMemcpyHostToDevice, g.s_h2d));
+        HIPCHK(c, hipEventRecord(g.ev_h2d[0], g.s_h2d));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, g.ev_h2d[0], 0));
+        item = 1;
+    } else {
+        HIPCHK(c, hipMemcpyAsync(c->sK.p, km, km_bytes, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->sOff.p, off, off_bytes, hipMemcpyHostToDevice, c->stream));
+    }
+    const int item0 = item;
+    // chunk table: sites [cs[k], cs[k+1])
+    std::vector<int64_t> cs{0};
+    while (cs.back() < S) {
+        const int64_t s0 = cs.back();
+        int64_t s1 = std::upper_bound(off + s0, off + S + 1, off[s0] + g.chunk_reads) - off - 1;
+        s1 = std::min<int64_t>(S, std::max<int64_t>(s1, s0 + 1));
+        cs.push_back(s1);
+    }
+    const int64_t nchunk = (int64_t)cs.size() - 1;
+    HIPCHK(c, c->sOffChunk.ensure((size_t)(S + nchunk) * 8));
+    std::vector<char> out_pending((size_t)nchunk, 0);
+    auto drain_out = [&](int64_t k) -> int {     // read probabilities of chunk k: pinned slot -> caller memory
+        if (!out_pending[(size_t)k]) return M6A_OK;
+        const int slot = (int)((k + item0) % kStageSlots);
+        HIPCHK(c, hipEventSynchronize(g.ev_d2h[slot]));
+        g.pool->copy(rp_host + off[cs[k]], g.pin_out[slot], (size_t)(off[cs[k + 1]] - off[cs[k]]) * 4);
+        out_pending[(size_t)k] = 0;
+        return M6A_OK;
+    };
+    for (int64_t k = 0; k < nchunk; k++, item++) {
+        const int slot = item % kStageSlots;
+        const int64_t s0 = cs[k], s1 = cs[k + 1], r0 = off[s0], nr = off[s1] - r0;
+        if (nr == 0) continue;
+        if (item >= kStageSlots) {
+            HIPCHK(c, hipEventSynchronize(g.ev_h2d[slot]));            // the slot's previous DMA has left it
+            if (k >= kStageSlots) { rc = drain_out(k - kStageSlots); if (rc) return rc; }
+        }
+        g.pool->copy(g.pin_in[slot], X + r0 * 9, (size_t)nr * 9 * 4);
+        HIPCHK(c, hipMemcpyAsync((float *)c->sX.p + r0 * 9, g.pin_in[slot], (size_t)nr * 9 * 4, hipMemcpyHostToDevice, g.s_h2d));
+        HIPCHK(c, hipEventRecord(g.ev_h2d[slot], g.s_h2d));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, g.ev_h2d[slot], 0));
+        // the encoder wants offsets that start at 0: the chunk's own CSR row
+        int64_t *d_off = (int64_t *)c->sOffChunk.p + s0 + k;
+        hipLaunchKernelGGL(rebase_off_kernel, dim3((unsigned)((s1 - s0 + 1 + 255) / 256)), dim3(256), 0, c->stream,
+                           (const int64_t *)c->sOff.p + s0, s1 - s0 + 1, d_off);
+        rc = launch_encode(c, (const float *)c->sX.p + r0 * 9, (const uint8_t *)c->sK.p + s0 * 3, d_off, s1 - s0, nr, (float *)c->sP.p + r0);
+        if (rc) return rc;
+        if (rp_host) {
+            HIPCHK(c, hipEventRecord(g.ev_enc[slot], c->stream));
+            HIPCHK(c, hipStreamWaitEvent(g.s_d2h, g.ev_enc[slot], 0));
+            HIPCHK(c, hipMemcpyAsync(g.pin_out[slot], (const float *)c->sP.p + r0, (size_t)nr * 4, hipMemcpyDeviceToHost, g.s_d2h));
+            HIPCHK(c, hipEventRecord(g.ev_d2h[slot], g.s_d2h));
+            out_pending[(size_t)k] = 1;
+        }
+    }
+    for (int64_t k = 0; k < nchunk; k++) { rc = drain_out(k); if (rc) return rc; }
+    return M6A_OK;
+}
+
+// site_prob / mod_ratio of a host-pointer call: through the (now idle) pinned slots when they fit, so the caller's
+// pageable arrays are filled by the copy threads instead of a staged synchronous hipMemcpy.  Synchronises the stream.
+int staged_outputs(m6a_ctx *c, int64_t S, float *site, double *mod)
+{
+    Staging &g = c->stg;
+    const size_t slot_bytes = g.ready ? (size_t)g.chunk_reads * 9 * 4 : 0;
+    if ((size_t)S * 8 > slot_bytes) {
+        HIPCHK(c, hipMemcpyAsync(site, c->sSite.p, (size_t)S * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(mod, c->sMod.p, (size_t)S * 8, hipMemcpyDeviceToHost, c->stream));
+        return sync_and_check(c);
+    }
+    HIPCHK(c, hipMemcpyAsync(g.pin_in[0], c->sSite.p, (size_t)S * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(g.pin_in[1], c->sMod.p, (size_t)S * 8, hipMemcpyDeviceToHost, c->stream));
+    const int rc = sync_and_check(c);
+    if (rc) return rc;
+    g.pool->copy(site, g.pin_in[0], (size_t)S * 4);
+    g.pool->copy(mod, g.pin_in[1], (size_t)S * 8);
+    return M6A_OK;
+}
+
+// ---- RCCL, bound at run time ---------------------------------------------------------------------------------
+// (types restated from rccl.h so the library builds and loads without RCCL: NCCL_UNIQUE_ID_BYTES = 128,
+// ncclFloat32 = 7, ncclFloat64 = 8, ncclSuccess = 0)
+struct RcclId { char internal[M6A_COMM_ID_BYTES]; };
+struct Rccl {
+    void *h = nullptr;
+    int (*GetUniqueId)(RcclId *) = nullptr;
+    int (*CommInitRank)(void **, int, RcclId, int) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Send)(const void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*Recv)(void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    std::string err;
+};
+
+Rccl *rccl()
+{
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        std::vector<std::string> names;
+        if (const char *e = getenv("M6A_RCCL_LIB")) names.push_back(e);
+        for (const char *n : {"librccl.so.1", "librccl.so"}) names.push_back(n);
+        names.push_back("/opt/rocm/lib/librccl.so.1");
+        for (size_t i = 0; i < names.size() && !r.h; i++) {
+            // a copy that is already mapped (e.g. PyTorch's) wins: it is bound to the process's HIP runtime
+            r.h = dlopen(names[i].c_str(), RTLD_NOW | RTLD_NOLOAD);
+        }
+        for (size_t i = 0; i < names.size() && !r.h; i++) r.h = dlopen(names[i].c_str(), RTLD_NOW | RTLD_LOCAL);
+        if (!r.h) { r.err = "librccl not found (set M6A_RCCL_LIB)"; return; }
+        auto sym = [&](const char *n) { void *p = dlsym(r.h, n); if (!p && r.err.empty()) r.err = std::string("librccl lacks ") + n; return p; };
+        r.GetUniqueId = (int (*)(RcclId *))sym("ncclGetUniqueId");
+        r.CommInitRank = (int (*)(void **, int, RcclId, int))sym("ncclCommInitRank");
+        r.CommDestroy = (int (*)(void *))sym("ncclCommDestroy");
+        r.GroupStart = (int (*)())sym("ncclGroupStart");
+        r.GroupEnd = (int (*)())sym("ncclGroupEnd");
+        r.Send = (int (*)(const void *, size_t, int, int, void *, hipStream_t))sym("ncclSend");
+        r.Recv = (int (*)(void *, size_t, int, int, void *, hipStream_t))sym("ncclRecv");
+        r.GetErrorString = (const char *(*)(int))sym("ncclGetErrorString");
+    });
+    return &r;
+}
+
+#define RCCLCHK(c, R, expr)                                                                             \
+    do {                                                                                                \
+        const int e_ = (expr);                                                                          \
+        if (e_ != 0) return fail((c), M6A_EHIP, "%s: %s", #expr, (R)->GetErrorString ? (R)->GetErrorString(e_) : "RCCL error"); \
+    } while (0)
 
 void host_bag_range(m6a_ctx *c, const int64_t *off, int64_t S)
 {
@@ -896,7 +1194,9 @@ void m6a_destroy(m6a_ctx *c)
     if (c->h_ctl) (void)hipHostFree(c->h_ctl);
     if (c->rt.C) (void)hipFree(c->rt.C);
     if (c->rt.RS) (void)hipFree(c->rt.RS);
-    for (DevBuf *b : {&c->ctl_dev, &c->rt_rank, &c->rt_order}) b->release();
+    for (DevBuf *b : {&c->ctl_dev, &c->rt_rank, &c->rt_order, &c->sOffChunk, &c->reg_out}) b->release();
+    release_staging(c);
+    if (c->comm) { Rccl *R = rccl(); if (R->CommDestroy) (void)R->CommDestroy(c->comm); c->comm = nullptr; }
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -949,6 +1249,13 @@ int m6a_sync(m6a_ctx *c)
     return sync_and_check(c);
 }
 
+int m6a_prepare_host_io(m6a_ctx *c)
+{
+    if (!c) return M6A_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    return ensure_staging(c);
+}
+
 int m6a_encode_reads(m6a_ctx *c, const float *X, const uint8_t *km, const int64_t *off, int64_t S, float *rp)
 {
     if (!c) return M6A_EINVAL;
@@ -964,17 +1271,9 @@ int m6a_encode_reads(m6a_ctx *c, const float *X, const uint8_t *km, const int64_
         for (int64_t s = 0; s < S; s++) if (off[s + 1] < off[s]) return fail(c, M6A_EINVAL, "off[] must be non-decreasing");
         const int64_t R = off[S];
         if (R == 0) return M6A_OK;
-        HIPCHK(c, c->sX.ensure((size_t)R * 9 * 4));
-        HIPCHK(c, c->sK.ensure((size_t)S * 3));
-        HIPCHK(c, c->sOff.ensure((size_t)(S + 1) * 8));
-        HIPCHK(c, c->sP.ensure((size_t)R * 4));
-        HIPCHK(c, hipMemcpyAsync(c->sX.p, X, (size_t)R * 9 * 4, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipMemcpyAsync(c->sK.p, km, (size_t)S * 3, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipMemcpyAsync(c->sOff.p, off, (size_t)(S + 1) * 8, hipMemcpyHostToDevice, c->stream));
         host_bag_range(c, off, S);
-        int rc = launch_encode(c, (const float *)c->sX.p, (const uint8_t *)c->sK.p, (const int64_t *)c->sOff.p, S, R, (float *)c->sP.p);
+        int rc = staged_encode(c, X, km, off, S, R, rp);
         if (rc) return rc;
-        HIPCHK(c, hipMemcpyAsync(rp, c->sP.p, (size_t)R * 4, hipMemcpyDeviceToHost, c->stream));
         return sync_and_check(c);
     }
     // device pointers: total reads (grid size) and smallest bag (kernel choice): one read-back
@@ -1042,25 +1341,16 @@ int m6a_infer(m6a_ctx *c, const float *X, const uint8_t *km, const int64_t *off,
     if (off[0] != 0) return fail(c, M6A_EINVAL, "off[0] must be 0");
     for (int64_t s = 0; s < S; s++) if (off[s + 1] < off[s]) return fail(c, M6A_EINVAL, "off[] must be non-decreasing");
     const int64_t R = off[S];
-    HIPCHK(c, c->sX.ensure((size_t)std::max<int64_t>(R, 1) * 9 * 4));
-    HIPCHK(c, c->sK.ensure((size_t)S * 3));
-    HIPCHK(c, c->sOff.ensure((size_t)(S + 1) * 8));
-    HIPCHK(c, c->sP.ensure((size_t)std::max<int64_t>(R, 1) * 4));
     HIPCHK(c, c->sSite.ensure((size_t)S * 4));
     HIPCHK(c, c->sMod.ensure((size_t)S * 8));
-    HIPCHK(c, hipMemcpyAsync(c->sX.p, X, (size_t)R * 9 * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->sK.p, km, (size_t)S * 3, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->sOff.p, off, (size_t)(S + 1) * 8, hipMemcpyHostToDevice, c->stream));
     host_bag_range(c, off, S);
-    rc = launch_encode(c, (const float *)c->sX.p, (const uint8_t *)c->sK.p, (const int64_t *)c->sOff.p, S, R, (float *)c->sP.p);
+    // chunks of X cross PCIe while earlier chunks are being encoded; read probabilities stream back the same way
+    rc = staged_encode(c, X, km, off, S, R, rp);
     if (rc) return rc;
     rc = launch_pool(c, (const float *)c->sP.p, (const int64_t *)c->sOff.p, S, T, K, thr, seed, bs, spb,
                      (float *)c->sSite.p, (double *)c->sMod.p);
     if (rc) return rc;
-    if (rp) HIPCHK(c, hipMemcpyAsync(rp, c->sP.p, (size_t)R * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(site, c->sSite.p, (size_t)S * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(mod, c->sMod.p, (size_t)S * 8, hipMemcpyDeviceToHost, c->stream));
-    return sync_and_check(c);
+    return staged_outputs(c, S, site, mod);
 }
 
 int m6a_bag_forward(m6a_ctx *c, const float *X, const uint8_t *km, int64_t B, int bag, float *site)
@@ -1290,6 +1580,75 @@ int m6a_shard_plan(const int64_t *off, int64_t S, int64_t bs, int64_t spb, int n
         }
         shard_off[k] = std::max(g[std::min(gi, G)], shard_off[k - 1]);
     }
+    return M6A_OK;
+}
+
+int m6a_comm_unique_id(void *id_out)
+{
+    if (!id_out) return M6A_EINVAL;
+    Rccl *R = rccl();
+    if (!R->err.empty()) return fail(nullptr, M6A_EUNSUPPORTED, "%s", R->err.c_str());
+    RcclId id;
+    const int e = R->GetUniqueId(&id);
+    if (e != 0) return fail(nullptr, M6A_EHIP, "ncclGetUniqueId: %s", R->GetErrorString(e));
+    std::memcpy(id_out, id.internal, M6A_COMM_ID_BYTES);
+    return M6A_OK;
+}
+
+int m6a_comm_init(m6a_ctx *c, const void *unique_id, int rank, int world)
+{
+    if (!c) return M6A_EINVAL;
+    if (!unique_id || world < 1 || rank < 0 || rank >= world) return fail(c, M6A_EINVAL, "bad communicator arguments");
+    if (c->comm) return fail(c, M6A_EINVAL, "the context already has a communicator");
+    Rccl *R = rccl();
+    if (!R->err.empty()) return fail(c, M6A_EUNSUPPORTED, "%s", R->err.c_str());
+    HIPCHK(c, hipSetDevice(c->device));
+    RcclId id;
+    std::memcpy(id.internal, unique_id, M6A_COMM_ID_BYTES);
+    RCCLCHK(c, R, R->CommInitRank(&c->comm, world, id, rank));
+    c->comm_rank = rank; c->comm_world = world;
+    return M6A_OK;
+}
+
+int m6a_comm_destroy(m6a_ctx *c)
+{
+    if (!c) return M6A_EINVAL;
+    if (!c->comm) return M6A_OK;
+    Rccl *R = rccl();
+    HIPCHK(c, hipSetDevice(c->device));
+    (void)hipStreamSynchronize(c->stream);
+    RCCLCHK(c, R, R->CommDestroy(c->comm));
+    c->comm = nullptr; c->comm_world = 0;
+    return M6A_OK;
+}
+
+int m6a_gather(m6a_ctx *c, const float *site, const double *mod, const int64_t *cuts, int dst, float *site_all, double *mod_all)
+{
+    if (!c) return M6A_EINVAL;
+    if (!c->comm) return fail(c, M6A_EINVAL, "m6a_comm_init has not run on this context");
+    const int W = c->comm_world, me = c->comm_rank;
+    if (!cuts || dst < 0 || dst >= W) return fail(c, M6A_EINVAL, "bad gather arguments");
+    for (int r = 0; r < W; r++) if (cuts[r + 1] < cuts[r]) return fail(c, M6A_EINVAL, "shard_site_off must be non-decreasing");
+    const int64_t mine = cuts[me + 1] - cuts[me];
+    if (mine > 0 && (!site || !mod)) return fail(c, M6A_EINVAL, "null pointer argument");
+    if (me == dst && cuts[W] > cuts[0] && (!site_all || !mod_all)) return fail(c, M6A_EINVAL, "rank dst needs site_all and mod_all");
+    Rccl *R = rccl();
+    HIPCHK(c, hipSetDevice(c->device));
+    // one grouped exchange: every rank (dst included) sends its two arrays, dst posts the matching receives at the
+    // shards' offsets -- direct peer-to-peer writes over xGMI, no ring, no padding
+    RCCLCHK(c, R, R->GroupStart());
+    if (mine > 0) {
+        RCCLCHK(c, R, R->Send(site, (size_t)mine, 7 /* ncclFloat32 */, dst, c->comm, c->stream));
+        RCCLCHK(c, R, R->Send(mod, (size_t)mine, 8 /* ncclFloat64 */, dst, c->comm, c->stream));
+    }
+    if (me == dst)
+        for (int r = 0; r < W; r++) {
+            const int64_t n = cuts[r + 1] - cuts[r];
+            if (n <= 0) continue;
+            RCCLCHK(c, R, R->Recv(site_all + (cuts[r] - cuts[0]), (size_t)n, 7, r, c->comm, c->stream));
+            RCCLCHK(c, R, R->Recv(mod_all + (cuts[r] - cuts[0]), (size_t)n, 8, r, c->comm, c->stream));
+        }
+    RCCLCHK(c, R, R->GroupEnd());
     return M6A_OK;
 }
 

@@ -1092,6 +1092,13 @@ __global__ void mean_over_passes_kernel(const float *y, int n_iters, int64_t n_s
     avg[s] = acc / (float)n_iters;
 }
 
+// out[i] = off[i] - off[0]: the CSR row of a chunk of sites, rebased to the chunk's first read
+__global__ void rebase_off_kernel(const int64_t *off, int64_t count, int64_t *out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) out[i] = off[i] - off[0];
+}
+
 __global__ void iota_off_kernel(int64_t *off, int64_t n_plus_1, int64_t step)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -62,10 +62,17 @@ __device__ __forceinline__ int64_t uni64(int64_t v)
 
 // =====================================================================================
 // MT19937 raw word stream on the device: np.random.seed(int) == init_genrand == std::mt19937(seed)
-// (m6anet/scripts/inference.py:86).  The recurrence x[k+624] = x[k+397] ^ twist(x[k], x[k+1]) is
-// sequential over 624-word blocks but 227-wide inside one: new[0..227) needs only old words,
-// new[227..454) needs new[0..227), new[454..624) needs new[227..397) (and new[0] for the last
-// word).  One workgroup, two state buffers in LDS, three barriers per block.
+// (m6anet/scripts/inference.py:86).  With x[0..623] the seeded state, the generator's words are
+// temper(x[624]), temper(x[625]), ... where
+//     x[j] = x[j-227] ^ T(j-624),      T(a) = twist(x[a], x[a+1]).
+// As written that is only 227-wide: x[j] needs x[j-227].  It is linear over GF(2), so substituting it
+// into itself twice gives
+//     x[j] = x[j-681] ^ T(j-1078) ^ T(j-851) ^ T(j-624),
+// whose newest operand is x[j-623]: 623 consecutive words can be computed at once from older ones.
+// One workgroup of 640 threads, the last 2048 words as a ring in LDS, ONE barrier per 623 words
+// (the first 454 generated words have no x[j-1078] yet and take two steps of the plain form).  The
+// barrier waits for LDS traffic only (lgkmcnt); the tempered stores stay in flight.  Measured on the
+// default 1.3 M words: three 227-wide phases per 624 words 1.5 ms, this form see profiles/.
 // =====================================================================================
 __device__ __forceinline__ uint32_t mt_twist(uint32_t a, uint32_t b)
 {
@@ -73,37 +80,50 @@ __device__ __forceinline__ uint32_t mt_twist(uint32_t a, uint32_t b)
     return (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
 }
 
-__global__ __launch_bounds__(256) void mt19937_kernel(uint32_t seed, int64_t n_words, uint32_t *raw)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+#define MT_RING 2048
+__global__ __launch_bounds__(640) void mt19937_kernel(uint32_t seed, int64_t n_words, uint32_t *raw)
 {
-    __shared__ uint32_t st[2][624];
+    __shared__ uint32_t x[MT_RING];
     const int k = threadIdx.x;
     if (k == 0) {
-        uint32_t x = seed;
-        st[0][0] = x;
-        for (uint32_t i = 1; i < 624; i++) { x = 1812433253u * (x ^ (x >> 30)) + i; st[0][i] = x; }
+        uint32_t v = seed;
+        x[0] = v;
+        for (uint32_t i = 1; i < 624; i++) { v = 1812433253u * (v ^ (v >> 30)) + i; x[i] = v; }
     }
-    __syncthreads();
-    int cur = 0;
-    for (int64_t base = 0; base < n_words; base += 624) {
-        const uint32_t *o = st[cur];
-        uint32_t *n = st[cur ^ 1];
-        if (k < 227) n[k] = o[k + 397] ^ mt_twist(o[k], o[k + 1]);
-        __syncthreads();
-        if (k < 227) { const int i = 227 + k; n[i] = n[i - 227] ^ mt_twist(o[i], o[i + 1]); }
-        __syncthreads();
-        if (k < 170) { const int i = 454 + k; n[i] = n[i - 227] ^ mt_twist(o[i], i == 623 ? n[0] : o[i + 1]); }
-        __syncthreads();
-        for (int i = k; i < 624; i += 256) {
-            uint32_t y = n[i];
-            y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
-            if (base + i < n_words) raw[base + i] = y;
+    lds_barrier();
+    auto emit = [&](int64_t j, uint32_t v) {                 // x[j] -> ring, temper(x[j]) -> raw[j - 624]
+        x[j & (MT_RING - 1)] = v;
+        uint32_t y = v;
+        y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
+        if (j - 624 < n_words) raw[j - 624] = y;
+    };
+    // x[624..850] and x[851..1077]: the plain recurrence, 227 wide
+    for (int64_t j0 = 624; j0 < 1078; j0 += 227) {
+        if (k < 227) {
+            const int64_t j = j0 + k;
+            emit(j, x[(j - 227) & (MT_RING - 1)] ^ mt_twist(x[(j - 624) & (MT_RING - 1)], x[(j - 623) & (MT_RING - 1)]));
         }
-        cur ^= 1;
+        lds_barrier();
+    }
+    for (int64_t j0 = 1078; j0 - 624 < n_words; j0 += 623) {
+        if (k < 623) {
+            const int64_t j = j0 + k;
+            const uint32_t v = x[(j - 681) & (MT_RING - 1)] ^
+                               mt_twist(x[(j - 1078) & (MT_RING - 1)], x[(j - 1077) & (MT_RING - 1)]) ^
+                               mt_twist(x[(j - 851) & (MT_RING - 1)], x[(j - 850) & (MT_RING - 1)]) ^
+                               mt_twist(x[(j - 624) & (MT_RING - 1)], x[(j - 623) & (MT_RING - 1)]);
+            emit(j, v);
+        }
+        // the ring holds 2048 words: step s writes x[j0 .. j0+622], the oldest word step s+1 reads is x[j0+623-1078]
+        lds_barrier();
     }
 }
 
 // =====================================================================================
-// Table build.  One wavefront = (one new bag size, one chunk of 16 blocks of 64 stream words).
+// Table build.  One wavefront = (one new bag size, one chunk of 16 blocks of 64 stream words); the bag size is
+// the fast grid axis, so a chunk of the stream is read by all bag sizes while it sits in L2.
 //   count: accepted words per block -> RS[slot][b]
 //   scan:  exclusive prefix per slot, total in RS[slot][n_blk]
 //   fill:  C[slot][RS[b] + rank] = 4 * (w & mask)     (byte offset into the float bag)
@@ -113,24 +133,24 @@ __global__ __launch_bounds__(256) void mt19937_kernel(uint32_t seed, int64_t n_w
 __global__ __launch_bounds__(256) void rtab_count_kernel(RtabBuild a)
 {
     const int lane = threadIdx.x & 63;
-    const uint32_t chunk = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int n = a.build_n[blockIdx.y];
-    const int64_t slot = a.build_slot[blockIdx.y];
-    const uint32_t b0 = chunk * RTAB_CHUNK;
-    if (b0 >= a.n_blk) return;
+    const int n = a.build_n[blockIdx.x];
+    const int64_t slot = a.build_slot[blockIdx.x];
     const uint32_t mask = pow2_mask_u32((uint32_t)(n - 1));
-    uint32_t mine = 0;
+    for (uint32_t chunk = blockIdx.y * 4 + (threadIdx.x >> 6); (uint64_t)chunk * RTAB_CHUNK < a.n_blk; chunk += gridDim.y * 4) {
+        const uint32_t b0 = chunk * RTAB_CHUNK;
+        uint32_t mine = 0;
 #pragma unroll
-    for (int i = 0; i < RTAB_CHUNK; i++) {
-        const uint32_t b = b0 + i;
-        uint32_t c = 0;
-        if (b < a.n_blk) {
-            const uint32_t w = a.raw[(int64_t)b * 64 + lane];
-            c = (uint32_t)__popcll(__ballot((w & mask) < (uint32_t)n));
+        for (int i = 0; i < RTAB_CHUNK; i++) {
+            const uint32_t b = b0 + i;
+            uint32_t c = 0;
+            if (b < a.n_blk) {
+                const uint32_t w = a.raw[(int64_t)b * 64 + lane];
+                c = (uint32_t)__popcll(__ballot((w & mask) < (uint32_t)n));
+            }
+            if (lane == i) mine = c;
         }
-        if (lane == i) mine = c;
+        if (lane < RTAB_CHUNK && b0 + lane < a.n_blk) a.RS[slot * ((int64_t)a.n_blk + 1) + b0 + lane] = mine;
     }
-    if (lane < RTAB_CHUNK && b0 + lane < a.n_blk) a.RS[slot * ((int64_t)a.n_blk + 1) + b0 + lane] = mine;
 }
 
 __global__ __launch_bounds__(256) void rtab_scan_kernel(RtabBuild a)
@@ -156,27 +176,27 @@ __global__ __launch_bounds__(256) void rtab_scan_kernel(RtabBuild a)
 __global__ __launch_bounds__(256) void rtab_fill_kernel(RtabBuild a)
 {
     const int lane = threadIdx.x & 63;
-    const uint32_t chunk = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int n = a.build_n[blockIdx.y];
-    const int64_t slot = a.build_slot[blockIdx.y];
-    const uint32_t b0 = chunk * RTAB_CHUNK;
-    if (b0 >= a.n_blk) return;
+    const int n = a.build_n[blockIdx.x];
+    const int64_t slot = a.build_slot[blockIdx.x];
     const uint32_t mask = pow2_mask_u32((uint32_t)(n - 1));
     const uint32_t *rs = a.RS + slot * ((int64_t)a.n_blk + 1);
     uint16_t *C = a.C + slot * a.c_stride;
-    uint32_t pre = 0;
-    if (lane < RTAB_CHUNK && b0 + lane < a.n_blk) pre = rs[b0 + lane];
+    for (uint32_t chunk = blockIdx.y * 4 + (threadIdx.x >> 6); (uint64_t)chunk * RTAB_CHUNK < a.n_blk; chunk += gridDim.y * 4) {
+        const uint32_t b0 = chunk * RTAB_CHUNK;
+        uint32_t pre = 0;
+        if (lane < RTAB_CHUNK && b0 + lane < a.n_blk) pre = rs[b0 + lane];
 #pragma unroll
-    for (int i = 0; i < RTAB_CHUNK; i++) {
-        const uint32_t b = b0 + i;
-        if (b >= a.n_blk) break;
-        const uint32_t w = a.raw[(int64_t)b * 64 + lane];
-        const uint32_t v = w & mask;
-        const bool ok = v < (uint32_t)n;
-        const unsigned long long bal = __ballot(ok);
-        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0));
-        const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)pre, i);
-        if (ok) C[(int64_t)base + rank] = (uint16_t)(4u * v);
+        for (int i = 0; i < RTAB_CHUNK; i++) {
+            const uint32_t b = b0 + i;
+            if (b >= a.n_blk) break;
+            const uint32_t w = a.raw[(int64_t)b * 64 + lane];
+            const uint32_t v = w & mask;
+            const bool ok = v < (uint32_t)n;
+            const unsigned long long bal = __ballot(ok);
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0));
+            const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)pre, i);
+            if (ok) C[(int64_t)base + rank] = (uint16_t)(4u * v);
+        }
     }
 }
 
@@ -283,21 +303,22 @@ __global__ __launch_bounds__(256) void rtab_order_kernel(const int64_t *off, int
 // The pooling proper: one wavefront per site.
 // =====================================================================================
 struct __attribute__((packed, aligned(2))) IdxRow20 { uint32_t w[10]; };
-
 // the K draws of one iteration: gather 1-p at the row's byte offsets, multiply left to right (np.prod's order)
-__device__ __forceinline__ float rtab_product20(const IdxRow20 &r, const char *bagb)
+__device__ __forceinline__ float rtab_product20w(const uint32_t (&w)[10], const char *bagb)
 {
     float g[20];
 #pragma unroll
     for (int j = 0; j < 10; j++) {
-        g[2 * j] = *(const float *)(bagb + (r.w[j] & 0xffffu));
-        g[2 * j + 1] = *(const float *)(bagb + (r.w[j] >> 16));
+        g[2 * j] = *(const float *)(bagb + (w[j] & 0xffffu));
+        g[2 * j + 1] = *(const float *)(bagb + (w[j] >> 16));
     }
     float prod = 1.0f;
 #pragma unroll
     for (int k = 0; k < 20; k++) prod *= g[k];
     return prod;
 }
+
+__device__ __forceinline__ float rtab_product20(const IdxRow20 &r, const char *bagb) { return rtab_product20w(r.w, bagb); }
 
 __device__ __forceinline__ float rtab_product_any(const uint16_t *row, const char *bagb, int K)
 {
@@ -379,15 +400,15 @@ __global__ __launch_bounds__(256) void pool_rtab_kernel(PoolArgs a, RtabUse u)
         const int64_t step = (int64_t)8 * K;
         float sum = 0.0f;
         if (KT == 20) {
-            // the index row of round i+1 is in flight while round i gathers and multiplies
-            IdxRow20 nxt = *(const IdxRow20 *)(my_rounds > 0 ? row : tb);
+            // (Tried on the configs[4] shape and dropped, neither faster than this plain loop at 0.60 ms: fetching the
+            // index row of round i+1 by hand while round i runs, 0.62 ms; additionally issuing the ten gathers of the
+            // next half row before the ten multiplies of the current one, 0.63 ms.  Seven to eight resident waves per
+            // SIMD already cover those latencies.)
             for (int i = 0; i < rounds; ++i) {
-                const IdxRow20 cur = nxt;
                 const bool live = i < my_rounds;
-                row += step;
-                nxt = *(const IdxRow20 *)(i + 1 < my_rounds ? row : tb);
-                const float v = 1.0f - rtab_product20(cur, bagb);
+                const float v = 1.0f - rtab_product20(*(const IdxRow20 *)(live ? row : tb), bagb);
                 sum += live ? v : 0.0f;
+                row += step;
             }
         } else {
             for (int i = 0; i < rounds; ++i) {

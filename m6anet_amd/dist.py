@@ -101,3 +101,37 @@ def gather_sites(site, mod, cuts, dst=0, group=None, buffers=None):
         buffers["g"] = SiteGather(cuts, site.device, dst=dst, group=group)
     g = buffers["g"]
     return g.finish(g.start(site, mod))
+
+
+class NativeGather:
+    """The same exchange on the C ABI's own communicator (include/m6a.h: m6a_comm_init / m6a_gather): one grouped
+    ncclSend/ncclRecv over xGMI, shards written at their offsets without padding.  The 128-byte RCCL id travels
+    over the launcher's process group (any backend).  `start`/`drain` mirror SiteGather so bench.py can use either."""
+
+    def __init__(self, engine, cuts, device, dst=0):
+        import torch
+        import torch.distributed as dist
+        from .engine import comm_unique_id
+        self.engine, self.cuts, self.dst = engine, np.asarray(cuts, np.int64), dst
+        rank, world = dist.get_rank(), dist.get_world_size()
+        ident = [comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ident, src=0)
+        engine.comm_init(ident[0], rank, world)
+        total = int(self.cuts[-1])
+        self.out = [(torch.empty(total, dtype=torch.float32, device=device), torch.empty(total, dtype=torch.float64, device=device))
+                    if rank == dst else None for _ in range(2)]
+        self.slot = 0
+
+    def start(self, site, mod):
+        k = self.slot
+        self.engine.gather(site, mod, self.cuts, self.dst, out=self.out[k])      # stream-ordered behind the pooling kernel
+        self.slot ^= 1
+        return k
+
+    def finish(self, k=None):
+        self.engine.sync()
+        o = self.out[self.slot ^ 1 if k is None else k]
+        return o if o is not None else (None, None)
+
+    def drain(self):
+        self.engine.sync()

@@ -138,6 +138,37 @@ class M6ANetEngine:
     def sync(self):
         self._chk(self._L.m6a_sync(self._h))
 
+    # -- the multi-GPU exchange on the library's own RCCL communicator (include/m6a.h: m6a_gather) --------
+    def comm_init(self, unique_id, rank, world_size):
+        """unique_id: the 128 bytes rank 0 got from `comm_unique_id()`, handed to every rank by the launcher."""
+        buf = (C.c_char * 128).from_buffer_copy(bytes(unique_id))
+        self._chk(self._L.m6a_comm_init(self._h, buf, int(rank), int(world_size)))
+        self._comm = (int(rank), int(world_size))
+
+    def comm_destroy(self):
+        self._chk(self._L.m6a_comm_destroy(self._h))
+
+    def gather(self, site, mod, cuts, dst=0, out=None):
+        """site_prob / mod_ratio of this rank's shard (torch tensors on the context's GPU) to rank `dst` in ONE
+        grouped RCCL exchange on the context's stream; returns (site_all, mod_all) on dst, (None, None) elsewhere."""
+        import torch
+        rank, world = self._comm
+        cuts = np.ascontiguousarray(cuts, np.int64)
+        assert cuts.size == world + 1
+        aS, aM = _Arg(site, np.float32, "float32"), _Arg(mod, np.float64, "float64")
+        total = int(cuts[-1] - cuts[0])
+        sa = ma = None
+        if rank == dst:
+            sa, ma = out if out is not None else (torch.empty(total, dtype=torch.float32, device=site.device),
+                                                  torch.empty(total, dtype=torch.float64, device=site.device))
+        self._chk(self._L.m6a_gather(self._h, aS.ptr, aM.ptr, cuts.ctypes.data, int(dst),
+                                     sa.data_ptr() if sa is not None else None, ma.data_ptr() if ma is not None else None))
+        return sa, ma
+
+    def prepare_host_io(self):
+        """Pin the staging ring of the host-pointer path now (otherwise the first numpy-array call does it)."""
+        self._chk(self._L.m6a_prepare_host_io(self._h))
+
     def profile(self, on=True):
         self._chk(self._L.m6a_profile_enable(self._h, 1 if on else 0))
 
@@ -245,6 +276,16 @@ class M6ANetEngine:
                                        int(seed) & 0xffffffff, aP.ptr if aP else None, aY.ptr, aA.ptr))
         y = y.reshape(int(n_iterations), S)
         return (y, avg, rp) if want_read_probs else (y, avg)
+
+
+def comm_unique_id():
+    """128-byte RCCL id for `M6ANetEngine.comm_init` (call on ONE rank, broadcast to the others)."""
+    buf = (C.c_char * 128)()
+    L = _lib.load()
+    rc = L.m6a_comm_unique_id(buf)
+    if rc != 0:
+        raise _lib.M6AError(rc, L.m6a_last_error(None).decode())
+    return bytes(buf.raw)
 
 
 def flush_groups(n_sites, batch_size=16, save_per_batch=2):

@@ -93,6 +93,7 @@ def main(args):
     def make_engine():
         try:
             made["engine"] = M6ANetEngine(weights=weights, device=_device_index(args.device))
+            made["engine"].prepare_host_io()     # pinned staging for the host arrays the loader is producing
         except BaseException as exc:        # re-raised on the main thread below
             made["error"] = exc
 
