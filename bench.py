@@ -193,6 +193,9 @@ def main():
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--enc-variant", type=int, default=0, help="0 auto, 1 general 16-slot, 2 12-slot encoder kernel")
     ap.add_argument("--scan-driver", type=int, default=0, help="ragged bags: 0 auto, 1 per group, 2 per site, 3 index tables")
+    ap.add_argument("--verify", action="store_true",
+                    help="after the timed steps rank 0 recomputes the WHOLE job unsharded on its GPU and checks that the gathered "
+                         "site_prob / mod_ratio equal it bit for bit (small --sites only: rank 0 holds the whole job)")
     args = ap.parse_args()
 
     if args.cpu_baseline_only:
@@ -304,6 +307,21 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt, first_call_ms = float(tmax[0].item()), float(tmax[1].item())
 
+    verified = None
+    if args.verify:
+        got = gather.finish() if gather is not None else (site, mod)
+        if rank == 0:
+            parts = [synthetic.make_sites(int(cuts[r + 1] - cuts[r]), seed=20250328 + r, n_reads=n_reads_job[int(cuts[r]):int(cuts[r + 1])])
+                     for r in range(world)]
+            wX = torch.from_numpy(np.concatenate([p["X"] for p in parts])).to(dev)
+            wk = torch.from_numpy(np.concatenate([p["site_kmers"] for p in parts])).to(dev)
+            whole = M6ANetEngine(weights=weights, device=local_rank)
+            _, w_site, w_mod = whole.infer(wX, wk, torch.from_numpy(off_job).to(dev), T, 20, thr, 0, 16, 2, want_read_probs=False)
+            whole.sync()
+            verified = bool(np.array_equal(got[0].cpu().numpy(), w_site.cpu().numpy()) and
+                            np.array_equal(got[1].cpu().numpy(), w_mod.cpu().numpy()))
+            whole.close()
+
     if rank == 0:
         total_sites = int(cuts[-1])
         enc_avg_ms = enc_ms / max(enc_n, 1)
@@ -334,6 +352,7 @@ def main():
                                    % (("RCCL (m6a_gather)" if native_gather else "RCCL (torch.distributed)") if backend == "nccl" else backend)
                                    if world > 1 else "none"},
             "first_call_ms": first_call_ms,
+            "verify": verified,
             "roofline": {"kernel": "read encoder (%s)" % eng.last_encoder_variant, "bound": "mfma", "achieved": enc_tflops,
                          "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": enc_tflops / PEAK_F32_TFLOPS,
                          "traffic": tr["traffic_bytes_per_launch"] if tr else None,

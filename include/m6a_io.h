@@ -48,6 +48,17 @@ const int32_t *m6a_io_read_rep(const m6a_sites *s);        /* [R] replicate of e
 const char *m6a_io_tx_id(const m6a_sites *s, int64_t site);    /* NUL-terminated */
 const char *m6a_io_kmer5(const m6a_sites *s, int64_t site);    /* centre 5-mer, NUL-terminated */
 
+/* Binary site store: everything m6a_io_load_sites produces -- normalised features,
+ * k-mer ids, CSR offsets, ids -- in one file, so a dataset is parsed from data.json ONCE and every later run maps it
+ * (replaces the per-item seek + json.loads + normalise of NanopolishDS.__getitem__, m6anet/utils/data_utils.py:
+ * 152-231, written by m6anet/utils/dataprep_utils.py:473-485).  m6a_io_open_store maps the file read-only: the
+ * arrays are views into the page cache, nothing is copied or parsed; the host-pointer path of m6a_infer streams X
+ * from the mapping through its pinned ring.  `tag` (<= 63 chars) records what the features were normalised with;
+ * m6a_io_store_tag returns it ("" for sites that came from m6a_io_load_sites). */
+int m6a_io_save_store(const m6a_sites *s, const char *path, const char *tag);
+int m6a_io_open_store(const char *path, m6a_sites **out);
+const char *m6a_io_store_tag(const m6a_sites *s);
+
 /* Appends the rows of all sites to <out_dir>/data.site_proba.csv and data.indiv_proba.csv
  * (headers are written when write_header != 0, truncating the files like
  * m6anet/scripts/inference.py:94-97).  read_prob [R], site_prob [S], mod_ratio [S]. */

@@ -1,9 +1,9 @@
-"""`python -m m6anet_amd {dataprep,inference} ...` -- the hot path and the step before it
+"""`python -m m6anet_amd {dataprep,pack,inference} ...` -- the hot path and the steps before it
 (dispatcher shape of m6anet/__init__.py:11-30)."""
 import sys
 from argparse import ArgumentParser
 
-from .scripts import dataprep, inference
+from .scripts import dataprep, inference, pack
 
 
 def main(argv=None):
@@ -11,8 +11,9 @@ def main(argv=None):
     sub = parser.add_subparsers(dest="command", required=True)
     sub.add_parser("inference", parents=[inference.argparser()], help="run the MI355X inference hot path")
     sub.add_parser("dataprep", parents=[dataprep.argparser()], help="eventalign.txt -> data.json / data.info (native, host-only)")
+    sub.add_parser("pack", parents=[pack.argparser()], help="data.json / data.info -> one binary site store that later runs map")
     args = parser.parse_args(argv)
-    {"inference": inference, "dataprep": dataprep}[args.command].main(args)
+    {"inference": inference, "dataprep": dataprep, "pack": pack}[args.command].main(args)
 
 
 if __name__ == "__main__":

@@ -9,7 +9,7 @@ LIB_PATH = os.path.join(_PKG, "libm6a_io.so")
 SYMBOLS = ["m6a_io_last_error", "m6a_io_load_sites", "m6a_io_free", "m6a_io_n_sites", "m6a_io_n_reads",
            "m6a_io_n_replicates", "m6a_io_X", "m6a_io_site_kmers", "m6a_io_off", "m6a_io_tx_pos",
            "m6a_io_read_ids", "m6a_io_read_rep", "m6a_io_tx_id", "m6a_io_kmer5", "m6a_io_write_csv", "m6a_io_write_csv_n",
-           "m6a_io_dataprep"]
+           "m6a_io_save_store", "m6a_io_open_store", "m6a_io_store_tag", "m6a_io_dataprep"]
 _lib = None
 
 
@@ -40,6 +40,10 @@ def load():
         getattr(L, name).restype = C.c_char_p
     L.m6a_io_write_csv.argtypes = [vp, C.c_char_p, vp, vp, vp, i32, i32]
     L.m6a_io_write_csv_n.argtypes = [vp, C.c_char_p, vp, vp, vp, i32, i32, i64]
+    L.m6a_io_save_store.argtypes = [vp, C.c_char_p, C.c_char_p]
+    L.m6a_io_open_store.argtypes = [C.c_char_p, C.POINTER(vp)]
+    L.m6a_io_store_tag.argtypes = [vp]
+    L.m6a_io_store_tag.restype = C.c_char_p
     L.m6a_io_dataprep.argtypes = [C.c_char_p, C.c_char_p, i32, i32, i32, i32, i32, i32, i32]
     _lib = L
     return L
@@ -62,20 +66,25 @@ def dataprep(eventalign, out_dir, n_threads=0, readcount_min=1, readcount_max=10
 class NativeSites:
     """Owns an m6a_sites handle; exposes its arrays as zero-copy numpy views."""
 
-    def __init__(self, input_dirs, min_reads, norm, n_threads=0):
+    def __init__(self, input_dirs=None, min_reads=20, norm=None, n_threads=0, store=None):
+        """Either parses `input_dirs` (data.info + data.json per directory) or maps a binary site `store` file."""
         L = load()
-        dirs = (C.c_char_p * len(input_dirs))(*[os.fsencode(d) for d in input_dirs])
-        if norm:
-            kmers = sorted(norm)
-            blob = "".join(kmers).encode()
-            mean = np.ascontiguousarray([norm[k][0] for k in kmers], np.float64)
-            std = np.ascontiguousarray([norm[k][1] for k in kmers], np.float64)
-            args = (blob, mean.ctypes.data, std.ctypes.data, len(kmers))
-        else:
-            args = (None, None, None, 0)
         h = C.c_void_p()
-        _chk(L.m6a_io_load_sites(dirs, len(input_dirs), int(min_reads), *args, int(n_threads), C.byref(h)))
+        if store is not None:
+            _chk(L.m6a_io_open_store(os.fsencode(store), C.byref(h)))
+        else:
+            dirs = (C.c_char_p * len(input_dirs))(*[os.fsencode(d) for d in input_dirs])
+            if norm:
+                kmers = sorted(norm)
+                blob = "".join(kmers).encode()
+                mean = np.ascontiguousarray([norm[k][0] for k in kmers], np.float64)
+                std = np.ascontiguousarray([norm[k][1] for k in kmers], np.float64)
+                args = (blob, mean.ctypes.data, std.ctypes.data, len(kmers))
+            else:
+                args = (None, None, None, 0)
+            _chk(L.m6a_io_load_sites(dirs, len(input_dirs), int(min_reads), *args, int(n_threads), C.byref(h)))
         self._h, self._L = h, L
+        self.tag = L.m6a_io_store_tag(h).decode()
         S, R = L.m6a_io_n_sites(h), L.m6a_io_n_reads(h)
         self.n_replicates = L.m6a_io_n_replicates(h)
 
@@ -96,6 +105,10 @@ class NativeSites:
 
     def kmer5(self, i):
         return self._L.m6a_io_kmer5(self._h, i).decode()
+
+    def save_store(self, path, tag=""):
+        """Writes everything this handle holds as one binary site store (include/m6a_io.h)."""
+        _chk(self._L.m6a_io_save_store(self._h, os.fsencode(path), tag.encode()[:63]))
 
     def write_csv(self, out_dir, read_prob, site_prob, mod_ratio, write_header=False, n_threads=0, n_sites=None):
         rp = np.ascontiguousarray(read_prob, np.float32)

@@ -3,7 +3,7 @@
 Mirrors the values the reference keeps in m6anet/utils/constants.py:8-37 (pretrained
 registry, thresholds, min reads, the 66-entry 5-mer vocabulary and the 18 DRACH motifs)
 and m6anet/utils/data_utils.py:89-96 (same vocabulary built inside the dataset).
-Nothing is imported from the reference; tests/test_host_logic.py checks the vocabulary
+Nothing is imported from the reference; tests/test_abi_and_host.py checks the vocabulary
 against tests/golden/vocab66.txt (captured from the reference).
 """
 import os

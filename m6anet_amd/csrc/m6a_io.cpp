@@ -237,6 +237,24 @@ struct m6a_sites {
     RawBuf<double> read_ids;
     RawBuf<int32_t> read_rep;
     std::vector<std::string> tx_ids, kmer5;
+    // what the accessors and the writers read: the owned buffers above after m6a_io_load_sites, or the file
+    // mapping of a binary site store (m6a_io_open_store) -- zero-copy, the kernel pages it in on first touch
+    const float *vX = nullptr;
+    const uint8_t *vK = nullptr;
+    const int64_t *vOff = nullptr, *vPos = nullptr;
+    const double *vIds = nullptr;
+    const int32_t *vRep = nullptr;
+    int64_t nS = 0, nR = 0;
+    void *map = nullptr;
+    size_t map_len = 0;
+    std::string tag;
+    void view_owned()
+    {
+        vX = X.data(); vK = site_kmers.data(); vOff = off.data(); vPos = tx_pos.data();
+        vIds = read_ids.data(); vRep = read_rep.data();
+        nS = (int64_t)tx_pos.size(); nR = off.empty() ? 0 : off.back();
+    }
+    ~m6a_sites() { if (map) munmap(map, map_len); }
 };
 
 namespace {
@@ -429,20 +447,138 @@ int m6a_io_load_sites(const char *const *input_dirs, int n_dirs, int min_reads, 
     for (auto &t : th) t.join();
     for (int w = 0; w < nw; w++)
         if (rcs[(size_t)w]) { g_err = errs[(size_t)w]; delete res; return rcs[(size_t)w]; }
+    res->view_owned();
     *out = res;
     return M6A_IO_OK;
 }
 
 void m6a_io_free(m6a_sites *s) { delete s; }
-int64_t m6a_io_n_sites(const m6a_sites *s) { return s ? (int64_t)s->tx_pos.size() : 0; }
-int64_t m6a_io_n_reads(const m6a_sites *s) { return s ? (int64_t)s->read_ids.size() : 0; }
+int64_t m6a_io_n_sites(const m6a_sites *s) { return s ? s->nS : 0; }
+int64_t m6a_io_n_reads(const m6a_sites *s) { return s ? s->nR : 0; }
 int m6a_io_n_replicates(const m6a_sites *s) { return s ? s->n_rep : 0; }
-const float *m6a_io_X(const m6a_sites *s) { return s->X.data(); }
-const uint8_t *m6a_io_site_kmers(const m6a_sites *s) { return s->site_kmers.data(); }
-const int64_t *m6a_io_off(const m6a_sites *s) { return s->off.data(); }
-const int64_t *m6a_io_tx_pos(const m6a_sites *s) { return s->tx_pos.data(); }
-const double *m6a_io_read_ids(const m6a_sites *s) { return s->read_ids.data(); }
-const int32_t *m6a_io_read_rep(const m6a_sites *s) { return s->read_rep.data(); }
+const float *m6a_io_X(const m6a_sites *s) { return s->vX; }
+const uint8_t *m6a_io_site_kmers(const m6a_sites *s) { return s->vK; }
+const int64_t *m6a_io_off(const m6a_sites *s) { return s->vOff; }
+const int64_t *m6a_io_tx_pos(const m6a_sites *s) { return s->vPos; }
+const double *m6a_io_read_ids(const m6a_sites *s) { return s->vIds; }
+const int32_t *m6a_io_read_rep(const m6a_sites *s) { return s->vRep; }
+const char *m6a_io_store_tag(const m6a_sites *s) { return s ? s->tag.c_str() : ""; }
+
+// ---- binary site store ------------------------------------------------------------------------------------
+// One file, little-endian, every array 64-byte aligned:
+//   header (128 B) | off i64[S+1] | tx_pos i64[S] | site_kmers u8[S][3] | kmer5 char[S][5] | tx_off i64[S+1] |
+//   tx bytes | read_ids f64[R] | read_rep i32[R] | X f32[R][9]
+namespace {
+struct StoreHeader {
+    char magic[8];               // "M6ASITES"
+    uint32_t version, n_rep;
+    int64_t S, R, tx_bytes;
+    char tag[64];                // what the features were normalised with (the caller's label, e.g. "norm_hct116.npz min_reads=20")
+    char pad[24];
+};
+static_assert(sizeof(StoreHeader) == 128, "store header is 128 bytes");
+size_t align64(size_t x) { return (x + 63) & ~(size_t)63; }
+struct StoreLayout { size_t off, pos, km, k5, txo, txb, ids, rep, x, end; };
+StoreLayout store_layout(int64_t S, int64_t R, int64_t tx_bytes)
+{
+    StoreLayout l;
+    size_t p = sizeof(StoreHeader);
+    l.off = p; p = align64(p + (size_t)(S + 1) * 8);
+    l.pos = p; p = align64(p + (size_t)S * 8);
+    l.km = p; p = align64(p + (size_t)S * 3);
+    l.k5 = p; p = align64(p + (size_t)S * 5);
+    l.txo = p; p = align64(p + (size_t)(S + 1) * 8);
+    l.txb = p; p = align64(p + (size_t)tx_bytes);
+    l.ids = p; p = align64(p + (size_t)R * 8);
+    l.rep = p; p = align64(p + (size_t)R * 4);
+    l.x = p; p = p + (size_t)R * 9 * 4;
+    l.end = p;
+    return l;
+}
+}  // namespace
+
+int m6a_io_save_store(const m6a_sites *s, const char *path, const char *tag)
+{
+    if (!s || !path) return fail(M6A_IO_EINVAL, "null argument");
+    const int64_t S = s->nS, R = s->nR;
+    std::vector<int64_t> txo((size_t)S + 1, 0);
+    for (int64_t i = 0; i < S; i++) txo[(size_t)i + 1] = txo[(size_t)i] + (int64_t)s->tx_ids[(size_t)i].size();
+    StoreHeader h;
+    std::memset(&h, 0, sizeof h);
+    std::memcpy(h.magic, "M6ASITES", 8);
+    h.version = 1; h.n_rep = (uint32_t)s->n_rep; h.S = S; h.R = R; h.tx_bytes = txo[(size_t)S];
+    if (tag) std::strncpy(h.tag, tag, sizeof h.tag - 1);
+    const StoreLayout l = store_layout(S, R, h.tx_bytes);
+    const std::string tmp = std::string(path) + ".tmp";
+    FILE *f = fopen(tmp.c_str(), "wb");
+    if (!f) return fail(M6A_IO_EIO, "cannot write %s", tmp.c_str());
+    bool ok = true;
+    size_t at = 0;
+    auto put = [&](size_t where, const void *p, size_t n) {
+        static const char zeros[64] = {0};
+        while (ok && at < where) { const size_t k = std::min<size_t>(64, where - at); ok = fwrite(zeros, 1, k, f) == k; at += k; }
+        if (ok && n) { ok = fwrite(p, 1, n, f) == n; at += n; }
+    };
+    std::string k5((size_t)S * 5, ' '), txb;
+    txb.reserve((size_t)h.tx_bytes);
+    for (int64_t i = 0; i < S; i++) {
+        std::memcpy(&k5[(size_t)i * 5], s->kmer5[(size_t)i].data(), std::min<size_t>(5, s->kmer5[(size_t)i].size()));
+        txb += s->tx_ids[(size_t)i];
+    }
+    put(0, &h, sizeof h);
+    put(l.off, s->vOff, (size_t)(S + 1) * 8);
+    put(l.pos, s->vPos, (size_t)S * 8);
+    put(l.km, s->vK, (size_t)S * 3);
+    put(l.k5, k5.data(), k5.size());
+    put(l.txo, txo.data(), txo.size() * 8);
+    put(l.txb, txb.data(), txb.size());
+    put(l.ids, s->vIds, (size_t)R * 8);
+    put(l.rep, s->vRep, (size_t)R * 4);
+    put(l.x, s->vX, (size_t)R * 9 * 4);
+    if (fclose(f) != 0) ok = false;
+    if (!ok || rename(tmp.c_str(), path) != 0) { remove(tmp.c_str()); return fail(M6A_IO_EIO, "cannot write %s", path); }
+    return M6A_IO_OK;
+}
+
+int m6a_io_open_store(const char *path, m6a_sites **out)
+{
+    if (!path || !out) return fail(M6A_IO_EINVAL, "null argument");
+    *out = nullptr;
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return fail(M6A_IO_EIO, "cannot open %s", path);
+    struct stat st;
+    if (fstat(fd, &st) != 0 || (size_t)st.st_size < sizeof(StoreHeader)) { close(fd); return fail(M6A_IO_EFORMAT, "%s is not a site store", path); }
+    void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (m == MAP_FAILED) return fail(M6A_IO_EIO, "cannot map %s", path);
+    const char *b = (const char *)m;
+    StoreHeader h;
+    std::memcpy(&h, b, sizeof h);
+    const bool sane = std::memcmp(h.magic, "M6ASITES", 8) == 0 && h.version == 1 && h.S >= 0 && h.R >= 0 && h.tx_bytes >= 0 &&
+                      h.S < ((int64_t)1 << 40) && h.R < ((int64_t)1 << 44) && h.tx_bytes < ((int64_t)1 << 40);
+    StoreLayout l{};
+    if (sane) l = store_layout(h.S, h.R, h.tx_bytes);
+    if (!sane || l.end != (size_t)st.st_size) { munmap(m, (size_t)st.st_size); return fail(M6A_IO_EFORMAT, "%s: bad header or truncated store", path); }
+    m6a_sites *s = new (std::nothrow) m6a_sites;
+    if (!s) { munmap(m, (size_t)st.st_size); return fail(M6A_IO_ENOMEM, "out of memory"); }
+    s->map = m; s->map_len = (size_t)st.st_size;
+    s->n_rep = (int)h.n_rep; s->nS = h.S; s->nR = h.R;
+    h.tag[sizeof h.tag - 1] = 0;
+    s->tag = h.tag;
+    s->vOff = (const int64_t *)(b + l.off); s->vPos = (const int64_t *)(b + l.pos); s->vK = (const uint8_t *)(b + l.km);
+    s->vIds = (const double *)(b + l.ids); s->vRep = (const int32_t *)(b + l.rep); s->vX = (const float *)(b + l.x);
+    const int64_t *txo = (const int64_t *)(b + l.txo);
+    bool good = s->vOff[0] == 0 && s->vOff[h.S] == h.R && txo[0] == 0 && txo[h.S] == h.tx_bytes;
+    for (int64_t i = 0; good && i < h.S; i++) good = s->vOff[i + 1] >= s->vOff[i] && txo[i + 1] >= txo[i];
+    if (!good) { delete s; return fail(M6A_IO_EFORMAT, "%s: inconsistent offsets", path); }
+    s->tx_ids.resize((size_t)h.S); s->kmer5.resize((size_t)h.S);
+    for (int64_t i = 0; i < h.S; i++) {
+        s->tx_ids[(size_t)i].assign(b + l.txb + txo[i], (size_t)(txo[i + 1] - txo[i]));
+        s->kmer5[(size_t)i].assign(b + l.k5 + i * 5, 5);
+    }
+    *out = s;
+    return M6A_IO_OK;
+}
 const char *m6a_io_tx_id(const m6a_sites *s, int64_t i) { return s->tx_ids[(size_t)i].c_str(); }
 const char *m6a_io_kmer5(const m6a_sites *s, int64_t i) { return s->kmer5[(size_t)i].c_str(); }
 
@@ -468,7 +604,7 @@ int m6a_io_write_csv_n(const m6a_sites *s, const char *out_dir, const float *rea
     }
     // rows are formatted in parallel into per-chunk strings, written in order
     const int nw = n_workers(n_threads, S);
-    const int64_t R = s->off[(size_t)S];
+    const int64_t R = s->vOff[S];
     int rc = 0;
     // one chunk per worker per round; chunks of at most 2^20 reads bound the text held in memory
     // (~64 MB per worker), at least 2^14 so tiny jobs do not spawn idle threads
@@ -477,8 +613,8 @@ int m6a_io_write_csv_n(const m6a_sites *s, const char *out_dir, const float *rea
     while (s_begin < S && !rc) {
         std::vector<int64_t> cuts{s_begin};
         for (int w = 0; w < nw && cuts.back() < S; w++) {
-            const int64_t target = std::min(R, s->off[(size_t)cuts.back()] + chunk_reads);
-            int64_t e = std::upper_bound(s->off.begin(), s->off.end(), target) - s->off.begin() - 1;
+            const int64_t target = std::min(R, s->vOff[cuts.back()] + chunk_reads);
+            int64_t e = std::upper_bound(s->vOff, s->vOff + s->nS + 1, target) - s->vOff - 1;
             e = std::min<int64_t>(S, std::max<int64_t>(e, cuts.back() + 1));
             cuts.push_back(e);
         }
@@ -488,24 +624,24 @@ int m6a_io_write_csv_n(const m6a_sites *s, const char *out_dir, const float *rea
             std::string &a = site_txt[(size_t)w], &b = indiv_txt[(size_t)w];
             char buf[128];
             for (int64_t i = cuts[(size_t)w]; i < cuts[(size_t)w + 1]; i++) {
-                const int64_t r0 = s->off[(size_t)i], r1 = s->off[(size_t)i + 1];
+                const int64_t r0 = s->vOff[i], r1 = s->vOff[i + 1];
                 // '%s,%d,%s,%.16f,%s,%.16f'  (inference_utils.py:62)
                 a += s->tx_ids[(size_t)i];
-                snprintf(buf, sizeof buf, ",%lld,%lld,%.16f,", (long long)s->tx_pos[(size_t)i], (long long)(r1 - r0), (double)site_prob[i]);
+                snprintf(buf, sizeof buf, ",%lld,%lld,%.16f,", (long long)s->vPos[i], (long long)(r1 - r0), (double)site_prob[i]);
                 a += buf;
                 a += s->kmer5[(size_t)i];
                 snprintf(buf, sizeof buf, ",%.16f\n", mod_ratio[i]);
                 a += buf;
                 // '%s,%d,%s,%.16f'  (inference_utils.py:66); read ids: str(float64), or "<int>_<rep>"
-                snprintf(buf, sizeof buf, ",%lld,", (long long)s->tx_pos[(size_t)i]);
+                snprintf(buf, sizeof buf, ",%lld,", (long long)s->vPos[i]);
                 const std::string head = s->tx_ids[(size_t)i] + buf;
                 for (int64_t r = r0; r < r1; r++) {
                     b += head;
                     if (s->n_rep > 1) {
-                        snprintf(buf, sizeof buf, "%lld_%d", (long long)s->read_ids[(size_t)r], (int)s->read_rep[(size_t)r]);
+                        snprintf(buf, sizeof buf, "%lld_%d", (long long)s->vIds[r], (int)s->vRep[r]);
                         b += buf;
                     } else {
-                        format_py_float(s->read_ids[(size_t)r], b);
+                        format_py_float(s->vIds[r], b);
                     }
                     snprintf(buf, sizeof buf, ",%.16f\n", (double)read_prob[r]);
                     b += buf;

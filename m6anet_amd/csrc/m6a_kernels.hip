@@ -9,6 +9,8 @@
 //                      flush group finds where each site starts in the shared MT19937 word stream
 //                      (masked rejection), then one wavefront per site compacts its accepted draws
 //                      through LDS and multiplies the 20-term products; or one wavefront per group.
+//                      (Large ragged jobs with bags <= 1024 take pool_rtab_kernel, m6a_pool_rtab.hip,
+//                      instead: per-bag-size index tables, no compaction at all.)
 //   pool_table_kernel  same result when every bag has the same size n <= 32: the accepted index
 //                      sequence is then identical in every flush group, so it is a precomputed table
 //                      and the kernel is a pure LDS gather, 8 sites per pass.  (The default for uniform
@@ -257,8 +259,9 @@ __global__ __launch_bounds__(256, 2) void enc_kernel(EncArgs a)
 //                  c_s[u] = b1'[u] + sum_e W1'[u][9+e] * emb_e(s)          (exact same terms),
 // i.e. 6 K-steps per unit tile instead of 8: 110 MFMAs per tile instead of 120.  The c vectors
 // (A operands of the indicator steps) are rebuilt for every tile on the VALU, in the shadow of the
-// matrix pipe: the 18 embedding floats of the three sites are fetched by lanes 0..17, broadcast
-// with v_readlane, and folded against W1'[:, 9..14] (kept in LDS, one row per lane) with 60 FMAs.
+// matrix pipe: the 18 embedding floats of the three sites are fetched by lanes 0..17, pulled into
+// (x, y) pairs over the LDS crossbar with ds_bpermute (not a VALU instruction), and folded against
+// W1'[:, 9..14] (kept in LDS, one row per lane) with 30 v_pk_fma_f32 -- two site vectors per FMA.
 // Lane halves: h=0 supplies slots x0,x2,x4,x6,x8,I(a+1); h=1 supplies x1,x3,x5,x7,I(a),I(a+2).
 // Everything else (layer 2, ReLU batching, ping-pong, epilogue, input prefetch chain) is as in
 // enc_kernel.  A tile that would need a fourth site raises the error flag (the host only
@@ -461,12 +464,13 @@ __global__ __launch_bounds__(256, 2) void enc_csite_kernel(EncArgs a)
 //
 // scan_site() replays one site from a given stream position.  Per step 64 consecutive words are
 // masked and range-tested; accepted lanes get their rank by ballot + mbcnt, gather 1-p from the
-// LDS bag and store it at ring slot cnt+rank.  The ring holds two windows of 32 iterations
-// (CH = 32*K slots each); a slot lives at dword slot + slot/4, which makes the stride between
-// iterations K*5/4 (25 for K = 20: odd, so the per-iteration read-back is bank-conflict-free, and
-// with K % 4 == 0 every read offset is a compile-time immediate) at no division.  When a window
-// fills, lanes 0..31 multiply their K values left to right (float32, the order of np.prod) and
-// add 1-prod.  The step that completes the site finds the lane holding the last accepted draw;
+// LDS bag and store it at buffer slot cnt+rank.  The buffer is ONE window of 32 iterations
+// (CH = 32*K slots) plus the <= 255 draws that arrive before the per-block window check; a slot
+// lives at dword slot + slot/4, which makes the stride between iterations K*5/4 (25 for K = 20:
+// odd, so the per-iteration read-back is bank-conflict-free, and with K % 4 == 0 every read offset
+// is a compile-time immediate) at no division.  When the window is full, lanes 0..31 multiply their
+// K values left to right (float32, the order of np.prod), add 1-prod, and the overhang is moved
+// down to slot 0.  The step that completes the site finds the lane holding the last accepted draw;
 // the next site starts at the following word, exactly like the sequential NumPy loop.
 //
 // Where a site starts depends on how many words every earlier site of its group rejected.  Two

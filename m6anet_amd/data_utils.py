@@ -87,6 +87,37 @@ def load_sites_native(input_dirs, min_reads=DEFAULT_MIN_READS, norm_path=None, n
     return SiteBatch(nat.X, nat.site_kmers, nat.off, None, nat.tx_pos, None, None, native=nat)
 
 
+STORE_SUFFIX = ".m6astore"
+
+
+def store_tag(norm_path, min_reads=DEFAULT_MIN_READS):
+    """What a binary site store was built with (it holds NORMALISED features of the sites that passed the
+    read-count filter): checked when the store is opened for a model."""
+    return "%s min_reads=%d" % (os.path.basename(str(norm_path)), min_reads)
+
+
+def pack_sites(input_dirs, out_path, min_reads=DEFAULT_MIN_READS, norm_path=None, n_threads=0):
+    """data.info + data.json (one directory, or several replicates) -> one binary site store: the dataset is parsed
+    and normalised once, later runs map the file."""
+    from . import _io
+    if isinstance(input_dirs, str):
+        input_dirs = [input_dirs]
+    nat = _io.NativeSites(list(input_dirs), min_reads, load_norm_factors(norm_path), n_threads)
+    nat.save_store(out_path, store_tag(norm_path, min_reads))
+    return nat
+
+
+def open_store(path, norm_path=None, min_reads=DEFAULT_MIN_READS):
+    """Maps a binary site store (zero-copy views into the page cache).  Refuses a store that was normalised with
+    other factors / another read-count filter than the ones asked for."""
+    from . import _io
+    nat = _io.NativeSites(store=path)
+    if norm_path is not None and nat.tag != store_tag(norm_path, min_reads):
+        raise ValueError("%s was packed with '%s', this run needs '%s': re-run `m6anet_amd pack`"
+                         % (path, nat.tag, store_tag(norm_path, min_reads)))
+    return SiteBatch(nat.X, nat.site_kmers, nat.off, None, nat.tx_pos, None, None, native=nat)
+
+
 def load_sites(input_dirs, min_reads=DEFAULT_MIN_READS, norm_path=None,
                num_neighboring_features=NUM_NEIGHBORING_FEATURES):
     """input_dirs: one directory (NanopolishDS) or several (NanopolishReplicateDS).  Pure-Python

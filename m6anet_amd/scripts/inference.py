@@ -7,7 +7,7 @@ from argparse import ArgumentDefaultsHelpFormatter, ArgumentParser
 
 from ..constants import (DEFAULT_MIN_READS, DEFAULT_PRETRAINED_MODEL, DEFAULT_PRETRAINED_MODELS,
                          DEFAULT_READ_THRESHOLD, N_WEIGHT_FLOATS, PRETRAINED_CONFIGS)
-from ..data_utils import load_sites, load_sites_native
+from ..data_utils import STORE_SUFFIX, load_sites, load_sites_native, open_store
 from ..engine import M6ANetEngine, load_weights, weights_from_state_dict
 from ..inference_utils import INDIV_HEADER, SITE_HEADER, run_inference
 
@@ -15,7 +15,8 @@ from ..inference_utils import INDIV_HEADER, SITE_HEADER, run_inference
 def argparser():
     parser = ArgumentParser(formatter_class=ArgumentDefaultsHelpFormatter, add_help=False)
     parser.add_argument("--input_dir", nargs="*", required=True,
-                        help="directories containing data.info and data.json.")
+                        help="directories containing data.info and data.json, or ONE binary site store written by "
+                             "`m6anet_amd pack` (*%s)." % STORE_SUFFIX)
     parser.add_argument("--out_dir", required=True, help="directory to output inference results.")
     parser.add_argument("--pretrained_model", default=DEFAULT_PRETRAINED_MODEL, type=str,
                         help="pre-trained model available at m6anet. Options include {}.".format(DEFAULT_PRETRAINED_MODELS))
@@ -105,10 +106,15 @@ def main(args):
     with open(os.path.join(args.out_dir, "data.indiv_proba.csv"), "w", encoding="utf-8") as g:
         g.write(INDIV_HEADER)
     # --n_processes is the reference's host-parallelism flag: here it sizes the loader / writer threads
-    try:
-        batch = load_sites_native(args.input_dir, DEFAULT_MIN_READS, args.norm_path, n_threads=args.n_processes)
-    except ImportError:
-        batch = load_sites(args.input_dir, DEFAULT_MIN_READS, args.norm_path)   # libm6a_io.so not built
+    if any(str(d).endswith(STORE_SUFFIX) for d in args.input_dir):
+        if len(args.input_dir) != 1:
+            raise ValueError("--input_dir takes ONE site store (pack replicates together with `m6anet_amd pack`)")
+        batch = open_store(args.input_dir[0], args.norm_path, DEFAULT_MIN_READS)
+    else:
+        try:
+            batch = load_sites_native(args.input_dir, DEFAULT_MIN_READS, args.norm_path, n_threads=args.n_processes)
+        except ImportError:
+            batch = load_sites(args.input_dir, DEFAULT_MIN_READS, args.norm_path)   # libm6a_io.so not built
     starter.join()
     if "error" in made:
         raise made["error"]

@@ -627,6 +627,28 @@ def test_soak_repeated_runs_are_bit_identical(engines):
             eng.set_stream(None)
 
 
+@pytest.mark.parametrize("workload,sites", [("uniform", 3001), ("ragged", 700)])
+def test_bench_self_launch_two_ranks_equal_the_whole_job(workload, sites):
+    """`python bench.py --gpus 2` with no launcher starts its own two ranks (here on gloo, sharing the one GPU of a
+    test box; the 8-GPU run is the same code on backend nccl): every rank runs the HIP engine on its flush-group-
+    aligned shard with the job offset, one gather brings site_prob / mod_ratio to rank 0, and --verify recomputes
+    the whole job unsharded on rank 0's GPU: bit-identical."""
+    import json
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, M6A_BENCH_BACKEND="gloo")
+    out = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--workload", workload, "--sites", str(sites),
+                          "--iters", "60", "--steps", "2", "--warmup", "1", "--verify", "--no-cpu-baseline"],
+                         capture_output=True, text=True, env=env, timeout=900)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, out.stderr[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["verify"] is True
+    assert d["value"] > 0 and d["config"]["sites_per_gpu"] == sites
+
+
 def test_native_rccl_gather_single_rank(eng):
     """m6a_comm_unique_id / m6a_comm_init / m6a_gather (include/m6a.h) on the one GPU a test box has: a
     communicator of one rank still goes through ncclCommInitRank and the grouped ncclSend/ncclRecv (to itself)
@@ -911,6 +933,22 @@ def test_cli_drop_unflushed_tail_writes_the_reference_row_set(tmp_path, golden, 
     assert len(indiv) == int(site["n_reads"].sum())
     full = pd.read_csv(os.path.join(_run_cli(tmp_path / "all", args), "data.site_proba.csv"))
     assert len(full) == 101 and full.iloc[:n].equals(site)
+
+
+def test_cli_from_binary_site_store_equals_cli_from_json(tmp_path):
+    """pack -> inference from the mapped store: byte-identical CSVs to inference from data.json / data.info."""
+    import os
+    from m6anet_amd.__main__ import main
+    data = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_tests_data")
+    store = str(tmp_path / "bundled.m6astore")
+    main(["pack", "--input_dir", data, "--out", store])
+    a = _run_cli(tmp_path / "a", ["--num_iterations", "50"])
+    b = str(tmp_path / "b" / "out")
+    main(["inference", "--input_dir", store, "--out_dir", b, "--n_processes", "1", "--num_iterations", "50"])
+    for fn in ("data.site_proba.csv", "data.indiv_proba.csv"):
+        assert open(os.path.join(a, fn), "rb").read() == open(os.path.join(b, fn), "rb").read(), fn
+    with pytest.raises(ValueError, match="re-run"):                      # a store holds features normalised for one model
+        main(["inference", "--input_dir", store, "--out_dir", b, "--pretrained_model", "arabidopsis_RNA002"])
 
 
 def test_cli_rejects_cpu_device(tmp_path):

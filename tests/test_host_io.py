@@ -146,3 +146,46 @@ def test_native_csv_bytes_equal_python_and_reference(golden, tmp_path):
     nat2.native.write_csv(str(out), rp2, sp2, mr2, write_header=True)
     assert (out / "data.indiv_proba.csv").read_text() == inference_utils.INDIV_HEADER + "".join(inference_utils.format_indiv_rows(py2, rp2))
     assert (out / "data.site_proba.csv").read_text() == inference_utils.SITE_HEADER + "".join(inference_utils.format_site_rows(py2, sp2, mr2))
+
+
+def test_binary_site_store_round_trip(tmp_path):
+    """`m6anet_amd pack`: data.json is parsed once into a binary site store; opening it maps the file and must hand
+    back exactly what the JSON loader produces -- arrays bit for bit, ids, replicate suffixes, CSV bytes -- and it
+    refuses stores packed for other normalisation factors, truncated files and foreign files."""
+    import shutil
+    from m6anet_amd import _io
+    from m6anet_amd.__main__ import main as cli
+    rep = tmp_path / "rep1"
+    rep.mkdir()
+    for fn in ("data.info", "data.json"):
+        shutil.copyfile(os.path.join(DATA, fn), rep / fn)
+    for dirs in ([DATA], [DATA, str(rep)]):
+        path = str(tmp_path / ("n%d.m6astore" % len(dirs)))
+        cli(["pack", "--input_dir"] + dirs + ["--out", path, "--n_processes", "2"])
+        ref = data_utils.load_sites_native(dirs, 20, "norm_hct116.npz")
+        st = data_utils.open_store(path, "norm_hct116.npz", 20)
+        assert st.native.n_replicates == ref.native.n_replicates == len(dirs)
+        for name in ("X", "site_kmers", "off", "tx_pos"):
+            a, b = getattr(st, name), getattr(ref, name)
+            assert a.dtype == b.dtype and np.array_equal(a, b), name
+        assert np.array_equal(st.native.read_id_values, ref.native.read_id_values)
+        assert np.array_equal(st.native.read_rep, ref.native.read_rep)
+        assert st.tx_ids == ref.tx_ids and st.kmer5 == ref.kmer5
+        g = np.random.Generator(np.random.PCG64(9))
+        rp, sp, mr = g.random(ref.X.shape[0], dtype=np.float32), g.random(ref.n_sites, dtype=np.float32), g.random(ref.n_sites)
+        for b, d in ((st, tmp_path / "o_store"), (ref, tmp_path / "o_json")):
+            d.mkdir(exist_ok=True)
+            b.native.write_csv(str(d), rp, sp, mr, write_header=True, n_threads=2)
+        for fn in ("data.site_proba.csv", "data.indiv_proba.csv"):
+            assert (tmp_path / "o_store" / fn).read_bytes() == (tmp_path / "o_json" / fn).read_bytes()
+        with pytest.raises(ValueError, match="re-run"):
+            data_utils.open_store(path, "norm_arabidopsis.npz", 20)          # packed for other norm factors
+        raw = open(path, "rb").read()
+        st.native.close()
+        ref.native.close()
+    (tmp_path / "cut.m6astore").write_bytes(raw[:len(raw) // 2])
+    (tmp_path / "junk.m6astore").write_bytes(b"not a store" * 100)
+    (tmp_path / "magic.m6astore").write_bytes(b"X" + raw[1:])
+    for bad in ("cut", "junk", "magic", "missing"):
+        with pytest.raises(_io.M6AIOError):
+            data_utils.open_store(str(tmp_path / (bad + ".m6astore")))
