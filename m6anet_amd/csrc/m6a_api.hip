@@ -901,8 +901,10 @@ int staged_encode(m6a_ctx *c, const float *X, const uint8_t *km, const int64_t *
     HIPCHK(c, c->sK.ensure((size_t)S * 3));
     HIPCHK(c, c->sOff.ensure((size_t)(S + 1) * 8));
     HIPCHK(c, c->sP.ensure((size_t)std::max<int64_t>(R, 1) * 4));
-    // small jobs (and single bags larger than a staging slot) are not worth a pinned ring: plain copies
-    const bool small = !g.ready && (size_t)R * 9 * 4 < ((size_t)8 << 20);
+    // Jobs under ~200 MB of features are not worth SETTING UP the pinned ring (pinning its 80 MB costs 15-40 ms once
+    // per context, a 72 MB job copies in 2.4 ms without it): plain copies, unless the ring already exists
+    // (m6a_prepare_host_io, or an earlier large call).  Single bags larger than a slot take the plain path too.
+    const bool small = !g.ready && (size_t)R * 9 * 4 < ((size_t)192 << 20);
     int rc = small ? M6A_OK : ensure_staging(c);
     if (rc) return rc;
     if (small || R == 0 || c->bag_max > g.chunk_reads) {

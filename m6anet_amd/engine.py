@@ -49,6 +49,28 @@ def weights_from_state_dict(sd):
     return w
 
 
+_libc = None
+
+
+def _hint_huge_pages(a):
+    """A fresh output array is first touched by the library's copy threads; with 4 KB pages that is tens of
+    thousands of page faults (80 MB of read probabilities per million sites).  Ask for transparent huge pages on
+    its 2 MB-aligned interior -- best effort, any failure is ignored."""
+    global _libc
+    if a.nbytes < (8 << 20):
+        return
+    try:
+        if _libc is None:
+            _libc = C.CDLL(None, use_errno=True)
+            _libc.madvise.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
+        lo = (a.ctypes.data + (1 << 21) - 1) & ~((1 << 21) - 1)
+        hi = (a.ctypes.data + a.nbytes) & ~((1 << 21) - 1)
+        if hi > lo:
+            _libc.madvise(lo, hi - lo, 14)          # MADV_HUGEPAGE
+    except Exception:
+        pass
+
+
 def _is_torch(x):
     return type(x).__module__.startswith("torch")
 
@@ -185,7 +207,9 @@ class M6ANetEngine:
         if like_dev:
             import torch
             return torch.empty(n, dtype=getattr(torch, torch_name), device="cuda:%d" % self.device)
-        return np.empty(n, np_dtype)
+        a = np.empty(n, np_dtype)
+        _hint_huge_pages(a)
+        return a
 
     # -- the path ---------------------------------------------------------------------------
     def get_read_probability(self, X, site_kmers, off, out=None):

@@ -678,6 +678,7 @@ def test_host_pointer_pipeline_matches_device_path(engines, orc, weights):
     inside flush groups, a job large enough for several ring wrap-arounds, and read probabilities optional."""
     import torch
     eng = engines["hek293t_glori"]
+    eng.prepare_host_io()                                          # jobs under ~200 MB only use the ring once it exists
     d = synthetic.make_sites(60_000, (20, 90), seed=11)            # 3.3 M reads = 119 MB of X: 5 chunks of 24 MB
     dev = torch.device("cuda:0")
     tX, tk, to = (torch.from_numpy(d[k]).to(dev) for k in ("X", "site_kmers", "off"))

@@ -37,10 +37,26 @@ def main():
         t = time.perf_counter()
         batch.native.write_csv(out, rp, sp, mr, write_header=True)
         t_csv = time.perf_counter() - t
+        # the same dataset packed once into a binary site store: opening it is a mmap
+        store = os.path.join(d, "data.m6astore")
+        t = time.perf_counter()
+        data_utils.pack_sites([d], store, 20, "norm_hct116.npz")
+        t_pack = time.perf_counter() - t
+        t = time.perf_counter()
+        sb = data_utils.open_store(store, "norm_hct116.npz", 20)
+        t_open = time.perf_counter() - t
+        t = time.perf_counter()
+        eng.infer(sb.X, sb.site_kmers, sb.off, 1000)
+        t_gpu_store = time.perf_counter() - t
+        t0 = time.perf_counter()
+        cli(["inference", "--input_dir", store, "--out_dir", out, "--num_iterations", "1000", "--n_processes", "0"])
+        wall_store = time.perf_counter() - t0
         sites, reads = batch.n_sites, int(batch.off[-1])
         print(json.dumps({"copies": n, "json_MB": size / 1e6, "sites": sites, "reads": reads,
                           "cli_wall_s": wall, "sites_per_s_end_to_end": sites / wall,
                           "load_s": t_load, "gpu_infer_host_pointers_s": t_gpu, "gpu_infer_host_pointers_warm_s": t_gpu_warm, "csv_s": t_csv,
+                          "store_pack_s": t_pack, "store_bytes": os.path.getsize(store), "store_open_s": t_open,
+                          "gpu_infer_from_mapped_store_s": t_gpu_store, "cli_wall_from_store_s": wall_store,
                           "pool_kernel": eng.last_pool_variant,
                           "site_csv_bytes": os.path.getsize(os.path.join(out, "data.site_proba.csv")),
                           "indiv_csv_bytes": os.path.getsize(os.path.join(out, "data.indiv_proba.csv")),

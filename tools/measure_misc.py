@@ -3,6 +3,8 @@
 through the scan kernel, configs[1] (100k sites, T=100), and the PCIe-inclusive host-pointer rate."""
 import json
 import os
+
+import numpy as np
 import sys
 import time
 
@@ -45,6 +47,7 @@ def main():
                     "enc_TFLOPs": 14164 * R / (e_ms * 1e-3) / 1e12, "pool_Gdraws_per_s": S * T * 20 / (p_ms * 1e-3) / 1e9}
         if tag.startswith("config1"):
             eng.set_stream(None)
+            eng.infer(d["X"], d["site_kmers"], d["off"], T)
             t0 = time.perf_counter()
             for _ in range(3):
                 eng.infer(d["X"], d["site_kmers"], d["off"], T)
@@ -58,7 +61,14 @@ def main():
     for _ in range(3):
         eng.infer(d["X"], d["site_kmers"], d["off"], 1000)
     out["bench_workload_host_pointers"] = {"sites_per_s": 3e6 / (time.perf_counter() - t0),
-                                           "note": "pageable numpy buffers, hipMemcpyAsync staging, synchronous call"}
+                                           "note": "pageable numpy buffers in, fresh numpy arrays out per call; chunks through "
+                                                   "the pinned staging ring, H2D / encoder / D2H overlapped"}
+    outs = (np.empty(20_000_000, np.float32), np.empty(1_000_000, np.float32), np.empty(1_000_000, np.float64))
+    eng.infer(d["X"], d["site_kmers"], d["off"], 1000, out=outs)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        eng.infer(d["X"], d["site_kmers"], d["off"], 1000, out=outs)
+    out["bench_workload_host_pointers"]["sites_per_s_reused_output_arrays"] = 3e6 / (time.perf_counter() - t0)
     # validation-style forward: 5 passes over 200 k ragged sites, device tensors
     eng = M6ANetEngine(weights=load_weights("HEK293T_RNA004"))
     d = synthetic.make_sites(200_000, (50, 500), seed=1)
