@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libm6a_hip.so")
+LIB_PATH = os.environ.get("M6A_HIP_LIB") or os.path.join(_PKG, "libm6a_hip.so")   # M6A_HIP_LIB: an experimental build
 
 M6A_OK = 0
 ERRORS = {-1: "M6A_EINVAL", -2: "M6A_ENOMEM", -3: "M6A_EHIP", -4: "M6A_ESTREAM", -5: "M6A_ENODEV",

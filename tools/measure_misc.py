@@ -53,22 +53,30 @@ def main():
                 eng.infer(d["X"], d["site_kmers"], d["off"], T)
             out[tag]["host_pointer_sites_per_s"] = S * 3 / (time.perf_counter() - t0)
         eng.close()
-    # PCIe-inclusive rate of the bench workload (host numpy arrays in, host arrays out)
+    # PCIe-inclusive rate of the bench workload (host numpy arrays in, host arrays out); the box's host cores are
+    # shared, so: best and median of 7 calls
     eng = M6ANetEngine(weights=load_weights())
     d = synthetic.make_sites(1_000_000, 20, seed=2)
     eng.infer(d["X"], d["site_kmers"], d["off"], 1000)
-    t0 = time.perf_counter()
-    for _ in range(3):
-        eng.infer(d["X"], d["site_kmers"], d["off"], 1000)
-    out["bench_workload_host_pointers"] = {"sites_per_s": 3e6 / (time.perf_counter() - t0),
-                                           "note": "pageable numpy buffers in, fresh numpy arrays out per call; chunks through "
-                                                   "the pinned staging ring, H2D / encoder / D2H overlapped"}
+
+    def rates(**kw):
+        ts = []
+        for _ in range(7):
+            t0 = time.perf_counter()
+            eng.infer(d["X"], d["site_kmers"], d["off"], 1000, **kw)
+            ts.append(time.perf_counter() - t0)
+        ts.sort()
+        return 1e6 / ts[0], 1e6 / ts[3]
+
+    best, med = rates()
     outs = (np.empty(20_000_000, np.float32), np.empty(1_000_000, np.float32), np.empty(1_000_000, np.float64))
     eng.infer(d["X"], d["site_kmers"], d["off"], 1000, out=outs)
-    t0 = time.perf_counter()
-    for _ in range(3):
-        eng.infer(d["X"], d["site_kmers"], d["off"], 1000, out=outs)
-    out["bench_workload_host_pointers"]["sites_per_s_reused_output_arrays"] = 3e6 / (time.perf_counter() - t0)
+    best_r, med_r = rates(out=outs)
+    out["bench_workload_host_pointers"] = {
+        "sites_per_s": best, "sites_per_s_median": med,
+        "sites_per_s_reused_output_arrays": best_r, "sites_per_s_reused_output_arrays_median": med_r,
+        "note": "pageable numpy buffers in; fresh numpy arrays out per call (first touch of 92 MB inside the call) or reused "
+                "output arrays; chunks through the pinned staging ring, H2D / encoder / D2H overlapped; best and median of 7"}
     # validation-style forward: 5 passes over 200 k ragged sites, device tensors
     eng = M6ANetEngine(weights=load_weights("HEK293T_RNA004"))
     d = synthetic.make_sites(200_000, (50, 500), seed=1)
