@@ -65,6 +65,45 @@ def measured_traffic(S, bag):
     return best
 
 
+def live_traffic(workload, kernel_name, timeout_s=240):
+    """HBM bytes per encoder launch measured NOW: two short re-runs of this script under
+    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, --kernel-trace only, as
+    MI355X_MICROARCH.md prescribes), read back from the rocpd database.  FETCH_SIZE x2: gfx950 tallies the 128-byte
+    requests of wide streaming reads at 64 bytes.  Returns None when rocprofv3 is unavailable or a pass fails."""
+    import glob
+    import shutil
+    import sqlite3
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None
+    vals = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="m6a_pmc_")
+        try:
+            cmd = ["rocprofv3", "--pmc", ctr, "--kernel-trace", "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
+                   "--workload", workload, "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-live-traffic"]
+            subprocess.run(cmd, capture_output=True, timeout=timeout_s, env=dict(os.environ, TMPDIR=os.environ.get("TMPDIR", "/tmp")))
+            dbs = glob.glob(os.path.join(d, "**", "*_results.db"), recursive=True)
+            if not dbs:
+                return None
+            con = sqlite3.connect(dbs[0])
+            cols = [r[1] for r in con.execute("pragma table_info(counters_collection)")]
+            kn = "kernel_name" if "kernel_name" in cols else "name"
+            row = con.execute("select avg(value), count(*) from counters_collection where counter_name = ? and %s like ?" % kn,
+                              (ctr, kernel_name + "%")).fetchone()
+            con.close()
+            if not row or not row[1]:
+                return None
+            vals[ctr] = float(row[0])
+        except (subprocess.SubprocessError, OSError, sqlite3.Error):
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return {"traffic_bytes_per_launch": (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0,
+            "source": "measured by this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over 4 launches of %s "
+                      "(FETCH_SIZE %.0f KiB x2 gfx950 correction + WRITE_SIZE %.0f KiB)" % (kernel_name, vals["FETCH_SIZE"], vals["WRITE_SIZE"])}
+
+
 # ---------------------------------------------------------------------------------------------
 # CPU baseline (runs in its own process: it forks worker pools, which must not happen after HIP is up)
 # ---------------------------------------------------------------------------------------------
@@ -190,6 +229,8 @@ def main():
     ap.add_argument("--reads", type=int, default=None, help="uniform workload: reads per site (default 20)")
     ap.add_argument("--iters", type=int, default=1000, help="num_iterations")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not re-run under rocprofv3 for roofline.traffic; quote the committed profiles/*_enc_traffic.json instead")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--enc-variant", type=int, default=0, help="0 auto, 1 general 16-slot, 2 12-slot encoder kernel")
     ap.add_argument("--scan-driver", type=int, default=0, help="ragged bags: 0 auto, 1 per group, 2 per site, 3 index tables")
@@ -329,9 +370,17 @@ def main():
         enc_tflops = ENC_FLOP_PER_READ * R / (enc_avg_ms * 1e-3) / 1e12
         enc_gbps = ENC_BYTES_PER_READ * R / (enc_avg_ms * 1e-3) / 1e9
         draws = Sr * T * 20
-        tr = measured_traffic(S, bag) if world == 1 else None
         bag_txt = "%d reads" % bag if not isinstance(bag, tuple) else "%d..%d reads" % bag
         enc_kernel = {"csite12": "enc_csite_kernel", "general16": "enc_kernel"}.get(eng.last_encoder_variant, "enc_kernel")
+        tr = None
+        if world == 1:
+            default_shape = S == spec["sites"] and T == 1000 and (args.workload == "ragged" or bag == spec["bag"])
+            if default_shape and not args.no_live_traffic:
+                tr = live_traffic(args.workload, enc_kernel)
+            if tr is None:
+                tr = measured_traffic(S, bag)
+                if tr is not None:
+                    tr = dict(tr, source="%s (%s) -- committed, not measured by this run" % (tr["file"], tr["source"]))
         pool_kernel = {"table-reg": "pool_reg_kernel", "table": "pool_table_kernel", "ragged-table": "pool_rtab_kernel"}.get(
             eng.last_pool_variant, "pool_scan_kernels")
         out = {
@@ -356,7 +405,7 @@ def main():
             "roofline": {"kernel": "read encoder (%s)" % eng.last_encoder_variant, "bound": "mfma", "achieved": enc_tflops,
                          "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": enc_tflops / PEAK_F32_TFLOPS,
                          "traffic": tr["traffic_bytes_per_launch"] if tr else None,
-                         "traffic_source": "%s (%s)" % (tr["file"], tr["source"]) if tr else None,
+                         "traffic_source": tr["source"] if tr else None,
                          "algorithmic_bytes_per_launch": ENC_BYTES_PER_READ * R,
                          "avg_launch_ms": enc_avg_ms, "launches": enc_n,
                          "algorithmic_flop_per_read": ENC_FLOP_PER_READ, "reads_per_launch": R,

@@ -119,6 +119,31 @@ private:
     bool stop_ = false;
 };
 
+// First touch of a caller's fresh output array, off the critical path: a call that returns 80 MB of read
+// probabilities into a just-allocated buffer otherwise pays ~20 000 page faults (zeroing included) inside the
+// copies that deliver the results.  A few threads walk the pages front to back while the first chunks are still
+// crossing PCIe; the touch is an atomic add of zero, so a page that already holds results is left as it is.
+class Prefault {
+public:
+    Prefault() = default;
+    void start(void *p, size_t bytes, int n_threads)
+    {
+        if (!p || bytes < ((size_t)4 << 20)) return;
+        char *b = (char *)p;
+        for (int t = 0; t < n_threads; t++)
+            th_.emplace_back([b, bytes, t, n_threads] {
+                const size_t page = 4096;
+                size_t first = (page - ((uintptr_t)b & (page - 1))) & (page - 1);
+                for (size_t o = first + (size_t)t * page; o < bytes; o += (size_t)n_threads * page)
+                    __atomic_fetch_add(b + o, (char)0, __ATOMIC_RELAXED);
+            });
+    }
+    void join() { for (auto &t : th_) t.join(); th_.clear(); }
+    ~Prefault() { join(); }
+private:
+    std::vector<std::thread> th_;
+};
+
 // pinned staging ring of the host-pointer path (m6a_infer / m6a_encode_reads with host buffers)
 constexpr int kStageSlots = 3;
 struct Staging {
@@ -1274,6 +1299,8 @@ int m6a_encode_reads(m6a_ctx *c, const float *X, const uint8_t *km, const int64_
         const int64_t R = off[S];
         if (R == 0) return M6A_OK;
         host_bag_range(c, off, S);
+        Prefault pf_rp;
+        pf_rp.start(rp, (size_t)R * 4, 4);
         int rc = staged_encode(c, X, km, off, S, R, rp);
         if (rc) return rc;
         return sync_and_check(c);
@@ -1346,6 +1373,9 @@ int m6a_infer(m6a_ctx *c, const float *X, const uint8_t *km, const int64_t *off,
     HIPCHK(c, c->sSite.ensure((size_t)S * 4));
     HIPCHK(c, c->sMod.ensure((size_t)S * 8));
     host_bag_range(c, off, S);
+    Prefault pf_rp, pf_out;                      // joined on every return path
+    if (rp) pf_rp.start(rp, (size_t)R * 4, 4);
+    pf_out.start(mod, (size_t)S * 8, 1);
     // chunks of X cross PCIe while earlier chunks are being encoded; read probabilities stream back the same way
     rc = staged_encode(c, X, km, off, S, R, rp);
     if (rc) return rc;
