@@ -381,7 +381,7 @@ def main():
                 tr = measured_traffic(S, bag)
                 if tr is not None:
                     tr = dict(tr, source="%s (%s) -- committed, not measured by this run" % (tr["file"], tr["source"]))
-        pool_kernel = {"table-reg": "pool_reg_kernel", "table": "pool_table_kernel", "ragged-table": "pool_rtab_kernel"}.get(
+        pool_kernel = {"table-reg": "pool_reg_kernel", "table": "pool_table_kernel", "ragged-table": "rtab_prep_kernel+pool_rtab_kernel"}.get(
             eng.last_pool_variant, "pool_scan_kernels")
         out = {
             "metric": "DRACH sites/sec at num_iterations=%d" % T,

@@ -821,9 +821,10 @@ int launch_pool(m6a_ctx *c, const float *rp, const int64_t *off, int64_t S, int 
             u.bag_cap = (int)std::max<int64_t>(64, (nmax + 63) / 64 * 64);
             c->pool_variant = "ragged-table";
             prof_begin(c, 1);
-            hipLaunchKernelGGL(rtab_chain_kernel, dim3((unsigned)std::min<int64_t>((a.n_groups + 3) / 4, (int64_t)c->n_cu * 16)), dim3(256), 0, c->stream, a, u);
-            hipLaunchKernelGGL(rtab_order_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, c->stream, off, S,
-                               (uint32_t *)c->ctl_dev.p, (uint32_t *)c->rt_order.p);
+            const unsigned n_order_blocks = (unsigned)((S + 255) / 256);
+            const unsigned n_chain_blocks = (unsigned)std::min<int64_t>((a.n_groups + 3) / 4, (int64_t)c->n_cu * 16);
+            hipLaunchKernelGGL(rtab_prep_kernel, dim3(n_order_blocks + n_chain_blocks), dim3(256), 0, c->stream, a, u,
+                               (uint32_t *)c->ctl_dev.p, (uint32_t *)c->rt_order.p, n_order_blocks);
             const size_t lds = (size_t)4 * (u.bag_cap + 16 + M6A_MEAN_STACK) * sizeof(float);
             const unsigned blocks = (unsigned)(((S + 3) / 4 + 7) / 8 * 8);
             if (K == 20) hipLaunchKernelGGL(pool_rtab_kernel<20>, dim3(blocks), dim3(256), lds, c->stream, a, u);
@@ -1425,6 +1426,37 @@ int m6a_bag_forward(m6a_ctx *c, const float *X, const uint8_t *km, int64_t B, in
 
 namespace {
 
+// MT19937 with the 624-word state refilled in bulk: the three recurrence loops have dependence distances of
+// 227 and more, so the compiler vectorises them; std::mt19937's per-call path was a third of the sampler's time.
+struct MtBulk {
+    uint32_t s[624], out[624];
+    int pos = 624;
+    explicit MtBulk(uint32_t seed)
+    {
+        uint32_t x = seed;
+        s[0] = x;
+        for (uint32_t i = 1; i < 624; i++) { x = 1812433253u * (x ^ (x >> 30)) + i; s[i] = x; }
+    }
+    static inline uint32_t tw(uint32_t a, uint32_t b)
+    {
+        const uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
+        return (y >> 1) ^ ((0u - (y & 1u)) & 0x9908b0dfu);
+    }
+    void refill()
+    {
+        for (int k = 0; k < 227; k++) s[k] = s[k + 397] ^ tw(s[k], s[k + 1]);
+        for (int k = 227; k < 623; k++) s[k] = s[k - 227] ^ tw(s[k], s[k + 1]);
+        s[623] = s[396] ^ tw(s[623], s[0]);
+        for (int k = 0; k < 624; k++) {
+            uint32_t y = s[k];
+            y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
+            out[k] = y;
+        }
+        pos = 0;
+    }
+    inline uint32_t next() { if (pos == 624) refill(); return out[pos++]; }
+};
+
 // the training-mode sampler of a whole validation run (data_utils.py:213-214 under
 // training_utils.py:235-240, num_workers=0): RandomState.choice(n, K, replace=False) =
 // permutation(n)[:K] = legacy shuffle of arange(n): for i = n-1..1: j = rk_interval(i) (masked rejection over
@@ -1442,17 +1474,17 @@ int validation_indices(m6a_ctx *c, const int64_t *h_off, int64_t S, int T, int K
     if (h_off[S] > 0x7fffffff) return fail(c, M6A_EUNSUPPORTED, "more than 2^31 reads");
     gidx.resize((size_t)T * S * K);
     std::vector<int32_t> perm((size_t)nmax);
-    std::mt19937 gen(seed);
+    MtBulk gen(seed);
     int32_t *out = gidx.data();
     for (int t = 0; t < T; t++)
         for (int64_t s = 0; s < S; s++) {
             const int64_t n = h_off[s + 1] - h_off[s];
             for (int64_t i = 0; i < n; i++) perm[i] = (int32_t)i;
-            for (int64_t i = n - 1; i >= 1; i--) {
-                uint32_t mask = (uint32_t)i, v;
-                mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
-                do { v = (uint32_t)gen() & mask; } while (v > (uint32_t)i);
-                std::swap(perm[i], perm[v]);
+            for (uint32_t i = (uint32_t)n - 1; i >= 1; i--) {
+                const uint32_t mask = 0xffffffffu >> __builtin_clz(i);       // smallest 2^b - 1 >= i
+                uint32_t v;
+                do { v = gen.next() & mask; } while (v > i);
+                const int32_t x = perm[i]; perm[i] = perm[v]; perm[v] = x;
             }
             for (int k = 0; k < K; k++) *out++ = (int32_t)h_off[s] + perm[k];
         }

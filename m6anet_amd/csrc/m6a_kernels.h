@@ -99,8 +99,7 @@ __global__ void rtab_count_kernel(RtabBuild a);
 __global__ void rtab_scan_kernel(RtabBuild a);
 __global__ void rtab_fill_kernel(RtabBuild a);
 __global__ void rtab_to_reg_table_kernel(const uint16_t *C, int64_t A, int64_t row_bytes, int jmax, uint8_t *tab);
-__global__ void rtab_chain_kernel(PoolArgs a, RtabUse u);
-__global__ void rtab_order_kernel(const int64_t *off, int64_t n_sites, uint32_t *cursor, uint32_t *order);
+__global__ void rtab_prep_kernel(PoolArgs a, RtabUse u, uint32_t *cursor, uint32_t *order, unsigned n_order_blocks);
 template <int KT> __global__ void pool_rtab_kernel(PoolArgs a, RtabUse u);
 
 #endif

@@ -1076,14 +1076,30 @@ __global__ void bag_noisy_or_kernel(const float *read_prob, int64_t n_bags, int 
 }
 
 // validation-style forward: y[b] = 1 - prod_k (1 - p[gidx[b][k]]), float32 left to right
-// (training_utils.py:239 -> MILModel.forward -> pooling_blocks.py:127-129 on the sampled 20-read bag)
+// (training_utils.py:239 -> MILModel.forward -> pooling_blocks.py:127-129 on the sampled 20-read bag).
+// A thread owns a bag; for k = 20 its index row is 80 contiguous, 16-byte aligned bytes: five dwordx4 loads, all 20
+// gathers in flight before the first multiply.
 __global__ void sampled_noisy_or_kernel(const float *read_prob, const int32_t *gidx, int64_t n_bags, int k, float *y)
 {
     const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= n_bags) return;
     const int32_t *row = gidx + b * k;
     float prod = 1.0f;
-    for (int j = 0; j < k; j++) prod *= 1.0f - read_prob[row[j]];
+    if (k == 20) {
+        int4 q[5];
+#pragma unroll
+        for (int j = 0; j < 5; j++) q[j] = ((const int4 *)row)[j];
+        float g[20];
+#pragma unroll
+        for (int j = 0; j < 5; j++) {
+            g[4 * j] = read_prob[q[j].x]; g[4 * j + 1] = read_prob[q[j].y];
+            g[4 * j + 2] = read_prob[q[j].z]; g[4 * j + 3] = read_prob[q[j].w];
+        }
+#pragma unroll
+        for (int j = 0; j < 20; j++) prod *= 1.0f - g[j];
+    } else {
+        for (int j = 0; j < k; j++) prod *= 1.0f - read_prob[row[j]];
+    }
     y[b] = 1.0f - prod;
 }
 

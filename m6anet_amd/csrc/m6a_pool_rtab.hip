@@ -16,9 +16,9 @@
 // one, where the group's next site starts.  That splits the job into
 //   rtab_count/scan/fill   C_n (as u16 byte offsets 4*v) + RS_n (rank at every 64-word block) for
 //                          each new bag size -- built once per (seed, T*K), kept across calls;
-//   rtab_chain_kernel      one wavefront per flush group walks its <= 32 sites: rank lookup, jump
+//   rtab_prep_kernel       one wavefront per flush group walks its <= 32 sites: rank lookup, jump
 //                          T*K ranks ahead, select -- three dependent L2 round trips per site,
-//                          no stream scanning at all;
+//                          no stream scanning at all; the same launch orders the sites by bag size;
 //   pool_rtab_kernel       one wavefront per site, sites ordered by bag size (a table of 2-3 MB
 //                          stays in one XCD's L2 while its sites run): lane = iteration, a lane
 //                          loads its 20 indices as one 40-byte row, gathers 1-p from the LDS bag
@@ -215,13 +215,13 @@ __global__ __launch_bounds__(256) void rtab_to_reg_table_kernel(const uint16_t *
 //   rank r of the site's first draw in C_n  ->  rank_out[s]
 //   p' = (stream word of accepted draw number r + T*K - 1) + 1   -> next site
 // =====================================================================================
-__global__ __launch_bounds__(256) void rtab_chain_kernel(PoolArgs a, RtabUse u)
+__device__ __forceinline__ void rtab_chain_part(const PoolArgs &a, const RtabUse &u, unsigned block, unsigned n_blocks)
 {
     const int lane = threadIdx.x & 63;
-    const int64_t n_waves = (int64_t)gridDim.x * 4;
+    const int64_t n_waves = (int64_t)n_blocks * 4;
     const uint32_t A = (uint32_t)(a.T * a.K);
     const uint32_t n_blk = u.n_blk;
-    for (int64_t g = (int64_t)blockIdx.x * 4 + uni((int)(threadIdx.x >> 6)); g < a.n_groups; g += n_waves) {
+    for (int64_t g = (int64_t)block * 4 + uni((int)(threadIdx.x >> 6)); g < a.n_groups; g += n_waves) {
         uint32_t p = 0;
         const int64_t s_beg = a.goff[g], s_end = a.goff[g + 1];
         uint32_t w = a.raw[lane];                     // the stream block that holds word p
@@ -280,12 +280,12 @@ __global__ __launch_bounds__(256) void rtab_chain_kernel(PoolArgs a, RtabUse u)
 // sites ordered by bag size: cursor[n] starts at the exclusive prefix of the bag-size histogram.  A workgroup
 // counts its 256 sites in LDS first and takes ONE global slot range per bag size it holds (uniform bags would
 // otherwise serialise every site on a single atomic).
-__global__ __launch_bounds__(256) void rtab_order_kernel(const int64_t *off, int64_t n_sites, uint32_t *cursor, uint32_t *order)
+__device__ __forceinline__ void rtab_order_part(const int64_t *off, int64_t n_sites, uint32_t *cursor, uint32_t *order, unsigned block)
 {
     __shared__ uint32_t s_cnt[M6A_HIST_BINS], s_base[M6A_HIST_BINS];
     for (int i = threadIdx.x; i < M6A_HIST_BINS; i += 256) s_cnt[i] = 0;
     __syncthreads();
-    const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t s = (int64_t)block * 256 + threadIdx.x;
     int64_t n = 0;
     uint32_t mine = 0;
     if (s < n_sites) {
@@ -297,6 +297,18 @@ __global__ __launch_bounds__(256) void rtab_order_kernel(const int64_t *off, int
     if (s < n_sites && mine == 0) s_base[n] = atomicAdd(&cursor[n], s_cnt[n]);
     __syncthreads();
     if (s < n_sites) order[s_base[n] + mine] = (uint32_t)s;
+}
+
+// One launch for both preparations of a call -- they are independent, the chain walk is a latency chain on few
+// waves and the ordering a burst of atomics, so they overlap: workgroups [0, n_order_blocks) order the sites, the
+// rest walk the flush groups.  Also zeroes the consumer's per-XCD work counters.
+__global__ __launch_bounds__(256) void rtab_prep_kernel(PoolArgs a, RtabUse u, uint32_t *cursor, uint32_t *order, unsigned n_order_blocks)
+{
+    if (blockIdx.x < n_order_blocks) {
+        rtab_order_part(a.off, a.n_sites, cursor, order, blockIdx.x);
+    } else {
+        rtab_chain_part(a, u, blockIdx.x - n_order_blocks, gridDim.x - n_order_blocks);
+    }
 }
 
 // =====================================================================================
@@ -337,7 +349,9 @@ __global__ __launch_bounds__(256) void pool_rtab_kernel(PoolArgs a, RtabUse u)
     float *bag = smem + wib * (u.bag_cap + 16 + M6A_MEAN_STACK);
     float *stage = bag + u.bag_cap, *tail = stage + 8, *stack = tail + 8;
     // blockIdx -> position in the bag-size order, XCD-aware: workgroups go round-robin over the 8 XCDs, so XCD x
-    // walks the contiguous eighth x of the order and the tables of "its" bag sizes stay in its L2
+    // walks the contiguous eighth x of the order and the tables of "its" bag sizes stay in its L2.  One site per
+    // wavefront and launch slot: persistent waves were tried and are slower (a fixed stride per wave 0.73 ms, a per-XCD
+    // atomic work counter 1.58 ms, against 0.60 ms) -- the hardware dispatcher balances the 31 250 workgroups better.
     const uint32_t chunk = gridDim.x >> 3;                 // gridDim.x is a multiple of 8
     const int64_t si = ((int64_t)(blockIdx.x & 7) * chunk + (blockIdx.x >> 3)) * 4 + wib;
     if (si >= a.n_sites) return;

@@ -784,6 +784,64 @@ def test_full_size_ragged_properties(engines, orc, weights):
     assert site[-1] > 0
 
 
+@pytest.mark.parametrize("config,n_sites,bag,model", [("configs[3]", 8_000_000, 20, "hct116"),
+                                                       ("configs[4]", 1_000_000, (50, 500), "hek293t_glori")])
+def test_whole_8gpu_job_as_eight_shards_on_one_gpu(engines, orc, weights, config, n_sites, bag, model):
+    """BASELINE.json configs[3] (8 M sites x 20 reads) and configs[4] (1 M sites x 50..500 reads, HEK293T weights) at
+    FULL size, T = 1000, on the one GPU a test box has (5.8 / 9.9 GB of features, generated on the device): the job run
+    whole, and run as the eight flush-group-aligned shards m6a_shard_plan gives the eight ranks, each with its job
+    offset -- everything a rank computes on an 8-GPU node, minus the RCCL transport.  Shards = whole bit for bit, and
+    sampled flush groups against the oracle."""
+    import torch
+    from m6anet_amd.engine import shard_plan
+    eng = engines[model]
+    dev = torch.device("cuda:0")
+    T = 1000
+    n_reads = synthetic.bag_sizes(n_sites, bag)
+    off_h = np.zeros(n_sites + 1, np.int64)
+    np.cumsum(n_reads, out=off_h[1:])
+    R = int(off_h[-1])
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234)
+    X = torch.empty((R, 9), dtype=torch.float32, device=dev)
+    for a in range(0, R, 1 << 24):                                    # in pieces: normal_ on 2.5 G elements at once is slow
+        X[a:a + (1 << 24)].normal_(generator=gen)
+    X.clamp_(-6.0, 6.0)
+    km_h = synthetic.make_sites(n_sites, 1, seed=3)["site_kmers"]     # only the k-mer ids of this call are used
+    km, off = torch.from_numpy(km_h).to(dev), torch.from_numpy(off_h).to(dev)
+    eng.use_torch_stream()
+    try:
+        rp, site, mod = eng.infer(X, km, off, T)
+        eng.sync()
+        cuts = shard_plan(off_h, 8)
+        assert cuts[0] == 0 and cuts[-1] == n_sites and np.all(np.diff(cuts) > 0)
+        reads = np.diff(off_h[cuts])
+        assert reads.max() / reads.mean() < 1.01                       # balanced by reads
+        for r in range(8):
+            a, b = int(cuts[r]), int(cuts[r + 1])
+            eng.set_job_offset(a)
+            o = off[a:b + 1] - off[a]
+            rp_s, site_s, mod_s = eng.infer(X[off_h[a]:off_h[b]], km[a:b], o.contiguous(), T)
+            eng.sync()
+            assert torch.equal(site_s, site[a:b]) and torch.equal(mod_s, mod[a:b]), (config, r)
+            assert torch.equal(rp_s, rp[off_h[a]:off_h[b]]), (config, r)
+    finally:
+        eng.set_job_offset(0)
+        eng.set_stream(None)
+    site_h, mod_h = site.cpu().numpy(), mod.cpu().numpy()
+    assert np.all(np.isfinite(site_h)) and site_h.min() >= 0 and site_h.max() <= 1
+    g = np.random.Generator(np.random.PCG64(4))
+    n_groups = (n_sites - 16) // 32
+    for grp in [0, n_groups] + list(g.integers(1, n_groups, size=6)):
+        a, b = (0, 16) if grp == 0 else (16 + 32 * (grp - 1), min(n_sites, 16 + 32 * grp))
+        lo, hi = int(off_h[a]), int(off_h[b])
+        Xs, rps = X[lo:hi].cpu().numpy(), rp[lo:hi].cpu().numpy()
+        p = orc.encode_reads(weights[model], Xs, km_h[a:b], off_h[a:b + 1] - lo)
+        assert np.allclose(rps, p, rtol=1e-5, atol=1e-8)
+        w_site, w_mod = orc.site_pool(rps, off_h[a:b + 1] - lo, T, THR, batch_size=b - a, save_per_batch=2)
+        assert same_sites(site_h[a:b], w_site) and np.array_equal(mod_h[a:b], w_mod)
+
+
 def test_beyond_4GiB_of_features(eng, orc, weights):
     """A job whose feature array crosses 2^32 bytes (3.4 M sites x 37 reads = 126 M reads, 4.5 GB of X): every
     byte offset on the path must be 64-bit (the 12-slot encoder and the register pooling kernel keep 32-bit tile /
