@@ -221,6 +221,9 @@ void m6a_or_encode_reads(const float *w, const float *X, const uint8_t *site_kme
 float m6a_or_site_proba(m6a_or_mt *st, const float *p, int64_t n, int n_iters, int n_samples,
                         int32_t *idx, float *vals)
 {
+    /* a site without reads: np.random.choice raises ("a must be non-empty") and the reference never has one
+     * (data_utils.py:129 keeps sites with >= 20 reads); the HIP path answers NaN and consumes no words */
+    if (n <= 0) return NAN;
     m6a_or_choice(st, n, (int64_t)n_iters * n_samples, idx);
     for (int t = 0; t < n_iters; t++) {
         float prod = 1.0f;

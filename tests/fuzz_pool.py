@@ -46,7 +46,9 @@ def main():
         K = 20 if g.random() < 0.8 else int(g.integers(1, 65))
         bs, spb = int(g.choice([1, 2, 5, 16, 32, 50])), int(g.choice([1, 2, 3]))
         seed = int(g.integers(0, 2 ** 32))
-        if T * K * bags.max() > 4e7 or T * K * S > 4e7:
+        if g.random() < 0.15:
+            bags = np.where(g.random(S) < 0.2, 0, bags)              # empty sites: NaN outputs, no words drawn
+        if bags.max() == 0 or T * K * bags.max() > 4e7 or T * K * S > 4e7:
             continue
         off = np.concatenate([[0], np.cumsum(bags)]).astype(np.int64)
         p = (g.random(int(off[-1]), dtype=np.float32) ** 4).astype(np.float32)

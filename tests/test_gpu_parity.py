@@ -215,6 +215,7 @@ def test_pool_uniform_table_vs_oracle(eng, orc, n, T):
 @pytest.mark.parametrize("bags", [
     [33] * 40, [64] * 35, [65] * 33, [1000] * 3, [1024, 1025, 1500, 20], [20, 21] * 30,
     [1, 2, 1, 20, 1, 40], list(range(20, 84)), [2048, 20, 4097],
+    [0, 25, 0, 0, 1, 40, 0], [0] * 5 + [1024] + [0] * 3 + [2, 3] * 20,
 ])
 def test_pool_scan_vs_oracle(eng, orc, bags):
     off = np.concatenate([[0], np.cumsum(bags)]).astype(np.int64)
@@ -232,7 +233,7 @@ def test_pool_scan_vs_oracle(eng, orc, bags):
                 assert eng.last_pool_variant == (name or eng.last_pool_variant)
                 assert eng.last_pool_variant.startswith("scan") or eng.last_pool_variant == "ragged-table"
                 assert same_sites(site, want_site), (T, driver)
-                assert np.array_equal(mod, want_mod)
+                assert np.array_equal(mod, want_mod, equal_nan=True)
     finally:
         eng.set_scan_driver(0)
 
@@ -647,6 +648,31 @@ def test_bench_self_launch_two_ranks_equal_the_whole_job(workload, sites):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["verify"] is True
     assert d["value"] > 0 and d["config"]["sites_per_gpu"] == sites
+
+
+def test_host_ring_with_empty_and_tiny_bags(engines, orc, weights):
+    """The chunked host-pointer path on a job with empty sites (no reads at all), one-read bags and runs of empty
+    sites at chunk boundaries: same results as the device path, NaN site probability / mod_ratio for empty sites
+    (the reference would divide by zero there too)."""
+    import torch
+    eng = engines["hct116"]
+    eng.prepare_host_io()
+    g = np.random.Generator(np.random.PCG64(21))
+    bags = g.integers(0, 60, size=90_000)
+    bags[g.random(bags.size) < 0.2] = 0
+    bags[40_000:40_500] = 0
+    X, km, off = rand_sites(5, bags)                                  # 2.1 M reads = 76 MB: four chunks
+    dev = torch.device("cuda:0")
+    rp_d, site_d, mod_d = eng.infer(torch.from_numpy(X).to(dev), torch.from_numpy(km).to(dev), torch.from_numpy(off).to(dev), 40)
+    eng.sync()
+    rp, site, mod = eng.infer(X, km, off, 40)
+    assert np.array_equal(rp, rp_d.cpu().numpy())
+    assert np.array_equal(site, site_d.cpu().numpy(), equal_nan=True) and np.array_equal(mod, mod_d.cpu().numpy(), equal_nan=True)
+    assert np.isnan(site[bags == 0]).all() and np.isnan(mod[bags == 0]).all() and np.isfinite(site[bags > 0]).all()
+    p = orc.encode_reads(weights["hct116"], X, km, off, n_threads=8)
+    assert np.allclose(rp, p, rtol=1e-5, atol=1e-8)
+    want_site, want_mod = orc.site_pool(rp, off, 40, THR, n_threads=8)
+    assert same_sites(site, want_site) and np.array_equal(mod, want_mod, equal_nan=True)
 
 
 def test_native_rccl_gather_single_rank(eng):
