@@ -77,6 +77,28 @@ def main():
         "sites_per_s_reused_output_arrays": best_r, "sites_per_s_reused_output_arrays_median": med_r,
         "note": "pageable numpy buffers in; fresh numpy arrays out per call (first touch of 92 MB inside the call) or reused "
                 "output arrays; chunks through the pinned staging ring, H2D / encoder / D2H overlapped; best and median of 7"}
+    # the INTEGRATION.md stub's shape: the reference's own loop, one m6a_encode_reads per 16-site batch and one
+    # m6a_site_pool per flush group of <= 32 sites, host arrays in and out (what a maintainer gets by swapping the
+    # three call sites and nothing else)
+    eng = M6ANetEngine(weights=load_weights())
+    d = synthetic.make_sites(20_000, (20, 90), seed=6)
+    off = d["off"]
+    t0 = time.perf_counter()
+    for s0 in range(0, 20_000, 16):
+        s1 = min(20_000, s0 + 16)
+        eng.get_read_probability(d["X"][off[s0]:off[s1]], d["site_kmers"][s0:s1], off[s0:s1 + 1] - off[s0])
+    t_enc = time.perf_counter() - t0
+    rp = eng.get_read_probability(d["X"], d["site_kmers"], off)
+    t0 = time.perf_counter()
+    n_calls = 0
+    for g0 in range(0, 20_000, 32):
+        g1 = min(20_000, g0 + 32)
+        eng.calculate_site_proba(rp[off[g0]:off[g1]], off[g0:g1 + 1] - off[g0], 1000, batch_size=g1 - g0)
+        n_calls += 1
+    t_pool = time.perf_counter() - t0
+    out["reference_loop_through_the_stub"] = {"sites": 20_000, "encode_calls_of_16_sites_s": t_enc, "pool_calls_of_32_sites_s": t_pool,
+                                              "sites_per_s": 20_000 / (t_enc + t_pool), "us_per_pool_call": t_pool / n_calls * 1e6,
+                                              "note": "per-batch / per-flush-group calls with host arrays, as INTEGRATION.md section 2 wires them"}
     # validation-style forward: 5 passes over 200 k ragged sites, device tensors
     eng = M6ANetEngine(weights=load_weights("HEK293T_RNA004"))
     d = synthetic.make_sites(200_000, (50, 500), seed=1)
