@@ -175,13 +175,14 @@ CASES = [(5, 16, 2, 0), (100, 16, 2, 0), (1000, 16, 2, 0), (50, 8, 3, 0), (20, 1
 
 @pytest.mark.parametrize("T,bs,spb,seed", CASES)
 def test_pool_bundled_golden(eng, golden, T, bs, spb, seed):
-    """Ragged real bags (20..662 reads): the scan kernel against full reference runs."""
+    """Ragged real bags (20..662 reads) against full reference runs -- the scan kernels (101 sites do not pay for 60
+    index tables), or the index-table kernel once earlier calls with the same (seed, T) have."""
     b = golden("bundled_inputs.npz")
     p = golden("bundled_readprob.npz")["hct116"]
     g = golden("bundled_site.npz")
     key = f"T{T}_bs{bs}_spb{spb}_seed{seed}"
     site, mod = eng.calculate_site_proba(p, b["off"], T, 20, THR, seed, bs, spb)
-    assert eng.last_pool_variant.startswith("scan")
+    assert eng.last_pool_variant.startswith("scan") or eng.last_pool_variant == "ragged-table"
     assert same_sites(site, g[key + "_site"])
     assert np.array_equal(mod, g[key + "_mod"])
 
@@ -426,6 +427,27 @@ def test_pool_auto_picks_tables_for_large_ragged_jobs(eng, orc):
     site2, _ = eng.calculate_site_proba(p[:int(off[40])], off[:41], 64, 20, THR, seed=99)
     assert eng.last_pool_variant.startswith("scan")              # 40 sites, new seed: replay the stream instead
     assert same_sites(site2, orc.site_pool(p[:int(off[40])], off[:41], 64, THR, seed=99)[0])
+
+
+def test_pool_flush_group_at_a_time_earns_its_tables(eng, orc):
+    """The reference-side stub hands over ONE flush group per call.  No single call pays for the
+    index tables it lacks, so the first ones replay the stream (scan kernels); the sites pooled that way are credited,
+    and once they would have paid for the missing tables those are built and every later call is a table gather.
+    Every call, on either kernel, equals the oracle bit for bit."""
+    bags = np.random.Generator(np.random.PCG64(31)).integers(20, 50, size=32 * 40)
+    off = np.concatenate([[0], np.cumsum(bags)]).astype(np.int64)
+    p = rand_probs(9, off)
+    seen = []
+    for g0 in range(0, len(bags), 32):
+        sl = slice(int(off[g0]), int(off[g0 + 32]))
+        o = off[g0:g0 + 33] - off[g0]
+        site, mod = eng.calculate_site_proba(p[sl], o, 200, 20, THR, seed=4242, batch_size=32)
+        seen.append(eng.last_pool_variant)
+        want_site, want_mod = orc.site_pool(p[sl], o, 200, THR, seed=4242, batch_size=32)
+        assert same_sites(site, want_site) and np.array_equal(mod, want_mod), (g0, seen[-1])
+    assert seen[0].startswith("scan") and seen[-1] == "ragged-table"
+    first_table = seen.index("ragged-table")
+    assert 5 <= first_table <= 20 and all(v == "ragged-table" for v in seen[first_table + 8:])
 
 
 def test_pool_seeds_differ_and_repeat(eng):
