@@ -71,6 +71,11 @@ int m6a_io_write_csv_n(const m6a_sites *s, const char *out_dir, const float *rea
                        const float *site_prob, const double *mod_ratio, int write_header, int n_threads,
                        int64_t n_sites_limit);
 
+/* The writers' '%.16f' (inference_utils.py:62,66) without printf: same characters as snprintf("%.16f", v) for every
+ * double (exact 128-bit arithmetic for 0 <= v < 2, snprintf itself otherwise); buf336 holds >= 336 bytes, NUL-terminated;
+ * returns the length.  Exported so the tests can pin it against printf. */
+int m6a_io_format_f16(double v, char *buf336);
+
 /* `m6anet dataprep` (m6anet/scripts/dataprep.py:54-70 -> m6anet/utils/dataprep_utils.py):
  * eventalign.txt -> <out_dir>/eventalign.index (parallel_index, :187-266), data.json + data.info +
  * data.log (combine :269-325, filter_events :19-168, preprocess_tx :399-488).  Same arithmetic as

@@ -310,6 +310,53 @@ void format_py_float(double v, std::string &out)
     if (!strpbrk(buf, ".en")) out += ".0";
 }
 
+// ---- "%.16f" without printf ---------------------------------------------------------------------------
+// The CSV rows print probabilities with '%.16f' (inference_utils.py:62,66): glibc formats a double exactly
+// (multi-precision) and costs ~1 us per number; for 0 <= v < 2 the same digits come from one 128-bit product:
+// v = m * 2^e exactly (m < 2^53), so round_half_even(v * 10^16) = (m * 10^16) >> -e with the dropped bits deciding
+// the rounding -- m * 10^16 < 2^107 fits an unsigned __int128.  Anything else (v >= 2, negative, nan, inf) goes
+// through snprintf.  Returns the number of characters written (no terminator); buf holds >= 336 (the longest
+// "%.16f" of a double: sign, 309 digits, point, 16 digits, NUL).
+const char kDigitPairs[201] =
+    "00010203040506070809101112131415161718192021222324252627282930313233343536373839404142434445464748495051525354555657585960"
+    "616263646566676869707172737475767778798081828384858687888990919293949596979899";
+
+inline void put8(char *o, uint32_t v)       // exactly 8 digits, zero padded
+{
+    for (int i = 3; i >= 0; i--) { const uint32_t q = v / 100, r = v - q * 100; memcpy(o + 2 * i, kDigitPairs + 2 * r, 2); v = q; }
+}
+
+int format_f16(double v, char *buf)
+{
+    uint64_t bits;
+    memcpy(&bits, &v, 8);
+    const int be = (int)(bits >> 52) & 0x7ff;
+    if ((bits >> 63) || be >= 1024) return snprintf(buf, 336, "%.16f", v);      // negative (incl. -0.0), >= 2, nan, inf
+    uint64_t m = bits & ((1ull << 52) - 1);
+    int e;                                                  // v = m * 2^e
+    if (be == 0) e = -1074; else { m |= 1ull << 52; e = be - 1075; }
+    const unsigned __int128 prod = (unsigned __int128)m * 10000000000000000ull;
+    const int sh = -e;                                      // >= 52 here (v < 2)
+    uint64_t n;                                             // round_half_even(v * 1e16) <= 2e16
+    if (sh >= 108) n = 0;                                   // prod < 2^107: below one half (a tie needs prod = 2^(sh-1), and 5^16 | prod)
+    else {
+        n = (uint64_t)(prod >> sh);
+        const unsigned __int128 rem = prod & (((unsigned __int128)1 << sh) - 1), half = (unsigned __int128)1 << (sh - 1);
+        if (rem > half || (rem == half && (n & 1))) n++;
+    }
+    const uint64_t ip = n / 10000000000000000ull, fp = n - ip * 10000000000000000ull;
+    buf[0] = (char)('0' + ip);
+    buf[1] = '.';
+    put8(buf + 2, (uint32_t)(fp / 100000000ull));
+    put8(buf + 10, (uint32_t)(fp % 100000000ull));
+    return 18;
+}
+
+inline int format_i64(long long v, char *buf)
+{
+    return (int)(std::to_chars(buf, buf + 24, v).ptr - buf);
+}
+
 int n_workers(int n_threads, int64_t items)
 {
     int n = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
@@ -582,6 +629,8 @@ int m6a_io_open_store(const char *path, m6a_sites **out)
 const char *m6a_io_tx_id(const m6a_sites *s, int64_t i) { return s->tx_ids[(size_t)i].c_str(); }
 const char *m6a_io_kmer5(const m6a_sites *s, int64_t i) { return s->kmer5[(size_t)i].c_str(); }
 
+int m6a_io_format_f16(double v, char *buf336) { const int k = format_f16(v, buf336); buf336[k] = 0; return k; }
+
 int m6a_io_write_csv(const m6a_sites *s, const char *out_dir, const float *read_prob, const float *site_prob,
                      const double *mod_ratio, int write_header, int n_threads)
 {
@@ -622,29 +671,56 @@ int m6a_io_write_csv_n(const m6a_sites *s, const char *out_dir, const float *rea
         std::vector<std::string> site_txt((size_t)nc), indiv_txt((size_t)nc);
         auto work = [&](int w) {
             std::string &a = site_txt[(size_t)w], &b = indiv_txt[(size_t)w];
-            char buf[128];
-            for (int64_t i = cuts[(size_t)w]; i < cuts[(size_t)w + 1]; i++) {
+            const int64_t i0 = cuts[(size_t)w], i1 = cuts[(size_t)w + 1];
+            a.reserve((size_t)(i1 - i0) * 96);
+            b.reserve((size_t)(s->vOff[i1] - s->vOff[i0]) * 64);
+            char buf[512];
+            std::string head;
+            for (int64_t i = i0; i < i1; i++) {
                 const int64_t r0 = s->vOff[i], r1 = s->vOff[i + 1];
                 // '%s,%d,%s,%.16f,%s,%.16f'  (inference_utils.py:62)
                 a += s->tx_ids[(size_t)i];
-                snprintf(buf, sizeof buf, ",%lld,%lld,%.16f,", (long long)s->vPos[i], (long long)(r1 - r0), (double)site_prob[i]);
-                a += buf;
+                int k = 0;
+                buf[k++] = ',';
+                k += format_i64((long long)s->vPos[i], buf + k);
+                buf[k++] = ',';
+                k += format_i64((long long)(r1 - r0), buf + k);
+                buf[k++] = ',';
+                k += format_f16((double)site_prob[i], buf + k);
+                buf[k++] = ',';
+                a.append(buf, (size_t)k);
                 a += s->kmer5[(size_t)i];
-                snprintf(buf, sizeof buf, ",%.16f\n", mod_ratio[i]);
-                a += buf;
+                k = 0;
+                buf[k++] = ',';
+                k += format_f16(mod_ratio[i], buf + k);
+                buf[k++] = '\n';
+                a.append(buf, (size_t)k);
                 // '%s,%d,%s,%.16f'  (inference_utils.py:66); read ids: str(float64), or "<int>_<rep>"
-                snprintf(buf, sizeof buf, ",%lld,", (long long)s->vPos[i]);
-                const std::string head = s->tx_ids[(size_t)i] + buf;
+                head.assign(s->tx_ids[(size_t)i]);
+                k = 0;
+                buf[k++] = ',';
+                k += format_i64((long long)s->vPos[i], buf + k);
+                buf[k++] = ',';
+                head.append(buf, (size_t)k);
                 for (int64_t r = r0; r < r1; r++) {
                     b += head;
+                    k = 0;
+                    const double id = s->vIds[r];
                     if (s->n_rep > 1) {
-                        snprintf(buf, sizeof buf, "%lld_%d", (long long)s->vIds[r], (int)s->vRep[r]);
-                        b += buf;
+                        k += format_i64((long long)id, buf + k);
+                        buf[k++] = '_';
+                        k += format_i64((long long)s->vRep[r], buf + k);
+                    } else if (id == std::floor(id) && std::fabs(id) < 1e15 && !std::signbit(id)) {
+                        k += format_i64((long long)id, buf + k);                     // str(float64) of an integral value
+                        buf[k++] = '.';
+                        buf[k++] = '0';
                     } else {
-                        format_py_float(s->vIds[r], b);
+                        format_py_float(id, b);
                     }
-                    snprintf(buf, sizeof buf, ",%.16f\n", (double)read_prob[r]);
-                    b += buf;
+                    buf[k++] = ',';
+                    k += format_f16((double)read_prob[r], buf + k);
+                    buf[k++] = '\n';
+                    b.append(buf, (size_t)k);
                 }
             }
         };

@@ -189,3 +189,36 @@ def test_binary_site_store_round_trip(tmp_path):
     for bad in ("cut", "junk", "magic", "missing"):
         with pytest.raises(_io.M6AIOError):
             data_utils.open_store(str(tmp_path / (bad + ".m6astore")))
+
+
+def test_fast_16_digit_formatter_equals_printf():
+    """The CSV writers print '%.16f' (inference_utils.py:62,66) through m6a_io_format_f16; it must give
+    the characters printf gives, for every kind of value a probability column can hold."""
+    import ctypes
+    from m6anet_amd import _io
+    L = _io.load()
+    buf = ctypes.create_string_buffer(336)
+
+    def fmt(v):
+        n = L.m6a_io_format_f16(float(v), buf)
+        out = buf.value.decode()
+        assert n == len(out)
+        return out
+
+    rng = np.random.default_rng(5)
+    f32 = np.concatenate([
+        rng.random(200000, dtype=np.float32),                                        # probabilities
+        np.exp(rng.uniform(-100, 0.5, 50000)).astype(np.float32),                    # tiny ones, down to denormal floats
+        rng.integers(0, 0x7f800000, 50000, dtype=np.uint32).view(np.float32)]).astype(np.float64)   # random finite bit patterns >= 0
+    f64 = np.concatenate([
+        rng.random(100000), rng.integers(0, 21, 20000) / 20.0, rng.integers(0, 1001, 20000) / 1000.0,
+        np.exp(rng.uniform(-800, 1.0, 50000)),
+        # exact ties of the 17th digit and their neighbours: k / 2^j with short expansions
+        (rng.integers(0, 2**20, 20000) * 2 + 1) / 2.0**rng.integers(1, 60, 20000)])
+    special = [0.0, -0.0, 1.0, 2.0, 0.5, 1.9999999999999998, 0.99999999999999994, 5e-17, 4.9999999999999996e-17, 1.5e-16, 2.5e-16,
+               5e-324, 2.2250738585072014e-308, 1e300, -0.25, 123456.789, float("nan"), float("inf"), float("-inf"),
+               float(np.float32(0.033379376)), float(np.float32(1.0) - np.float32(2**-24))]
+    vals = np.concatenate([f32, f64, np.array(special)])
+    assert np.isfinite(vals).sum() > 500000
+    bad = [(v, fmt(v), "%.16f" % v) for v in vals.tolist() if fmt(v) != "%.16f" % v]
+    assert not bad, bad[:5]
