@@ -42,6 +42,28 @@ PEAK_HBM_GBPS = 8000.0
 # ds_read_b32 gathers, conflict-free: 64 lanes per 2 LDS cycles per CU (MI355X_MICROARCH.md, LDS table)
 PEAK_LDS_GATHERS = 256 * 2.4e9 * 32
 
+# one multiply per draw; packed f32: 2 per lane per 4-cycle issue slot = the 157.3 TFLOP/s vector peak / 2 flops per FMA
+PEAK_VALU_MULS = PEAK_F32_TFLOPS * 1e12 / 2
+
+
+def pool_roofline(variant, draws, avg_ms, launches):
+    """The pooling kernel against the resource that bounds it: the register kernel of uniform bags issues one
+    v_pk_mul_f32 per two draws and no LDS gather at all (VALU issue); every other variant gathers one 4-byte value
+    per draw from LDS.  DESIGN.md sections 4.2r / 4.3 derive both and the practical ceilings under them."""
+    rate = draws / (avg_ms * 1e-3) if avg_ms else None
+    if variant == "table-reg":
+        bound, peak = "valu", PEAK_VALU_MULS
+        note = ("peak = packed float32 multiply rate (2 per lane per issue slot, 78.6 T/s); on this part v_pk_mul_f32 issues every "
+                "~7 cycles, not 4 (profiles/r02_gpr_variants.txt), which puts the practical ceiling of bags-in-registers at 44.8 T draws/s")
+    else:
+        bound, peak = "lds-gather", PEAK_LDS_GATHERS
+        note = ("peak = conflict-free ds_read_b32 gather rate (one 4-byte gather per draw); random indices into a 50-500 entry bag "
+                "conflict 1.6-2.5x (profiles/r02_lds_gather_probe.txt), so the practical ceiling is 0.28-0.43 of this peak")
+    return {"kernel": "site pooling (%s)" % variant, "bound": bound, "achieved": rate / 1e12 if rate else None, "peak": peak / 1e12,
+            "unit": "T draws/s", "frac": rate / peak if rate else None, "note": note, "avg_launch_ms": avg_ms, "launches": launches,
+            "draws_per_launch": draws}
+
+
 WORKLOADS = {
     "uniform": dict(model="HCT116_RNA002", sites=1_000_000, bag=20, config="BASELINE.json configs[2]"),
     "ragged": dict(model="HEK293T_RNA004", sites=125_000, bag=(50, 500), config="BASELINE.json configs[4] per-GPU shape"),
@@ -411,13 +433,7 @@ def main():
                          "algorithmic_flop_per_read": ENC_FLOP_PER_READ, "reads_per_launch": R,
                          "hbm_view": {"achieved": enc_gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                                       "frac": enc_gbps / PEAK_HBM_GBPS, "algorithmic_bytes_per_read": ENC_BYTES_PER_READ}},
-            "pool_roofline": {"kernel": "site pooling (%s)" % eng.last_pool_variant, "bound": "lds-gather",
-                              "achieved": draws / (pool_avg_ms * 1e-3) / 1e12 if pool_avg_ms else None,
-                              "peak": PEAK_LDS_GATHERS / 1e12, "unit": "T draws/s",
-                              "frac": draws / (pool_avg_ms * 1e-3) / PEAK_LDS_GATHERS if pool_avg_ms else None,
-                              "note": "peak = conflict-free ds_read_b32 gather rate (one 4-byte gather per draw); the uniform-bag "
-                                      "register kernel issues no LDS gathers and is bound by VALU issue instead",
-                              "avg_launch_ms": pool_avg_ms, "launches": pool_n, "draws_per_launch": draws},
+            "pool_roofline": pool_roofline(eng.last_pool_variant, draws, pool_avg_ms, pool_n),
             "kernels": {enc_kernel: {"avg_ms": enc_avg_ms, "launches": enc_n},
                         pool_kernel: {"avg_ms": pool_avg_ms, "launches": pool_n,
                                       "Gdraws_per_s": draws / (pool_avg_ms * 1e-3) / 1e9 if pool_avg_ms else None}},

@@ -605,7 +605,8 @@ int ensure_rtab(m6a_ctx *c, uint32_t seed, int T, int K, int64_t gmax, const uin
             rt.C = nullptr; rt.RS = nullptr; rt.cap = 0;
         }
         // an allocation that fails is not an error of the call: the scan kernels need no tables
-        if (hipMalloc((void **)&nC, (size_t)new_cap * c_stride * 2) != hipSuccess) { (void)hipGetLastError(); return M6A_OK; }
+        // + 64 bytes: a site of odd rank reads its rows as 11 aligned dwords, one halfword past the row on either side
+        if (hipMalloc((void **)&nC, (size_t)new_cap * c_stride * 2 + 64) != hipSuccess) { (void)hipGetLastError(); return M6A_OK; }
         if (hipMalloc((void **)&nRS, (size_t)new_cap * (n_blk + 1) * 4) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(nC); return M6A_OK; }
         if (!fresh && rt.used) {
             HIPCHK(c, hipMemcpyAsync(nC, rt.C, (size_t)rt.used * c_stride * 2, hipMemcpyDeviceToDevice, c->stream));
@@ -828,10 +829,16 @@ int launch_pool(m6a_ctx *c, const float *rp, const int64_t *off, int64_t S, int 
             HIPCHK(c, c->rt_rank.ensure((size_t)S * 4));
             HIPCHK(c, c->rt_order.ensure((size_t)S * 4));
             HIPCHK(c, c->ctl_dev.ensure(kCtlWords * 4));
-            // sites in bag-size order: cursor[n] = first position of size n (the histogram came with the bag range)
+            // sites grouped by bag size: cursor[n] = first position of size n (the histogram came with the bag range).
+            // The kernel gives XCD x the x-th eighth of this order, and a site's cost grows with its bag size (a gather
+            // from 500 entries conflicts 1.5x as often as one from 50): sizes are dealt to the eighths by n mod 8, so
+            // every XCD gets the whole range of sizes and still owns the tables of "its" sizes; largest first inside an
+            // eighth, so the longest sites do not start last.
             uint32_t *cur = ctl_cursor(c);
             uint32_t run = 0;
-            for (int n = 0; n < M6A_HIST_BINS; n++) { cur[n] = run; run += c->h_hist[n]; }
+            for (int x = 0; x < 8; x++)
+                for (int n = M6A_HIST_BINS - 1; n >= 0; n--)
+                    if ((n & 7) == x) { cur[n] = run; run += c->h_hist[n]; }
             std::memcpy(ctl_slot(c), c->rt.slot_of_n, sizeof c->rt.slot_of_n);
             HIPCHK(c, hipMemcpyAsync(c->ctl_dev.p, c->h_ctl, (size_t)(M6A_HIST_BINS + M6A_RTAB_MAX_N + 1) * 4, hipMemcpyHostToDevice, c->stream));
             RtabUse u;

@@ -314,23 +314,38 @@ __global__ __launch_bounds__(256) void rtab_prep_kernel(PoolArgs a, RtabUse u, u
 // =====================================================================================
 // The pooling proper: one wavefront per site.
 // =====================================================================================
-struct __attribute__((packed, aligned(2))) IdxRow20 { uint32_t w[10]; };
-// the K draws of one iteration: gather 1-p at the row's byte offsets, multiply left to right (np.prod's order)
-__device__ __forceinline__ float rtab_product20w(const uint32_t (&w)[10], const char *bagb)
+// The K = 20 draws of one iteration are 40 bytes of the table, at byte offset 2 * (rank + 20 t): dword-aligned when the
+// site's rank is even.  Loads that are only 2-byte aligned cost the texture addresser twice (0.71 -> 0.58 ms per launch
+// on the configs[4] shape with every rank forced even), so a site of odd rank reads the 11 ALIGNED dwords around its
+// row instead and takes its indices from the other halves: hi(d0), lo(d1), hi(d1), ... lo(d10).  The parity is
+// wave-uniform (one site per wave), no shifting is needed -- the SDWA extract picks either half for free.
+struct __attribute__((aligned(4))) IdxRow20 { uint32_t w[10]; };
+struct __attribute__((aligned(4))) IdxRow20Odd { uint32_t w[11]; };
+// gather 1-p at the row's byte offsets, multiply left to right (np.prod's order)
+template <bool ODD>
+__device__ __forceinline__ float rtab_product20(const uint16_t *row, const char *bagb)
 {
     float g[20];
+    if (ODD) {
+        const IdxRow20Odd r = *(const IdxRow20Odd *)(row - 1);
 #pragma unroll
-    for (int j = 0; j < 10; j++) {
-        g[2 * j] = *(const float *)(bagb + (w[j] & 0xffffu));
-        g[2 * j + 1] = *(const float *)(bagb + (w[j] >> 16));
+        for (int j = 0; j < 10; j++) {
+            g[2 * j] = *(const float *)(bagb + (r.w[j] >> 16));
+            g[2 * j + 1] = *(const float *)(bagb + (r.w[j + 1] & 0xffffu));
+        }
+    } else {
+        const IdxRow20 r = *(const IdxRow20 *)row;
+#pragma unroll
+        for (int j = 0; j < 10; j++) {
+            g[2 * j] = *(const float *)(bagb + (r.w[j] & 0xffffu));
+            g[2 * j + 1] = *(const float *)(bagb + (r.w[j] >> 16));
+        }
     }
     float prod = 1.0f;
 #pragma unroll
     for (int k = 0; k < 20; k++) prod *= g[k];
     return prod;
 }
-
-__device__ __forceinline__ float rtab_product20(const IdxRow20 &r, const char *bagb) { return rtab_product20w(r.w, bagb); }
 
 __device__ __forceinline__ float rtab_product_any(const uint16_t *row, const char *bagb, int K)
 {
@@ -388,12 +403,13 @@ __global__ __launch_bounds__(256) void pool_rtab_kernel(PoolArgs a, RtabUse u)
     const uint16_t *tb = n >= 2 ? u.C + (int64_t)u.slot_of_n[n] * u.c_stride + rank : u.C;
     const char *bagb = (const char *)bag;
     const int T = a.T;
+    const bool odd = n >= 2 && (rank & 1u);                // wave-uniform: which halves of the aligned dwords hold the row
 
     // the last leaf's n % 8 tail iterations first; their values wait in LDS
     if (a.n_rem) {
         const int t = lane < a.n_rem ? T - a.n_rem + lane : 0;
         const uint16_t *row = tb + (int64_t)t * K;
-        const float v = 1.0f - (KT == 20 ? rtab_product20(*(const IdxRow20 *)row, bagb) : rtab_product_any(row, bagb, K));
+        const float v = 1.0f - (KT == 20 ? (odd ? rtab_product20<true>(row, bagb) : rtab_product20<false>(row, bagb)) : rtab_product_any(row, bagb, K));
         if (lane < 8) tail[lane] = v;
     }
     int sp = 0;                                            // merge-stack height (lane 0's view)
@@ -418,11 +434,20 @@ __global__ __launch_bounds__(256) void pool_rtab_kernel(PoolArgs a, RtabUse u)
             // index row of round i+1 by hand while round i runs, 0.62 ms; additionally issuing the ten gathers of the
             // next half row before the ten multiplies of the current one, 0.63 ms.  Seven to eight resident waves per
             // SIMD already cover those latencies.)
-            for (int i = 0; i < rounds; ++i) {
-                const bool live = i < my_rounds;
-                const float v = 1.0f - rtab_product20(*(const IdxRow20 *)(live ? row : tb), bagb);
-                sum += live ? v : 0.0f;
-                row += step;
+            if (odd) {
+                for (int i = 0; i < rounds; ++i) {
+                    const bool live = i < my_rounds;
+                    const float v = 1.0f - rtab_product20<true>(live ? row : tb, bagb);
+                    sum += live ? v : 0.0f;
+                    row += step;
+                }
+            } else {
+                for (int i = 0; i < rounds; ++i) {
+                    const bool live = i < my_rounds;
+                    const float v = 1.0f - rtab_product20<false>(live ? row : tb, bagb);
+                    sum += live ? v : 0.0f;
+                    row += step;
+                }
             }
         } else {
             for (int i = 0; i < rounds; ++i) {
