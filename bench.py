@@ -56,9 +56,12 @@ def pool_roofline(variant, draws, avg_ms, launches):
         note = ("peak = packed float32 multiply rate (2 per lane per issue slot, 78.6 T/s); on this part v_pk_mul_f32 issues every "
                 "~7 cycles, not 4 (profiles/r02_gpr_variants.txt), which puts the practical ceiling of bags-in-registers at 44.8 T draws/s")
     else:
-        bound, peak = "lds-gather", PEAK_LDS_GATHERS
-        note = ("peak = conflict-free ds_read_b32 gather rate (one 4-byte gather per draw); random indices into a 50-500 entry bag "
-                "conflict 1.6-2.5x (profiles/r02_lds_gather_probe.txt), so the practical ceiling is 0.28-0.43 of this peak")
+        bound, peak = "l1-lds", PEAK_LDS_GATHERS
+        note = ("a draw moves 2 index bytes through the vector L1 (64 B/clk/CU) and one 4-byte LDS gather (32 banks/clk/CU): both pipes "
+                "peak at 19.7 T draws/s; knock-out builds show the index rows are the binding one for the table kernel "
+                "(DESIGN.md section 4.3; the preparation kernel runs on a side stream under the encoder and is not in avg_launch_ms)"
+                if variant == "ragged-table" else
+                "peak = conflict-free ds_read_b32 gather rate (one 4-byte gather per draw)")
     return {"kernel": "site pooling (%s)" % variant, "bound": bound, "achieved": rate / 1e12 if rate else None, "peak": peak / 1e12,
             "unit": "T draws/s", "frac": rate / peak if rate else None, "note": note, "avg_launch_ms": avg_ms, "launches": launches,
             "draws_per_launch": draws}
@@ -403,7 +406,7 @@ def main():
                 tr = measured_traffic(S, bag)
                 if tr is not None:
                     tr = dict(tr, source="%s (%s) -- committed, not measured by this run" % (tr["file"], tr["source"]))
-        pool_kernel = {"table-reg": "pool_reg_kernel", "table": "pool_table_kernel", "ragged-table": "rtab_prep_kernel+pool_rtab_kernel"}.get(
+        pool_kernel = {"table-reg": "pool_reg_kernel", "table": "pool_table_kernel", "ragged-table": "pool_rtab_kernel"}.get(
             eng.last_pool_variant, "pool_scan_kernels")
         out = {
             "metric": "DRACH sites/sec at num_iterations=%d" % T,

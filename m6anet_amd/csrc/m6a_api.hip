@@ -215,6 +215,10 @@ struct m6a_ctx {
     uint32_t *h_hist = nullptr, *d_hist = nullptr;
     uint32_t *h_ctl = nullptr;                // [cursor HIST_BINS | slot_of_n 1025 | build_n 1024 | build_slot 1024]
     DevBuf ctl_dev, rt_rank, rt_order, reg_out;
+    // ragged pooling prepared ahead of the encoder (m6a_infer): rank / order computed on a side stream
+    hipStream_t s_prep = nullptr;
+    hipEvent_t ev_main = nullptr, ev_prep = nullptr;
+    struct { bool ready = false, use = false; const int64_t *off = nullptr; int64_t S = 0, bs = 0, spb = 0; int T = 0, K = 0; uint32_t seed = 0; } prep;
     // per-bag-size index tables (m6a_pool_rtab.hip), valid for (seed, T*K, stream length)
     struct {
         bool valid = false; uint32_t seed = 0; int64_t A = 0, n_blk = 0;
@@ -747,9 +751,111 @@ int launch_encode(m6a_ctx *c, const float *X, const uint8_t *km, const int64_t *
     return M6A_OK;
 }
 
+RtabUse rtab_use(m6a_ctx *c, int64_t nmax)
+{
+    RtabUse u;
+    u.C = c->rt.C; u.RS = c->rt.RS; u.slot_of_n = (const int32_t *)c->ctl_dev.p + M6A_HIST_BINS;
+    u.rank = (uint32_t *)c->rt_rank.p; u.order = (const uint32_t *)c->rt_order.p;
+    u.c_stride = c->rt.n_blk * 64; u.n_blk = (uint32_t)c->rt.n_blk;
+    u.bag_cap = (int)std::max<int64_t>(64, (nmax + 63) / 64 * 64);
+    return u;
+}
+
+// Ragged bags, first half: decide whether this call pools through the per-bag-size index tables, build the ones
+// that are missing (on the context's stream) and launch the preparation -- every site's rank in its table and the
+// bag-size order -- on `stream`.  Needs only off[] and the histogram of query_bags / host_bag_range, not the read
+// probabilities, so m6a_infer runs it on a side stream next to the encoder (a latency chain on a few waves: 0.1 ms
+// that would otherwise sit between the two big kernels).  a: off, goff, n_groups, n_sites, T, K, err filled in.
+int rtab_prepare(m6a_ctx *c, PoolArgs a, int64_t nmax, int64_t gmax, uint32_t seed, hipStream_t stream, bool *use)
+{
+    *use = false;
+    const int T = a.T, K = a.K;
+    const int64_t S = a.n_sites;
+    const int64_t need = stream_need(gmax, T, K);
+    // Default: per-bag-size index tables (pool_rtab_kernel) when every bag fits one (n <= 1024)
+    // and the work seen so far pays for the tables still lacking (a table = one pass over the stream, about
+    // what 50 sites cost the scan kernels); otherwise the scan kernels replay the stream per site.
+    if (nmax > M6A_RTAB_MAX_N || c->scan_driver == 1 || c->scan_driver == 2) {
+        if (c->scan_driver == 3)
+            return fail(c, M6A_EUNSUPPORTED, "index-table pooling needs every bag <= %d reads (largest: %lld)", M6A_RTAB_MAX_N, (long long)nmax);
+        return M6A_OK;
+    }
+    int distinct = 0;
+    const int missing = rtab_missing(c, seed, T, K, need, c->h_hist, &distinct);
+    // Tables that exist are always worth using (a 32-site call: 125 us against 485 us on the scan kernels).
+    // Missing ones are built once the sites pooled for this (seed, T*K) -- this call's plus those of earlier
+    // calls that went to the scan kernels, e.g. a caller that hands over one flush group at a time -- would
+    // have paid for them.
+    if (c->rt_credit_seed != seed || c->rt_credit_A != (int64_t)T * K) { c->rt_credit_seed = seed; c->rt_credit_A = (int64_t)T * K; c->rt_credit = 0; }
+    bool use_rtab = c->scan_driver == 3 || missing == 0 || c->rt_credit + S >= (int64_t)16 * missing;
+    if (use_rtab) c->rt_credit = 0; else c->rt_credit += S;
+    if (!use_rtab) return M6A_OK;
+    int rc = ensure_rtab(c, seed, T, K, gmax, c->h_hist, &use_rtab);      // false: over the memory budget
+    if (rc) return rc;
+    if (!use_rtab) return M6A_OK;
+    a.raw = (const uint32_t *)c->raw.p; a.raw_len = c->raw_len;
+    HIPCHK(c, c->rt_rank.ensure((size_t)S * 4));
+    HIPCHK(c, c->rt_order.ensure((size_t)S * 4));
+    HIPCHK(c, c->ctl_dev.ensure(kCtlWords * 4));
+    // sites grouped by bag size: cursor[n] = first position of size n (the histogram came with the bag range).
+    // The kernel gives XCD x the x-th eighth of this order, and a site's cost grows with its bag size:
+    // sizes are dealt to the eighths by n mod 8, so every XCD gets the whole range of sizes and still owns the
+    // tables of "its" sizes; largest first inside an eighth, so the longest sites do not start last.
+    uint32_t *cur = ctl_cursor(c);
+    uint32_t run = 0;
+    for (int x = 0; x < 8; x++)
+        for (int n = M6A_HIST_BINS - 1; n >= 0; n--)
+            if ((n & 7) == x) { cur[n] = run; run += c->h_hist[n]; }
+    std::memcpy(ctl_slot(c), c->rt.slot_of_n, sizeof c->rt.slot_of_n);
+    if (stream != c->stream) {
+        // everything queued so far (table builds, flush-group offsets, the previous call's pooling that still reads
+        // rank / order) comes first
+        HIPCHK(c, hipEventRecord(c->ev_main, c->stream));
+        HIPCHK(c, hipStreamWaitEvent(stream, c->ev_main, 0));
+    }
+    HIPCHK(c, hipMemcpyAsync(c->ctl_dev.p, c->h_ctl, (size_t)(M6A_HIST_BINS + M6A_RTAB_MAX_N + 1) * 4, hipMemcpyHostToDevice, stream));
+    const RtabUse u = rtab_use(c, nmax);
+    const unsigned n_order_blocks = (unsigned)((S + 255) / 256);
+    const unsigned n_chain_blocks = (unsigned)std::min<int64_t>((a.n_groups + 3) / 4, (int64_t)c->n_cu * 16);
+    hipLaunchKernelGGL(rtab_prep_kernel, dim3(n_order_blocks + n_chain_blocks), dim3(256), 0, stream, a, u,
+                       (uint32_t *)c->ctl_dev.p, (uint32_t *)c->rt_order.p, n_order_blocks);
+    HIPCHK(c, hipGetLastError());
+    if (stream != c->stream) HIPCHK(c, hipEventRecord(c->ev_prep, stream));
+    *use = true;
+    return M6A_OK;
+}
+
+// m6a_infer, device pointers: the ragged preparation goes to a side stream BEFORE the encoder is launched, so the
+// two overlap; launch_pool() for the same (off, S, ...) then only waits for its event.  Uniform bags have nothing
+// to prepare (their tables do not depend on the call).
+int pool_prepare_ahead(m6a_ctx *c, const int64_t *off, int64_t S, int T, int K, uint32_t seed, int64_t bs, int64_t spb)
+{
+    c->prep.ready = false;
+    if (S <= 0 || !c->s_prep) return M6A_OK;
+    int rc = ensure_groups(c, S, bs, spb);
+    if (rc) return rc;
+    const int64_t nmin = c->bag_min, nmax = c->bag_max, gmax = c->goff_key.gmax;
+    if (nmin < 0 || nmax > 0x7fffffff) return M6A_OK;        // launch_pool reports it
+    if (nmin == nmax && nmin >= 1 && nmin <= M6A_TABLE_MAX_N && K == 20 && gmax <= 4096) return M6A_OK;
+    PoolArgs a;
+    memset(&a, 0, sizeof a);
+    a.off = off; a.goff = (const int64_t *)c->goff.p; a.err = c->d_err;
+    a.n_groups = c->goff_key.G; a.n_sites = S; a.T = T; a.K = K;
+    bool use = false;
+    rc = rtab_prepare(c, a, nmax, gmax, seed, c->s_prep, &use);
+    if (rc) return rc;
+    c->prep.ready = true; c->prep.use = use;
+    c->prep.off = off; c->prep.S = S; c->prep.bs = bs; c->prep.spb = spb; c->prep.T = T; c->prep.K = K; c->prep.seed = seed;
+    return M6A_OK;
+}
+
 int launch_pool(m6a_ctx *c, const float *rp, const int64_t *off, int64_t S, int T, int K, float thr,
                 uint32_t seed, int64_t bs, int64_t spb, float *site, double *mod)
 {
+    // did m6a_infer already run the ragged preparation of exactly this call (pool_prepare_ahead)?  One-shot.
+    const bool prepared = c->prep.ready && c->prep.off == off && c->prep.S == S && c->prep.T == T && c->prep.K == K &&
+                          c->prep.seed == seed && c->prep.bs == bs && c->prep.spb == spb;
+    c->prep.ready = false;
     if (S <= 0) return M6A_OK;
     int rc = ensure_groups(c, S, bs, spb);
     if (rc) return rc;
@@ -806,56 +912,24 @@ int launch_pool(m6a_ctx *c, const float *rp, const int64_t *off, int64_t S, int 
         // what 50 sites cost the scan kernels); otherwise the scan kernels replay the stream per site.
         const int64_t need = stream_need(gmax, T, K);
         bool use_rtab = false;
-        if (nmax <= M6A_RTAB_MAX_N && c->scan_driver != 1 && c->scan_driver != 2) {
-            int distinct = 0;
-            const int missing = rtab_missing(c, seed, T, K, need, c->h_hist, &distinct);
-            // Tables that exist are always worth using (a 32-site call: 125 us against 485 us on the scan kernels).
-            // Missing ones are built once the sites pooled for this (seed, T*K) -- this call's plus those of earlier
-            // calls that went to the scan kernels, e.g. a caller that hands over one flush group at a time -- would
-            // have paid for them.
-            if (c->rt_credit_seed != seed || c->rt_credit_A != (int64_t)T * K) { c->rt_credit_seed = seed; c->rt_credit_A = (int64_t)T * K; c->rt_credit = 0; }
-            use_rtab = c->scan_driver == 3 || missing == 0 || c->rt_credit + S >= (int64_t)16 * missing;
-            if (use_rtab) c->rt_credit = 0; else c->rt_credit += S;
-            if (use_rtab) {
-                rc = ensure_rtab(c, seed, T, K, gmax, c->h_hist, &use_rtab);      // false: over the memory budget
-                if (rc) return rc;
-            }
-        } else if (c->scan_driver == 3) {
-            return fail(c, M6A_EUNSUPPORTED, "index-table pooling needs every bag <= %d reads (largest: %lld)", M6A_RTAB_MAX_N, (long long)nmax);
+        if (prepared) {
+            use_rtab = c->prep.use;                           // pool_prepare_ahead() decided (and, if so, built and launched)
+        } else {
+            rc = rtab_prepare(c, a, nmax, gmax, seed, c->stream, &use_rtab);
+            if (rc) return rc;
         }
         if (use_rtab) {
             plan_args(c, a);
             a.raw = (const uint32_t *)c->raw.p; a.raw_len = c->raw_len;
-            HIPCHK(c, c->rt_rank.ensure((size_t)S * 4));
-            HIPCHK(c, c->rt_order.ensure((size_t)S * 4));
-            HIPCHK(c, c->ctl_dev.ensure(kCtlWords * 4));
-            // sites grouped by bag size: cursor[n] = first position of size n (the histogram came with the bag range).
-            // The kernel gives XCD x the x-th eighth of this order, and a site's cost grows with its bag size (a gather
-            // from 500 entries conflicts 1.5x as often as one from 50): sizes are dealt to the eighths by n mod 8, so
-            // every XCD gets the whole range of sizes and still owns the tables of "its" sizes; largest first inside an
-            // eighth, so the longest sites do not start last.
-            uint32_t *cur = ctl_cursor(c);
-            uint32_t run = 0;
-            for (int x = 0; x < 8; x++)
-                for (int n = M6A_HIST_BINS - 1; n >= 0; n--)
-                    if ((n & 7) == x) { cur[n] = run; run += c->h_hist[n]; }
-            std::memcpy(ctl_slot(c), c->rt.slot_of_n, sizeof c->rt.slot_of_n);
-            HIPCHK(c, hipMemcpyAsync(c->ctl_dev.p, c->h_ctl, (size_t)(M6A_HIST_BINS + M6A_RTAB_MAX_N + 1) * 4, hipMemcpyHostToDevice, c->stream));
-            RtabUse u;
-            u.C = c->rt.C; u.RS = c->rt.RS; u.slot_of_n = (const int32_t *)c->ctl_dev.p + M6A_HIST_BINS;
-            u.rank = (uint32_t *)c->rt_rank.p; u.order = (const uint32_t *)c->rt_order.p;
-            u.c_stride = c->rt.n_blk * 64; u.n_blk = (uint32_t)c->rt.n_blk;
-            u.bag_cap = (int)std::max<int64_t>(64, (nmax + 63) / 64 * 64);
+            const RtabUse u = rtab_use(c, nmax);
             c->pool_variant = "ragged-table";
+            if (prepared) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_prep, 0));   // else it ran on this stream
             prof_begin(c, 1);
-            const unsigned n_order_blocks = (unsigned)((S + 255) / 256);
-            const unsigned n_chain_blocks = (unsigned)std::min<int64_t>((a.n_groups + 3) / 4, (int64_t)c->n_cu * 16);
-            hipLaunchKernelGGL(rtab_prep_kernel, dim3(n_order_blocks + n_chain_blocks), dim3(256), 0, c->stream, a, u,
-                               (uint32_t *)c->ctl_dev.p, (uint32_t *)c->rt_order.p, n_order_blocks);
-            const size_t lds = (size_t)4 * (u.bag_cap + 16 + M6A_MEAN_STACK) * sizeof(float);
-            const unsigned blocks = (unsigned)(((S + 3) / 4 + 7) / 8 * 8);
-            if (K == 20) hipLaunchKernelGGL(pool_rtab_kernel<20>, dim3(blocks), dim3(256), lds, c->stream, a, u);
-            else hipLaunchKernelGGL(pool_rtab_kernel<0>, dim3(blocks), dim3(256), lds, c->stream, a, u);
+            const int wpb = 4;                                // sites per workgroup (1, 2 and 4 measure the same: 0.464 ms)
+            const size_t lds = (size_t)wpb * (u.bag_cap + 16 + M6A_MEAN_STACK) * sizeof(float);
+            const unsigned blocks = (unsigned)(((S + wpb - 1) / wpb + 7) / 8 * 8);
+            if (K == 20) hipLaunchKernelGGL(pool_rtab_kernel<20>, dim3(blocks), dim3(64 * wpb), lds, c->stream, a, u);
+            else hipLaunchKernelGGL(pool_rtab_kernel<0>, dim3(blocks), dim3(64 * wpb), lds, c->stream, a, u);
             prof_end(c, 1);
             HIPCHK(c, hipGetLastError());
             return M6A_OK;
@@ -1198,6 +1272,9 @@ int m6a_create(m6a_ctx **out, const float *weights, size_t n_floats, int device_
     }
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     CRCHK(hipStreamCreate(&c->own_stream));
+    CRCHK(hipStreamCreateWithFlags(&c->s_prep, hipStreamNonBlocking));
+    CRCHK(hipEventCreateWithFlags(&c->ev_main, hipEventDisableTiming));
+    CRCHK(hipEventCreateWithFlags(&c->ev_prep, hipEventDisableTiming));
     c->stream = c->own_stream;
     std::vector<float> frag, frag2, w1e;
     build_fragments(weights, frag, frag2, w1e);
@@ -1252,6 +1329,9 @@ void m6a_destroy(m6a_ctx *c)
     for (DevBuf *b : {&c->ctl_dev, &c->rt_rank, &c->rt_order, &c->sOffChunk, &c->reg_out}) b->release();
     release_staging(c);
     if (c->comm) { Rccl *R = rccl(); if (R->CommDestroy) (void)R->CommDestroy(c->comm); c->comm = nullptr; }
+    if (c->s_prep) (void)hipStreamDestroy(c->s_prep);
+    if (c->ev_main) (void)hipEventDestroy(c->ev_main);
+    if (c->ev_prep) (void)hipEventDestroy(c->ev_prep);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -1391,8 +1471,10 @@ int m6a_infer(m6a_ctx *c, const float *X, const uint8_t *km, const int64_t *off,
         const int64_t R = c->n_reads;
         float *p = rp;
         if (!p) { HIPCHK(c, c->rp_scratch.ensure((size_t)std::max<int64_t>(R, 1) * 4)); p = (float *)c->rp_scratch.p; }
-        rc = launch_encode(c, X, km, off, S, R, p);
+        rc = pool_prepare_ahead(c, off, S, T, K, seed, bs, spb);
         if (rc) return rc;
+        rc = launch_encode(c, X, km, off, S, R, p);
+        if (rc) { c->prep.ready = false; return rc; }
         return launch_pool(c, p, off, S, T, K, thr, seed, bs, spb, site, mod);
     }
     if (off[0] != 0) return fail(c, M6A_EINVAL, "off[0] must be 0");

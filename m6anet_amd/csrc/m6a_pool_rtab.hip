@@ -368,7 +368,8 @@ __global__ __launch_bounds__(256) void pool_rtab_kernel(PoolArgs a, RtabUse u)
     // wavefront and launch slot: persistent waves were tried and are slower (a fixed stride per wave 0.73 ms, a per-XCD
     // atomic work counter 1.58 ms, against 0.60 ms) -- the hardware dispatcher balances the 31 250 workgroups better.
     const uint32_t chunk = gridDim.x >> 3;                 // gridDim.x is a multiple of 8
-    const int64_t si = ((int64_t)(blockIdx.x & 7) * chunk + (blockIdx.x >> 3)) * 4 + wib;
+    const int wpb = (int)(blockDim.x >> 6);                // sites (wavefronts) per workgroup
+    const int64_t si = ((int64_t)(blockIdx.x & 7) * chunk + (blockIdx.x >> 3)) * wpb + wib;
     if (si >= a.n_sites) return;
     const int64_t s = (int64_t)(uint32_t)uni((int)u.order[si]);
     const int64_t r0 = uni64(a.off[s]);
@@ -430,10 +431,11 @@ __global__ __launch_bounds__(256) void pool_rtab_kernel(PoolArgs a, RtabUse u)
         const int64_t step = (int64_t)8 * K;
         float sum = 0.0f;
         if (KT == 20) {
-            // (Tried on the configs[4] shape and dropped, neither faster than this plain loop at 0.60 ms: fetching the
-            // index row of round i+1 by hand while round i runs, 0.62 ms; additionally issuing the ten gathers of the
-            // next half row before the ten multiplies of the current one, 0.63 ms.  Seven to eight resident waves per
-            // SIMD already cover those latencies.)
+            // (Tried on the configs[4] shape and dropped, neither faster than this plain loop: the index row of round i+1
+            // in flight while round i runs -- by hand with inline-asm loads before the rows were aligned, 0.62 against
+            // 0.60 ms; as two row buffers in a loop unrolled by two after, 0.484 against 0.467 ms -- and issuing the ten
+            // gathers of the next half row before the ten multiplies of the current one, 0.63 ms.  Seven to eight resident
+            // waves per SIMD already cover those latencies.)
             if (odd) {
                 for (int i = 0; i < rounds; ++i) {
                     const bool live = i < my_rounds;
