@@ -925,11 +925,10 @@ int launch_pool(m6a_ctx *c, const float *rp, const int64_t *off, int64_t S, int 
             c->pool_variant = "ragged-table";
             if (prepared) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_prep, 0));   // else it ran on this stream
             prof_begin(c, 1);
-            const int wpb = 4;                                // sites per workgroup (1, 2 and 4 measure the same: 0.464 ms)
-            const size_t lds = (size_t)wpb * (u.bag_cap + 16 + M6A_MEAN_STACK) * sizeof(float);
-            const unsigned blocks = (unsigned)(((S + wpb - 1) / wpb + 7) / 8 * 8);
-            if (K == 20) hipLaunchKernelGGL(pool_rtab_kernel<20>, dim3(blocks), dim3(64 * wpb), lds, c->stream, a, u);
-            else hipLaunchKernelGGL(pool_rtab_kernel<0>, dim3(blocks), dim3(64 * wpb), lds, c->stream, a, u);
+            const size_t lds = (size_t)(u.bag_cap + 16 + M6A_MEAN_STACK) * sizeof(float);
+            const unsigned blocks = (unsigned)((S + 7) / 8 * 8);            // one wavefront (workgroup) per site
+            if (K == 20) hipLaunchKernelGGL(pool_rtab_kernel<20>, dim3(blocks), dim3(64), lds, c->stream, a, u);
+            else hipLaunchKernelGGL(pool_rtab_kernel<0>, dim3(blocks), dim3(64), lds, c->stream, a, u);
             prof_end(c, 1);
             HIPCHK(c, hipGetLastError());
             return M6A_OK;

@@ -12,7 +12,8 @@
 #define M6A_CSITE_MIN_BAG 16          // enc_csite_kernel: a 32-read tile must span <= 3 sites
 #define M6A_TABLE_MAX_N 32        // pool_table_kernel: byte offsets 8*idx must fit a byte; pool_reg_kernel: 32 register pairs
 #define M6A_REG_STACK 8           // pool_reg_kernel: merge stack entries held in registers
-#define M6A_RTAB_MAX_N 1024       // pool_rtab_kernel: bag sizes with an index table (u16 byte offsets, LDS bag)
+#define M6A_RTAB_MAX_N 1024       // pool_rtab_kernel: bag sizes with an index table (LDS bag)
+#define M6A_RTAB_U8_MAX_N 256     // ... tables of bags up to this size hold index bytes, larger ones u16 byte offsets
 #define M6A_HIST_BINS (M6A_RTAB_MAX_N + 2)   // bag-size histogram: n = 0..1024, last bin = larger
 
 struct EncArgs {

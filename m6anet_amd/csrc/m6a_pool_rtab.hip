@@ -126,7 +126,8 @@ __global__ __launch_bounds__(640) void mt19937_kernel(uint32_t seed, int64_t n_w
 // the fast grid axis, so a chunk of the stream is read by all bag sizes while it sits in L2.
 //   count: accepted words per block -> RS[slot][b]
 //   scan:  exclusive prefix per slot, total in RS[slot][n_blk]
-//   fill:  C[slot][RS[b] + rank] = 4 * (w & mask)     (byte offset into the float bag)
+//   fill:  C[slot][RS[b] + rank] = w & mask as a byte (bags <= 256 reads: the slot's first half) or 4 * (w & mask) as
+//          u16 (the byte offset into the float bag)
 // =====================================================================================
 #define RTAB_CHUNK 16
 
@@ -195,7 +196,10 @@ __global__ __launch_bounds__(256) void rtab_fill_kernel(RtabBuild a)
             const unsigned long long bal = __ballot(ok);
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0));
             const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)pre, i);
-            if (ok) C[(int64_t)base + rank] = (uint16_t)(4u * v);
+            if (ok) {
+                if (n <= M6A_RTAB_U8_MAX_N) ((uint8_t *)C)[(int64_t)base + rank] = (uint8_t)v;      // index
+                else C[(int64_t)base + rank] = (uint16_t)(4u * v);                                 // byte offset
+            }
         }
     }
 }
@@ -207,7 +211,7 @@ __global__ __launch_bounds__(256) void rtab_to_reg_table_kernel(const uint16_t *
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= A * jmax) return;
     const int64_t j = e / A, w = e - j * A;
-    tab[j * row_bytes + w] = (uint8_t)(C[e] >> 1);
+    tab[j * row_bytes + w] = (uint8_t)(2u * ((const uint8_t *)C)[e]);      // uniform bags are <= 32 reads: a byte table
 }
 
 // =====================================================================================
@@ -314,62 +318,126 @@ __global__ __launch_bounds__(256) void rtab_prep_kernel(PoolArgs a, RtabUse u, u
 // =====================================================================================
 // The pooling proper: one wavefront per site.
 // =====================================================================================
-// The K = 20 draws of one iteration are 40 bytes of the table, at byte offset 2 * (rank + 20 t): dword-aligned when the
-// site's rank is even.  Loads that are only 2-byte aligned cost the texture addresser twice (0.71 -> 0.58 ms per launch
-// on the configs[4] shape with every rank forced even), so a site of odd rank reads the 11 ALIGNED dwords around its
-// row instead and takes its indices from the other halves: hi(d0), lo(d1), hi(d1), ... lo(d10).  The parity is
-// wave-uniform (one site per wave), no shifting is needed -- the SDWA extract picks either half for free.
-struct __attribute__((aligned(4))) IdxRow20 { uint32_t w[10]; };
-struct __attribute__((aligned(4))) IdxRow20Odd { uint32_t w[11]; };
-// gather 1-p at the row's byte offsets, multiply left to right (np.prod's order)
-template <bool ODD>
-__device__ __forceinline__ float rtab_product20(const uint16_t *row, const char *bagb)
+// The K = 20 draws of one iteration are one table row: 40 bytes of u16 byte offsets at byte 2 * (rank + 20 t), or -- bags of
+// at most 256 reads -- 20 index bytes at byte rank + 20 t.  The rows are what bounds this kernel (profiles/r02_ragged_rows.txt:
+// 2 bytes per draw through the vector L1), hence the byte tables; and a row that is not dword-aligned costs the address path
+// twice (0.71 -> 0.58 ms per launch with every rank forced even), so a lane always loads the ALIGNED dwords around its row
+// and picks its indices out of them at the site's alignment class (rank mod 2, or rank mod 4 for byte rows): wave-uniform,
+// one instantiation of the loop per class, and the SDWA extract picks any half or byte for free.
+//   MODE 0 / 1: u16 rows, rank even / odd;  MODE 2..5: byte rows, rank mod 4 = MODE - 2.
+// 4 * byte B of w in ONE instruction (the compiler's own choice is v_bfe_u32 + v_lshl_add_u32): an SDWA shift whose source
+// operand selects the byte.  SDWA takes no literal, the shift count rides in a register.
+template <int B>
+__device__ __forceinline__ uint32_t byte_times4(uint32_t w, uint32_t two)
+{
+    uint32_t r;
+    if (B == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(two), "v"(w));
+    else if (B == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(two), "v"(w));
+    else if (B == 2) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(two), "v"(w));
+    else asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(two), "v"(w));
+    return r;
+}
+
+template <int MODE, int J>
+struct ByteGather {                                                     // draws J..19 of a byte row (compile-time byte positions)
+    template <typename Row>
+    static __device__ __forceinline__ void run(const Row &r, const char *bagb, uint32_t two, float (&g)[20])
+    {
+        constexpr int b = J + MODE - 2;
+        g[J] = *(const float *)(bagb + byte_times4<(b & 3)>(r.w[b >> 2], two));
+        ByteGather<MODE, J + 1>::run(r, bagb, two, g);
+    }
+};
+template <int MODE>
+struct ByteGather<MODE, 20> {
+    template <typename Row>
+    static __device__ __forceinline__ void run(const Row &, const char *, uint32_t, float (&)[20]) {}
+};
+
+template <int MODE>
+__device__ __forceinline__ float rtab_product20(const char *row, const char *bagb)
 {
     float g[20];
-    if (ODD) {
-        const IdxRow20Odd r = *(const IdxRow20Odd *)(row - 1);
+    if (MODE < 2) {
+        constexpr int ND = 10 + MODE;
+        struct __attribute__((aligned(4))) Row { uint32_t w[ND]; };
+        const Row r = *(const Row *)(row - 2 * MODE);
 #pragma unroll
-        for (int j = 0; j < 10; j++) {
-            g[2 * j] = *(const float *)(bagb + (r.w[j] >> 16));
-            g[2 * j + 1] = *(const float *)(bagb + (r.w[j + 1] & 0xffffu));
+        for (int j = 0; j < 20; j++) {
+            const int h = j + MODE;                                     // halfword of the aligned dwords
+            g[j] = *(const float *)(bagb + ((h & 1) ? r.w[h >> 1] >> 16 : r.w[h >> 1] & 0xffffu));
         }
     } else {
-        const IdxRow20 r = *(const IdxRow20 *)row;
-#pragma unroll
-        for (int j = 0; j < 10; j++) {
-            g[2 * j] = *(const float *)(bagb + (r.w[j] & 0xffffu));
-            g[2 * j + 1] = *(const float *)(bagb + (r.w[j] >> 16));
-        }
+        constexpr int AL = MODE - 2, ND = (AL + 20 + 3) / 4;
+        struct __attribute__((aligned(4))) Row { uint32_t w[ND]; };
+        const Row r = *(const Row *)(row - AL);
+        uint32_t two;
+        asm("v_mov_b32 %0, 2" : "=v"(two));                             // opaque: a known constant would be folded back into v_bfe + shift
+        ByteGather<(MODE < 2 ? 2 : MODE), 0>::run(r, bagb, two, g);     // draw j = byte j + AL of the aligned dwords
     }
     float prod = 1.0f;
 #pragma unroll
-    for (int k = 0; k < 20; k++) prod *= g[k];
+    for (int k = 0; k < 20; k++) prod *= g[k];                          // left to right: np.prod's order
     return prod;
 }
 
-__device__ __forceinline__ float rtab_product_any(const uint16_t *row, const char *bagb, int K)
+template <bool BYTES>
+__device__ __forceinline__ float rtab_product_any(const char *row, const char *bagb, int K)
 {
     float prod = 1.0f;
-    for (int k = 0; k < K; k++) prod *= *(const float *)(bagb + row[k]);
+    for (int k = 0; k < K; k++)
+        prod *= *(const float *)(bagb + (BYTES ? 4u * ((const uint8_t *)row)[k] : (uint32_t)((const uint16_t *)row)[k]));
     return prod;
+}
+
+// a lane's chain of one pass: rounds of 8 iterations apart (row stride `step` bytes); lanes whose leaf is shorter re-read
+// the site's first row and add nothing
+template <int KT, int MODE>
+__device__ __forceinline__ float rtab_chain(const char *row, const char *tb, int64_t step, int rounds, int my_rounds, const char *bagb, int K)
+{
+    float sum = 0.0f;
+    for (int i = 0; i < rounds; ++i) {
+        const bool live = i < my_rounds;
+        const char *rp = live ? row : tb;
+        const float v = 1.0f - (KT == 20 ? rtab_product20<MODE>(rp, bagb) : rtab_product_any<(MODE >= 2)>(rp, bagb, K));
+        sum += live ? v : 0.0f;
+        row += step;
+    }
+    return sum;
 }
 
 template <int KT>
-__global__ __launch_bounds__(256) void pool_rtab_kernel(PoolArgs a, RtabUse u)
+__device__ __forceinline__ float rtab_chain_mode(int mode, const char *row, const char *tb, int64_t step, int rounds, int my_rounds, const char *bagb, int K)
 {
+    // (Tried on the configs[4] shape and dropped, neither faster than the plain loop: the index row of round i+1 in flight
+    // while round i runs -- by hand with inline-asm loads before the rows were aligned, 0.62 against 0.60 ms; as two row
+    // buffers in a loop unrolled by two after, 0.484 against 0.467 ms -- and issuing the ten gathers of the next half row
+    // before the ten multiplies of the current one, 0.63 ms.  Seven to eight resident waves per SIMD cover those latencies.)
+    switch (mode) {                                                     // wave-uniform
+    case 0: return rtab_chain<KT, 0>(row, tb, step, rounds, my_rounds, bagb, K);
+    case 1: return rtab_chain<KT, 1>(row, tb, step, rounds, my_rounds, bagb, K);
+    case 2: return rtab_chain<KT, 2>(row, tb, step, rounds, my_rounds, bagb, K);
+    case 3: return rtab_chain<KT, 3>(row, tb, step, rounds, my_rounds, bagb, K);
+    case 4: return rtab_chain<KT, 4>(row, tb, step, rounds, my_rounds, bagb, K);
+    default: return rtab_chain<KT, 5>(row, tb, step, rounds, my_rounds, bagb, K);
+    }
+}
+
+template <int KT>
+__global__ __launch_bounds__(64) void pool_rtab_kernel(PoolArgs a, RtabUse u)
+{
+    // one wavefront = one workgroup = one site (1, 2 and 4 sites per workgroup measure the same; with one, every LDS
+    // address below is a compile-time offset): stage[8] leaf sums of a pass | tail[8] | merge stack | bag
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *stage = smem, *tail = smem + 8, *stack = smem + 16, *bag = smem + 16 + M6A_MEAN_STACK;
     const int K = KT ? KT : a.K;
-    const int lane = threadIdx.x & 63, wib = uni((int)(threadIdx.x >> 6));
-    // per wave: bag | stage[8] leaf sums of a pass | tail[8] | merge stack
-    float *bag = smem + wib * (u.bag_cap + 16 + M6A_MEAN_STACK);
-    float *stage = bag + u.bag_cap, *tail = stage + 8, *stack = tail + 8;
+    const int lane = threadIdx.x;
     // blockIdx -> position in the bag-size order, XCD-aware: workgroups go round-robin over the 8 XCDs, so XCD x
     // walks the contiguous eighth x of the order and the tables of "its" bag sizes stay in its L2.  One site per
-    // wavefront and launch slot: persistent waves were tried and are slower (a fixed stride per wave 0.73 ms, a per-XCD
-    // atomic work counter 1.58 ms, against 0.60 ms) -- the hardware dispatcher balances the 31 250 workgroups better.
+    // launch slot: persistent waves were tried and are slower (a fixed stride per wave 0.73 ms, a per-XCD
+    // atomic work counter 1.58 ms, against 0.60 ms) -- the hardware dispatcher balances the workgroups better.
     const uint32_t chunk = gridDim.x >> 3;                 // gridDim.x is a multiple of 8
-    const int wpb = (int)(blockDim.x >> 6);                // sites (wavefronts) per workgroup
-    const int64_t si = ((int64_t)(blockIdx.x & 7) * chunk + (blockIdx.x >> 3)) * wpb + wib;
+    const int64_t si = (int64_t)(blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
     if (si >= a.n_sites) return;
     const int64_t s = (int64_t)(uint32_t)uni((int)u.order[si]);
     const int64_t r0 = uni64(a.off[s]);
@@ -400,17 +468,20 @@ __global__ __launch_bounds__(256) void pool_rtab_kernel(PoolArgs a, RtabUse u)
     if (lane == 0) a.mod_ratio[s] = (double)cge / (double)n;
     if (rank == 0xffffffffu) return;                       // stream too short: the chain kernel raised the flag
     wave_fence();
-    // bags of one read draw no words: slot 0 is a table of zeros (every draw is read 0)
-    const uint16_t *tb = n >= 2 ? u.C + (int64_t)u.slot_of_n[n] * u.c_stride + rank : u.C;
+    // the site's rows: byte rows for bags <= 256 reads, u16 rows above; bags of one read draw no words: slot 0 is a
+    // table of zeros (every draw is read 0), read as byte rows at rank 0
+    const bool bytes = n <= M6A_RTAB_U8_MAX_N;
+    const int esz = bytes ? 1 : 2;
+    const char *tb = (const char *)u.C + (n >= 2 ? ((int64_t)u.slot_of_n[n] * u.c_stride) * 2 + (int64_t)rank * esz : 0);
+    const int mode = n < 2 ? 2 : bytes ? 2 + (int)(rank & 3u) : (int)(rank & 1u);      // wave-uniform alignment class
     const char *bagb = (const char *)bag;
     const int T = a.T;
-    const bool odd = n >= 2 && (rank & 1u);                // wave-uniform: which halves of the aligned dwords hold the row
+    const int64_t row_bytes = (int64_t)K * esz;
 
     // the last leaf's n % 8 tail iterations first; their values wait in LDS
     if (a.n_rem) {
         const int t = lane < a.n_rem ? T - a.n_rem + lane : 0;
-        const uint16_t *row = tb + (int64_t)t * K;
-        const float v = 1.0f - (KT == 20 ? (odd ? rtab_product20<true>(row, bagb) : rtab_product20<false>(row, bagb)) : rtab_product_any(row, bagb, K));
+        const float v = rtab_chain_mode<KT>(mode, tb + t * row_bytes, tb, 0, 1, 1, bagb, K);
         if (lane < 8) tail[lane] = v;
     }
     int sp = 0;                                            // merge-stack height (lane 0's view)
@@ -427,38 +498,7 @@ __global__ __launch_bounds__(256) void pool_rtab_kernel(PoolArgs a, RtabUse u)
         rounds = uni(rounds);
         // merges that follow each of the pass's leaves: 8 bytes of the plan, scalar loads (uniform address)
         const uint32_t mw0 = ((const uint32_t *)a.merge_after)[2 * ps], mw1 = ((const uint32_t *)a.merge_after)[2 * ps + 1];
-        const uint16_t *row = tb + (int64_t)(ls + (lane & 7)) * K;
-        const int64_t step = (int64_t)8 * K;
-        float sum = 0.0f;
-        if (KT == 20) {
-            // (Tried on the configs[4] shape and dropped, neither faster than this plain loop: the index row of round i+1
-            // in flight while round i runs -- by hand with inline-asm loads before the rows were aligned, 0.62 against
-            // 0.60 ms; as two row buffers in a loop unrolled by two after, 0.484 against 0.467 ms -- and issuing the ten
-            // gathers of the next half row before the ten multiplies of the current one, 0.63 ms.  Seven to eight resident
-            // waves per SIMD already cover those latencies.)
-            if (odd) {
-                for (int i = 0; i < rounds; ++i) {
-                    const bool live = i < my_rounds;
-                    const float v = 1.0f - rtab_product20<true>(live ? row : tb, bagb);
-                    sum += live ? v : 0.0f;
-                    row += step;
-                }
-            } else {
-                for (int i = 0; i < rounds; ++i) {
-                    const bool live = i < my_rounds;
-                    const float v = 1.0f - rtab_product20<false>(live ? row : tb, bagb);
-                    sum += live ? v : 0.0f;
-                    row += step;
-                }
-            }
-        } else {
-            for (int i = 0; i < rounds; ++i) {
-                const bool live = i < my_rounds;
-                const float v = 1.0f - rtab_product_any(live ? row : tb, bagb, K);
-                sum += live ? v : 0.0f;
-                row += step;
-            }
-        }
+        const float sum = rtab_chain_mode<KT>(mode, tb + (ls + (lane & 7)) * row_bytes, tb, 8 * row_bytes, rounds, my_rounds, bagb, K);
         const float lsum = chain8_sum_r(sum);
         if ((lane & 7) == 0) stage[lane >> 3] = lsum;
         wave_fence();
