@@ -14,16 +14,19 @@
 // and a site of size n that starts at stream word p simply uses C_n[r .. r + T*K) with
 // r = rank_n(p) = #accepted words before p; it ends at the word after the (r + T*K - 1)-th accepted
 // one, where the group's next site starts.  That splits the job into
-//   rtab_count/scan/fill   C_n (as u16 byte offsets 4*v) + RS_n (rank at every 64-word block) for
-//                          each new bag size -- built once per (seed, T*K), kept across calls;
+//   rtab_count/scan/fill   C_n (index bytes for n <= 256, u16 byte offsets 4*v above) + RS_n (rank at every
+//                          64-word block) for each new bag size -- built once per (seed, T*K), kept across calls;
 //   rtab_prep_kernel       one wavefront per flush group walks its <= 32 sites: rank lookup, jump
 //                          T*K ranks ahead, select -- three dependent L2 round trips per site,
 //                          no stream scanning at all; the same launch orders the sites by bag size;
-//   pool_rtab_kernel       one wavefront per site, sites ordered by bag size (a table of 2-3 MB
+//                          m6a_infer runs it on a side stream under the encoder;
+//   pool_rtab_kernel       one wavefront per site, sites ordered by bag size (a table of 1-3 MB
 //                          stays in one XCD's L2 while its sites run): lane = iteration, a lane
-//                          loads its 20 indices as one 40-byte row, gathers 1-p from the LDS bag
-//                          (one ds_read_b32 per draw, no compaction, no ballots) and multiplies
-//                          left to right.  Bound: LDS gather rate under random bank conflicts.
+//                          loads its 20 indices as one 20- or 40-byte row (aligned dwords, picked apart
+//                          at the site's alignment class), gathers 1-p from the LDS bag (one ds_read_b32
+//                          per draw, no compaction, no ballots) and multiplies left to right.
+//                          Bound: first the index rows through the vector L1, after the byte tables the
+//                          LDS gathers under random bank conflicts (profiles/r02_ragged_rows.txt).
 // The mean over iterations follows NumPy's pairwise sum exactly as the other pooling kernels do
 // (MeanPlan, m6a_api.hip): lane = accumulator chain (lane & 7) of leaf 8*pass + lane/8.
 #include "m6a_kernels.h"
