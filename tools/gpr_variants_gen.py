@@ -23,15 +23,24 @@ def body(variant):
             return '  v_fma_f32 v4, v128, v4, 0\\n  v_fma_f32 v5, v129, v5, 0\\n  v_fma_f32 v6, v192, v6, 0\\n  v_fma_f32 v7, v193, v7, 0\\n'
         if variant == 'mac4':
             return '  v_mul_f32_e32 v4, v128, v4\\n  v_mul_f32_e32 v5, v129, v5\\n  v_mul_f32_e32 v6, v192, v6\\n  v_mul_f32_e32 v7, v193, v7\\n'
+        if variant == 'pk_noidx_nc':      # no VGPR bank shared between the two 64-bit sources (bank = register number mod 4)
+            return '  v_pk_mul_f32 v[6:7], v[128:129], v[6:7]\\n  v_pk_mul_f32 v[4:5], v[194:195], v[4:5]\\n'
+        if variant == 'pk_noidx_c':       # both sources in the same two banks
+            return '  v_pk_mul_f32 v[4:5], v[128:129], v[4:5]\\n  v_pk_mul_f32 v[6:7], v[194:195], v[6:7]\\n'
+        if variant == 'pk_nc':            # indexed, bag pairs at a stride of four registers: always banks {0,1} / {2,3}
+            return '  v_pk_mul_f32 v[6:7], v[128:129], v[6:7]\\n  v_pk_mul_f32 v[4:5], v[130:131], v[4:5]\\n'
         if variant in ('pk','pk_fixed','pk_noidx'):
             return '  v_pk_mul_f32 v[4:5], v[128:129], v[4:5]\\n  v_pk_mul_f32 v[6:7], v[192:193], v[6:7]\\n'
         return '  v_mul_f32 v4, v128, v4\\n  v_mul_f32 v5, v129, v5\\n  v_mul_f32 v6, v192, v6\\n  v_mul_f32 v7, v193, v7\\n'
-    idx = variant in ('pk','mul4','pkfma','fma4','mac4')
+    idx = variant in ('pk','mul4','pkfma','fma4','mac4','pk_nc')
     fixed = variant in ('pk_fixed','mul4_fixed')
-    if idx or fixed: L.append('  s_set_gpr_idx_on s16, gpr_idx(SRC0)\\n')
+    if variant == 'pk_nc':
+        L.append('  s_lshl_b32 s40, s16, 1\\n  s_set_gpr_idx_on s40, gpr_idx(SRC0)\\n')
+    elif idx or fixed: L.append('  s_set_gpr_idx_on s16, gpr_idx(SRC0)\\n')
     L.append(mul())
     for k in range(17,36):
-        if idx: L.append('  s_set_gpr_idx_idx s%d\\n'%k)
+        if variant == 'pk_nc': L.append('  s_lshl_b32 s40, s%d, 1\\n  s_set_gpr_idx_idx s40\\n'%k)
+        elif idx: L.append('  s_set_gpr_idx_idx s%d\\n'%k)
         L.append(mul())
     if idx or fixed: L.append('  s_set_gpr_idx_off\\n')
     L.append('  v_pk_add_f32 v[4:5], v[4:5], 1.0 op_sel_hi:[1,0] neg_lo:[1,0] neg_hi:[1,0]\\n  v_pk_add_f32 v[6:7], v[6:7], 1.0 op_sel_hi:[1,0] neg_lo:[1,0] neg_hi:[1,0]\\n')
@@ -39,13 +48,13 @@ def body(variant):
     L.append('  s_add_u32 s38, s38, 80\\n  s_addc_u32 s39, s39, 0\\n  s_sub_u32 s36, s36, 1\\n  s_cmp_lg_u32 s36, 0\\n  s_cbranch_scc1 1b\\n')
     for i,r in enumerate((8,9,10,11)): L.append('  v_mov_b32 %%[o%d], v%d\\n'%(i,r))
     return ''.join('        "%s"\n'%x for x in L)
-clob=', '.join('"v%d"'%i for i in list(range(3,12))+list(range(128,256)))+', '+', '.join('"s%d"'%i for i in range(16,40))+', "m0", "scc", "memory"'
+clob=', '.join('"v%d"'%i for i in list(range(3,12))+list(range(128,256)))+', '+', '.join('"s%d"'%i for i in range(16,41))+', "m0", "scc", "memory"'
 src='''#include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 '''
-variants=['pk','pkfma','fma4','pkfma_noidx','fma4_noidx','mac4']
+variants=['pk','pk_noidx','pk_noidx_nc','pk_noidx_c','pk_nc']
 for v in variants:
     src+='''__global__ __launch_bounds__(64) void k_%s(const unsigned *tab, int T, float *out)
 {
