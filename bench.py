@@ -332,7 +332,16 @@ def main():
     else:
         gather = mdist.SiteGather(cuts, dev if backend == "nccl" else "cpu", dst=0) if world > 1 else None
 
+    off_host = np.ascontiguousarray(d["off"], dtype=np.int64)
+    host_offsets = os.environ.get("M6A_BENCH_HOST_OFFSETS", "1") != "0"
+
     def step():
+        # the loader's host copy of the CSR offsets rides along (every step: its statistics are recomputed from it on
+        # the host, the device array is checked against them on the GPU), so the call has nothing to read back and the
+        # steps queue back to back; M6A_BENCH_HOST_OFFSETS=0: the library reads the statistics back itself (one stream
+        # sync per step)
+        if host_offsets:
+            eng.set_host_offsets(off_host)
         eng.infer(X, km, off, T, 20, thr, 0, 16, 2, out=(rp, site, mod))
         if world > 1:
             if backend == "nccl":
@@ -421,7 +430,8 @@ def main():
                                    % (S, bag_txt, spec["model"], T, spec["config"],
                                       " x%d GPUs%s" % (world, " (configs[3])" if args.workload == "uniform" else " (configs[4])") if world > 1 else ""),
                        "sites_per_gpu": S, "reads_per_site": list(bag) if isinstance(bag, tuple) else bag, "reads_rank0": R,
-                       "num_iterations": T, "pool_kernel": eng.last_pool_variant, "encoder_kernel": eng.last_encoder_variant,
+                       "num_iterations": T, "bag_statistics": "host copy of off[] per step, device-checked (m6a_set_host_offsets)" if host_offsets else "read back per step",
+                       "pool_kernel": eng.last_pool_variant, "encoder_kernel": eng.last_encoder_variant,
                        "sharding": "contiguous flush-group-aligned site shards balanced by reads, 1 %s gather/step"
                                    % (("RCCL (m6a_gather)" if native_gather else "RCCL (torch.distributed)") if backend == "nccl" else backend)
                                    if world > 1 else "none"},

@@ -65,6 +65,14 @@ int m6a_set_stream(m6a_ctx *ctx, void *hip_stream);
  * such cuts).  Default 0. */
 int m6a_set_job_offset(m6a_ctx *ctx, int64_t first_site);
 int m6a_sync(m6a_ctx *ctx);    /* waits for the stream; returns a deferred kernel-side error if any */
+/* Optional, for calls with DEVICE pointers: hand over the host copy of the NEXT call's off[] (S+1 values; the loader that
+ * built the CSR array has it -- the reference's collate keeps n_reads on the host, data_utils.py:498-506).  The bag
+ * statistics that choose the kernels then come from this copy and the call neither reads anything back nor blocks on the
+ * stream: consecutive calls queue back to back.  The device array is still checked against the copy, on the device; a
+ * mismatch makes the results of that call undefined and is reported as a deferred M6A_EINVAL by the next m6a_sync.
+ * One-shot: consumed by the next m6a_encode_reads / m6a_site_pool / m6a_infer / m6a_validate call on this context; the
+ * pointer is read inside that call only.  NULL withdraws it. */
+int m6a_set_host_offsets(m6a_ctx *ctx, const int64_t *off_host);
 /* Optional: set up the host-pointer path now (pinned staging ring + copy threads; tens of milliseconds of page
  * pinning) instead of inside the first call that passes host buffers -- e.g. while the caller is still parsing
  * its input.  Host-buffer calls to m6a_infer / m6a_encode_reads cut the job into chunks and overlap the PCIe

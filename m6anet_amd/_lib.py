@@ -12,7 +12,7 @@ ERRORS = {-1: "M6A_EINVAL", -2: "M6A_ENOMEM", -3: "M6A_EHIP", -4: "M6A_ESTREAM",
 RNG_NUMPY = 0
 
 # every symbol include/m6a.h declares (tests check the .so exports exactly these)
-SYMBOLS = ["m6a_create", "m6a_destroy", "m6a_last_error", "m6a_set_stream", "m6a_set_job_offset", "m6a_set_scan_driver", "m6a_set_table_variant", "m6a_set_encoder_variant", "m6a_last_encoder_variant", "m6a_sync", "m6a_prepare_host_io",
+SYMBOLS = ["m6a_create", "m6a_destroy", "m6a_last_error", "m6a_set_stream", "m6a_set_job_offset", "m6a_set_scan_driver", "m6a_set_table_variant", "m6a_set_encoder_variant", "m6a_last_encoder_variant", "m6a_sync", "m6a_set_host_offsets", "m6a_prepare_host_io",
            "m6a_encode_reads", "m6a_site_pool", "m6a_infer", "m6a_bag_forward", "m6a_validate_pool", "m6a_validate", "m6a_flush_groups",
            "m6a_reference_written_sites",
            "m6a_shard_plan", "m6a_comm_unique_id", "m6a_comm_init", "m6a_gather", "m6a_comm_destroy", "m6a_profile_enable", "m6a_profile_read", "m6a_last_pool_variant",
@@ -66,6 +66,7 @@ def load():
     L.m6a_last_error.restype = C.c_char_p
     L.m6a_set_stream.argtypes = [vp, vp]
     L.m6a_sync.argtypes = [vp]
+    L.m6a_set_host_offsets.argtypes = [vp, vp]
     L.m6a_prepare_host_io.argtypes = [vp]
     L.m6a_set_job_offset.argtypes = [vp, i64]
     L.m6a_set_scan_driver.argtypes = [vp, i32]

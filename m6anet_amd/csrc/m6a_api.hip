@@ -216,6 +216,9 @@ struct m6a_ctx {
     uint32_t *h_ctl = nullptr;                // [cursor HIST_BINS | slot_of_n 1025 | build_n 1024 | build_slot 1024]
     DevBuf ctl_dev, rt_rank, rt_order, reg_out;
     // ragged pooling prepared ahead of the encoder (m6a_infer): rank / order computed on a side stream
+    bool side_work = false;                   // something is queued on s_prep that the main stream does not wait for
+    const int64_t *hint_off = nullptr;        // m6a_set_host_offsets: host copy of the next device call's off[]
+    hipEvent_t ev_ctl = nullptr;              // the last upload from h_ctl (the host rewrites it per call)
     hipStream_t s_prep = nullptr;
     hipEvent_t ev_main = nullptr, ev_prep = nullptr;
     struct { bool ready = false, use = false; const int64_t *off = nullptr; int64_t S = 0, bs = 0, spb = 0; int T = 0, K = 0; uint32_t seed = 0; } prep;
@@ -707,6 +710,7 @@ int sync_and_check(m6a_ctx *c);
 // which blocks on the stream
 int query_bags(m6a_ctx *c, const int64_t *d_off, int64_t S)
 {
+    if (c->side_work) { HIPCHK(c, hipStreamSynchronize(c->s_prep)); c->side_work = false; }   // a pending check uses the same scratch
     c->h_minmax[0] = ~0ull; c->h_minmax[1] = 0ull; c->h_minmax[2] = 0ull;
     HIPCHK(c, hipMemcpyAsync(c->d_minmax, c->h_minmax, 24, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_hist, 0, M6A_HIST_BINS * 4, c->stream));
@@ -719,6 +723,38 @@ int query_bags(m6a_ctx *c, const int64_t *d_off, int64_t S)
     c->bag_min = (int64_t)c->h_minmax[0];
     c->bag_max = (int64_t)c->h_minmax[1];
     c->n_reads = (int64_t)c->h_minmax[2];
+    return M6A_OK;
+}
+
+// Device-pointer calls: bag statistics of d_off.  Default: query_bags (a read-back, blocks on the stream).  After
+// m6a_set_host_offsets the statistics come from the caller's host copy instead -- the loader that built the CSR array
+// has it -- and the device array is only CHECKED against them, asynchronously: the call does not block, consecutive
+// calls queue back to back, a mismatch surfaces as a deferred M6A_EINVAL at the next m6a_sync.
+int bag_stats(m6a_ctx *c, const int64_t *d_off, int64_t S)
+{
+    const int64_t *h = c->hint_off;
+    c->hint_off = nullptr;                                     // one call
+    if (!h) return query_bags(c, d_off, S);
+    if (h[0] != 0) return fail(c, M6A_EINVAL, "off[0] must be 0");
+    host_bag_range(c, h, S);
+    if (c->bag_min < 0) return fail(c, M6A_EINVAL, "off[] must be non-decreasing");
+    unsigned long long hash = 0;
+    for (int i = 0; i < M6A_HIST_BINS; i++) hash += (unsigned long long)c->h_hist[i] * m6a_bin_weight(i);
+    // the check runs on the side stream, next to the kernels of the call (it orders itself behind everything queued so far)
+    hipStream_t st = c->s_prep ? c->s_prep : c->stream;
+    if (st != c->stream) {
+        HIPCHK(c, hipEventRecord(c->ev_main, c->stream));
+        HIPCHK(c, hipStreamWaitEvent(st, c->ev_main, 0));
+    }
+    HIPCHK(c, hipMemsetAsync(c->d_minmax, 0xff, 8, st));
+    HIPCHK(c, hipMemsetAsync(c->d_minmax + 1, 0, 16, st));
+    HIPCHK(c, hipMemsetAsync(c->d_hist, 0, M6A_HIST_BINS * 4, st));
+    hipLaunchKernelGGL(bag_minmax_kernel, dim3((unsigned)std::min<int64_t>((S + 255) / 256, 512)), dim3(256), 0,
+                       st, d_off, S, c->d_minmax, c->d_hist);
+    hipLaunchKernelGGL(bag_verify_kernel, dim3(1), dim3(256), 0, st, c->d_minmax, c->d_hist, (unsigned long long)c->bag_min,
+                       (unsigned long long)c->bag_max, (unsigned long long)c->n_reads, hash, c->d_err);
+    HIPCHK(c, hipGetLastError());
+    c->side_work = true;                                       // m6a_sync also waits for the side stream
     return M6A_OK;
 }
 
@@ -801,6 +837,7 @@ int rtab_prepare(m6a_ctx *c, PoolArgs a, int64_t nmax, int64_t gmax, uint32_t se
     // The kernel gives XCD x the x-th eighth of this order, and a site's cost grows with its bag size:
     // sizes are dealt to the eighths by n mod 8, so every XCD gets the whole range of sizes and still owns the
     // tables of "its" sizes; largest first inside an eighth, so the longest sites do not start last.
+    HIPCHK(c, hipEventSynchronize(c->ev_ctl));                // the previous call's upload from h_ctl (calls need not block any more)
     uint32_t *cur = ctl_cursor(c);
     uint32_t run = 0;
     for (int x = 0; x < 8; x++)
@@ -814,6 +851,7 @@ int rtab_prepare(m6a_ctx *c, PoolArgs a, int64_t nmax, int64_t gmax, uint32_t se
         HIPCHK(c, hipStreamWaitEvent(stream, c->ev_main, 0));
     }
     HIPCHK(c, hipMemcpyAsync(c->ctl_dev.p, c->h_ctl, (size_t)(M6A_HIST_BINS + M6A_RTAB_MAX_N + 1) * 4, hipMemcpyHostToDevice, stream));
+    HIPCHK(c, hipEventRecord(c->ev_ctl, stream));
     const RtabUse u = rtab_use(c, nmax);
     const unsigned n_order_blocks = (unsigned)((S + 255) / 256);
     const unsigned n_chain_blocks = (unsigned)std::min<int64_t>((a.n_groups + 3) / 4, (int64_t)c->n_cu * 16);
@@ -1182,14 +1220,32 @@ Rccl *rccl()
 
 void host_bag_range(m6a_ctx *c, const int64_t *off, int64_t S)
 {
+    // pass 1, range only: a loop the compiler vectorises, memory-bound (0.2 ms per 1 M sites)
     int64_t mn = INT64_MAX, mx = 0;
-    std::memset(c->h_hist, 0, M6A_HIST_BINS * 4);
     for (int64_t s = 0; s < S; s++) {
         const int64_t n = off[s + 1] - off[s];
-        mn = std::min(mn, n); mx = std::max(mx, n);
-        c->h_hist[n < 0 ? 0 : n > M6A_RTAB_MAX_N ? M6A_RTAB_MAX_N + 1 : n]++;
+        mn = n < mn ? n : mn;
+        mx = n > mx ? n : mx;
     }
-    c->bag_min = mn; c->bag_max = mx; c->n_reads = off[S];
+    auto bin = [](int64_t n) { return n < 0 ? 0 : n > M6A_RTAB_MAX_N ? M6A_RTAB_MAX_N + 1 : n; };
+    std::memset(c->h_hist, 0, M6A_HIST_BINS * 4);
+    if (mn == mx || S == 0) {
+        if (S > 0) c->h_hist[bin(mn)] = (uint32_t)S;           // uniform bags: nothing to count
+    } else {
+        // pass 2: eight interleaved histograms, so that runs of equal bag sizes do not serialise on one counter
+        static thread_local uint32_t part[8][M6A_HIST_BINS];
+        std::memset(part, 0, sizeof part);
+        int64_t s = 0;
+        for (; s + 8 <= S; s += 8)
+            for (int k = 0; k < 8; k++) part[k][bin(off[s + k + 1] - off[s + k])]++;
+        for (; s < S; s++) part[0][bin(off[s + 1] - off[s])]++;
+        for (int i = 0; i < M6A_HIST_BINS; i++) {
+            uint32_t t = 0;
+            for (int k = 0; k < 8; k++) t += part[k][i];
+            c->h_hist[i] = t;
+        }
+    }
+    c->bag_min = S > 0 ? mn : 0; c->bag_max = mx; c->n_reads = off[S];
 }
 
 int check_pool_args(m6a_ctx *c, int64_t S, int T, int K, int rng_mode, int64_t bs, int64_t spb)
@@ -1211,6 +1267,7 @@ int deferred_error(m6a_ctx *c)
         const int e = *c->h_err;
         *c->h_err = 0;
         if (e == 2) return fail(c, M6A_EINVAL, "encoder: a 32-read tile spans more than 3 sites (bag < 16 reads) in the 12-slot kernel");
+        if (e == 3) return fail(c, M6A_EINVAL, "the host offsets given to m6a_set_host_offsets differ from the device off[] of the call");
         return fail(c, M6A_ESTREAM, "MT19937 stream too short for a flush group");
     }
     return M6A_OK;
@@ -1218,6 +1275,7 @@ int deferred_error(m6a_ctx *c)
 
 int sync_and_check(m6a_ctx *c)
 {
+    if (c->side_work) { HIPCHK(c, hipStreamSynchronize(c->s_prep)); c->side_work = false; }
     HIPCHK(c, hipMemcpyAsync(c->h_err, c->d_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (*c->h_err) {
@@ -1274,6 +1332,7 @@ int m6a_create(m6a_ctx **out, const float *weights, size_t n_floats, int device_
     CRCHK(hipStreamCreateWithFlags(&c->s_prep, hipStreamNonBlocking));
     CRCHK(hipEventCreateWithFlags(&c->ev_main, hipEventDisableTiming));
     CRCHK(hipEventCreateWithFlags(&c->ev_prep, hipEventDisableTiming));
+    CRCHK(hipEventCreateWithFlags(&c->ev_ctl, hipEventDisableTiming));
     c->stream = c->own_stream;
     std::vector<float> frag, frag2, w1e;
     build_fragments(weights, frag, frag2, w1e);
@@ -1331,6 +1390,7 @@ void m6a_destroy(m6a_ctx *c)
     if (c->s_prep) (void)hipStreamDestroy(c->s_prep);
     if (c->ev_main) (void)hipEventDestroy(c->ev_main);
     if (c->ev_prep) (void)hipEventDestroy(c->ev_prep);
+    if (c->ev_ctl) (void)hipEventDestroy(c->ev_ctl);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -1339,6 +1399,14 @@ int m6a_set_stream(m6a_ctx *c, void *hip_stream)
 {
     if (!c) return M6A_EINVAL;
     c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return M6A_OK;
+}
+
+int m6a_set_host_offsets(m6a_ctx *c, const int64_t *off_host)
+{
+    if (!c) return M6A_EINVAL;
+    if (off_host && is_device_ptr(off_host)) return fail(c, M6A_EINVAL, "m6a_set_host_offsets takes a host pointer");
+    c->hint_off = off_host;
     return M6A_OK;
 }
 
@@ -1413,7 +1481,7 @@ int m6a_encode_reads(m6a_ctx *c, const float *X, const uint8_t *km, const int64_
         return sync_and_check(c);
     }
     // device pointers: total reads (grid size) and smallest bag (kernel choice): one read-back
-    int rc = query_bags(c, off, S);
+    int rc = bag_stats(c, off, S);
     if (rc) return rc;
     return launch_encode(c, X, km, off, S, c->n_reads, rp);
 }
@@ -1430,7 +1498,7 @@ int m6a_site_pool(m6a_ctx *c, const float *rp, const int64_t *off, int64_t S, in
     if (dev != is_device_ptr(off) || dev != is_device_ptr(site) || dev != is_device_ptr(mod))
         return fail(c, M6A_EINVAL, "read_prob, off, site_prob, mod_ratio must be all host or all device pointers");
     if (dev) {
-        rc = query_bags(c, off, S);
+        rc = bag_stats(c, off, S);
         if (rc) return rc;
         return launch_pool(c, rp, off, S, T, K, thr, seed, bs, spb, site, mod);
     }
@@ -1465,7 +1533,7 @@ int m6a_infer(m6a_ctx *c, const float *X, const uint8_t *km, const int64_t *off,
         dev != is_device_ptr(mod) || (rp && dev != is_device_ptr(rp)))
         return fail(c, M6A_EINVAL, "all data pointers must be host pointers or all device pointers");
     if (dev) {
-        rc = query_bags(c, off, S);
+        rc = bag_stats(c, off, S);
         if (rc) return rc;
         const int64_t R = c->n_reads;
         float *p = rp;
@@ -1681,7 +1749,7 @@ int m6a_validate(m6a_ctx *c, const float *X, const uint8_t *km, const int64_t *o
         return fail(c, M6A_EINVAL, "X, site_kmers, off and the outputs must be all host or all device pointers");
     if (dev) {
         float *d_rp = rp;
-        rc = query_bags(c, off, S);
+        rc = bag_stats(c, off, S);
         if (rc) return rc;
         if (!d_rp) { HIPCHK(c, c->rp_scratch.ensure((size_t)std::max<int64_t>(c->n_reads, 1) * 4)); d_rp = (float *)c->rp_scratch.p; }
         rc = launch_encode(c, X, km, off, S, c->n_reads, d_rp);

@@ -16,6 +16,16 @@
 #define M6A_RTAB_U8_MAX_N 256     // ... tables of bags up to this size hold index bytes, larger ones u16 byte offsets
 #define M6A_HIST_BINS (M6A_RTAB_MAX_N + 2)   // bag-size histogram: n = 0..1024, last bin = larger
 
+// weight of histogram bin i in the hash bag_verify_kernel compares (splitmix64 finaliser: NOT linear in i -- a linear weight
+// would only re-check the total number of reads)
+__host__ __device__ inline unsigned long long m6a_bin_weight(int i)
+{
+    unsigned long long z = (unsigned long long)(i + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
 struct EncArgs {
     const float *X;               // [R][9]
     const uint8_t *site_kmers;    // [S][3]
@@ -95,6 +105,8 @@ __global__ void rebase_off_kernel(const int64_t *off, int64_t count, int64_t *ou
 __global__ void sampled_noisy_or_kernel(const float *read_prob, const int32_t *gidx, int64_t n_bags, int k, float *y);
 __global__ void mean_over_passes_kernel(const float *y, int n_iters, int64_t n_sites, float *avg);
 __global__ void bag_minmax_kernel(const int64_t *off, int64_t n_sites, unsigned long long *out, uint32_t *hist);
+__global__ void bag_verify_kernel(const unsigned long long *got, const uint32_t *hist, unsigned long long mn, unsigned long long mx,
+                                  unsigned long long reads, unsigned long long hash, int *err);
 __global__ void mt19937_kernel(uint32_t seed, int64_t n_words, uint32_t *raw);
 __global__ void rtab_count_kernel(RtabBuild a);
 __global__ void rtab_scan_kernel(RtabBuild a);

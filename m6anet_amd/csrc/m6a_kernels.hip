@@ -1161,3 +1161,20 @@ __global__ __launch_bounds__(256) void bag_minmax_kernel(const int64_t *off, int
         if (blockIdx.x == 0) out[2] = (unsigned long long)off[n_sites];
     }
 }
+
+// m6a_set_host_offsets: the host took the bag statistics from its own copy of off[]; this checks them against what
+// bag_minmax_kernel found in the device array (no read-back): range, total reads, and a hash of the bag-size histogram
+__global__ __launch_bounds__(256) void bag_verify_kernel(const unsigned long long *got, const uint32_t *hist, unsigned long long mn,
+                                                         unsigned long long mx, unsigned long long reads, unsigned long long hash, int *err)
+{
+    __shared__ unsigned long long s_part[256];
+    unsigned long long h = 0;
+    for (int i = threadIdx.x; i < M6A_HIST_BINS; i += 256) h += (unsigned long long)hist[i] * m6a_bin_weight(i);
+    s_part[threadIdx.x] = h;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < 256; i++) h += s_part[i];
+        if (got[0] != mn || got[1] != mx || got[2] != reads || h != hash) atomicExch(err, 3);
+    }
+}
+

@@ -160,6 +160,17 @@ class M6ANetEngine:
     def sync(self):
         self._chk(self._L.m6a_sync(self._h))
 
+    def set_host_offsets(self, off_host):
+        """For the NEXT call with device tensors: the host copy (numpy int64 [S+1]) of its CSR offsets.  The call then
+        takes the bag statistics from it, does not block on the stream, and only checks the device array against it
+        (a mismatch is reported by the next `sync()`).  include/m6a.h: m6a_set_host_offsets."""
+        if off_host is None:
+            self._chk(self._L.m6a_set_host_offsets(self._h, None))
+            return
+        a = np.ascontiguousarray(off_host, dtype=np.int64)
+        self._host_off_keepalive = a                      # read inside the next call
+        self._chk(self._L.m6a_set_host_offsets(self._h, a.ctypes.data))
+
     # -- the multi-GPU exchange on the library's own RCCL communicator (include/m6a.h: m6a_gather) --------
     def comm_init(self, unique_id, rank, world_size):
         """unique_id: the 128 bytes rank 0 got from `comm_unique_id()`, handed to every rank by the launcher."""

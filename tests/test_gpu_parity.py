@@ -747,6 +747,61 @@ def test_host_pointer_pipeline_matches_device_path(engines, orc, weights):
     assert np.allclose(rp2[sl], p, rtol=1e-5, atol=1e-8)
 
 
+def test_host_offsets_hint_same_results_and_no_stream_sync(engines):
+    """m6a_set_host_offsets: with the loader's host copy of off[] a device-pointer call takes the bag statistics from
+    it (checked on the device) instead of reading them back.  Results are bit-identical either way, for uniform and
+    ragged bags and for the separate encode / pool entry points; the hint is consumed by one call."""
+    import torch
+    eng = engines["hek293t_glori"]
+    dev = torch.device("cuda:0")
+    for bags in (20, (20, 90), (1, 40)):
+        d = synthetic.make_sites(3000, bags, seed=5)
+        tX, tk, to = (torch.from_numpy(d[k]).to(dev) for k in ("X", "site_kmers", "off"))
+        rp0, site0, mod0 = eng.infer(tX, tk, to, 100)
+        eng.sync()
+        want = [t.cpu().numpy() for t in (rp0, site0, mod0)]
+        for _ in range(3):                                          # back to back, no sync in between
+            eng.set_host_offsets(d["off"])
+            rp1, site1, mod1 = eng.infer(tX, tk, to, 100)
+        eng.sync()
+        for a, b in zip(want, (rp1, site1, mod1)):
+            assert np.array_equal(a, b.cpu().numpy(), equal_nan=True)
+        eng.set_host_offsets(d["off"])
+        rp2 = eng.get_read_probability(tX, tk, to)
+        eng.set_host_offsets(d["off"])
+        site2, mod2 = eng.calculate_site_proba(rp2, to, 100)
+        eng.sync()
+        assert np.array_equal(want[0], rp2.cpu().numpy()) and np.array_equal(want[1], site2.cpu().numpy(), equal_nan=True)
+        assert np.array_equal(want[2], mod2.cpu().numpy(), equal_nan=True)
+
+
+def test_host_offsets_hint_mismatch_is_reported(engines):
+    """A host copy that is not the device array: the call's results are undefined, the next sync says so, and the
+    context works normally afterwards."""
+    import torch
+    from m6anet_amd._lib import M6AError
+    eng = engines["hek293t_glori"]
+    dev = torch.device("cuda:0")
+    d = synthetic.make_sites(2000, (20, 60), seed=9)
+    tX, tk, to = (torch.from_numpy(d[k]).to(dev) for k in ("X", "site_kmers", "off"))
+    rp0, site0, mod0 = eng.infer(tX, tk, to, 50)
+    eng.sync()
+    wrong = d["off"].copy()
+    wrong[1000] += 1                                                # same range, same total, another histogram
+    assert wrong[1000] <= wrong[1001]
+    eng.set_host_offsets(wrong)
+    eng.infer(tX, tk, to, 50)
+    with pytest.raises(M6AError, match="m6a_set_host_offsets"):
+        eng.sync()
+    rp1, site1, mod1 = eng.infer(tX, tk, to, 50)                    # no hint: read back as before
+    eng.sync()
+    assert np.array_equal(site0.cpu().numpy(), site1.cpu().numpy()) and np.array_equal(mod0.cpu().numpy(), mod1.cpu().numpy())
+    eng.set_host_offsets(np.arange(1, len(d["off"]) + 1, dtype=np.int64))   # off[0] != 0: rejected by the call itself
+    with pytest.raises(M6AError, match="off"):
+        eng.infer(tX, tk, to, 50)
+    eng.sync()
+
+
 # ------------------------------------------------------------------ full size ------------------
 def test_full_size_properties(eng, orc, weights):
     """BASELINE.json configs[2] size (1M sites x 20 reads, T=1000): size-independent checks.
