@@ -178,7 +178,8 @@ int m6a_gather(m6a_ctx *ctx, const float *site_prob, const double *mod_ratio, co
 int m6a_comm_destroy(m6a_ctx *ctx);
 
 /* Per-kernel timing with HIP events on the context's stream (bench.py's live roofline).
- * kind: 0 = read encoder, 1 = site pooling.  m6a_profile_read synchronises the stream. */
+ * kind: 0 = read encoder, 1 = site pooling.  on: 0 off, 1 both kinds, 2 the encoder only, 3 the pooling only (two events per
+ * timed launch cost ~5 us each on the stream).  m6a_profile_read synchronises the stream. */
 int m6a_profile_enable(m6a_ctx *ctx, int on);
 int m6a_profile_read(m6a_ctx *ctx, int kind, double *total_ms, int64_t *n_launches);
 /* Tuning knob for the read encoder: 0 = auto (default), 1 = general kernel (16 K-slots, any bags),

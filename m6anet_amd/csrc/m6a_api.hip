@@ -47,6 +47,7 @@ constexpr int kMaxProfiled = 8192;
 
 struct Profiler {
     bool on = false;
+    int mask = 3;                             // bit 0: time the encoder launches, bit 1: the pooling launches
     std::vector<hipEvent_t> start[2], stop[2];
     int used[2] = {0, 0};
     int64_t dropped[2] = {0, 0};
@@ -686,7 +687,7 @@ int ensure_table_reg(m6a_ctx *c, uint32_t seed, int n, int T, int K, int jmax)
 void prof_begin(m6a_ctx *c, int kind)
 {
     Profiler &p = c->prof;
-    if (!p.on) return;
+    if (!p.on || !(p.mask >> kind & 1)) return;
     if (p.used[kind] >= kMaxProfiled) { p.dropped[kind]++; return; }
     if ((int)p.start[kind].size() <= p.used[kind]) {
         hipEvent_t a, b;
@@ -698,7 +699,7 @@ void prof_begin(m6a_ctx *c, int kind)
 void prof_end(m6a_ctx *c, int kind)
 {
     Profiler &p = c->prof;
-    if (!p.on || p.used[kind] >= kMaxProfiled) return;
+    if (!p.on || !(p.mask >> kind & 1) || p.used[kind] >= kMaxProfiled) return;
     (void)hipEventRecord(p.stop[kind][p.used[kind]], c->stream);
     p.used[kind]++;
 }
@@ -1896,6 +1897,7 @@ int m6a_profile_enable(m6a_ctx *c, int on)
 {
     if (!c) return M6A_EINVAL;
     c->prof.on = on != 0;
+    c->prof.mask = on == 2 ? 1 : on == 3 ? 2 : 3;
     c->prof.used[0] = c->prof.used[1] = 0;
     c->prof.dropped[0] = c->prof.dropped[1] = 0;
     return M6A_OK;

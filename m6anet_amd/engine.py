@@ -203,7 +203,8 @@ class M6ANetEngine:
         self._chk(self._L.m6a_prepare_host_io(self._h))
 
     def profile(self, on=True):
-        self._chk(self._L.m6a_profile_enable(self._h, 1 if on else 0))
+        """HIP-event timing of the launches: False off, True both kernels, 'encoder' / 'pooling' one kind."""
+        self._chk(self._L.m6a_profile_enable(self._h, {False: 0, True: 1, 'encoder': 2, 'pooling': 3}[on]))
 
     def profile_read(self, kind):
         ms, n = C.c_double(), C.c_int64()
