@@ -1268,6 +1268,7 @@ int deferred_error(m6a_ctx *c)
         const int e = *c->h_err;
         *c->h_err = 0;
         if (e == 2) return fail(c, M6A_EINVAL, "encoder: a 32-read tile spans more than 3 sites (bag < 16 reads) in the 12-slot kernel");
+        if (e == 4) return fail(c, M6A_EHIP, "pool_rtab_kernel: the dynamic LDS block does not start at offset 0");
         if (e == 3) return fail(c, M6A_EINVAL, "the host offsets given to m6a_set_host_offsets differ from the device off[] of the call");
         return fail(c, M6A_ESTREAM, "MT19937 stream too short for a flush group");
     }

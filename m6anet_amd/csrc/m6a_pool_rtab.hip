@@ -330,6 +330,8 @@ __global__ __launch_bounds__(256) void rtab_prep_kernel(PoolArgs a, RtabUse u, u
 //   MODE 0 / 1: u16 rows, rank even / odd;  MODE 2..5: byte rows, rank mod 4 = MODE - 2.
 // 4 * byte B of w in ONE instruction (the compiler's own choice is v_bfe_u32 + v_lshl_add_u32): an SDWA shift whose source
 // operand selects the byte.  SDWA takes no literal, the shift count rides in a register.
+#define RTAB_BAG_LDS ((16 + M6A_MEAN_STACK) * 4)     // byte offset of the bag in the kernel's LDS block: stage[8] | tail[8] | stack | bag
+
 template <int B>
 __device__ __forceinline__ uint32_t byte_times4(uint32_t w, uint32_t two)
 {
@@ -347,7 +349,11 @@ struct ByteGather {                                                     // draws
     static __device__ __forceinline__ void run(const Row &r, const char *bagb, uint32_t two, float (&g)[20])
     {
         constexpr int b = J + MODE - 2;
-        g[J] = *(const float *)(bagb + byte_times4<(b & 3)>(r.w[b >> 2], two));
+        // the bag sits at a compile-time LDS address (RTAB_BAG_LDS; the kernel checks it): as an address_space(3) access
+        // the constant goes into the instruction's offset field; through the generic `bagb + x` the compiler spends a
+        // v_add_u32 per draw on the (zero) base of the dynamic LDS block
+        typedef const __attribute__((address_space(3))) float lds_cfloat;
+        g[J] = *(lds_cfloat *)(uintptr_t)(byte_times4<(b & 3)>(r.w[b >> 2], two) + RTAB_BAG_LDS);
         ByteGather<MODE, J + 1>::run(r, bagb, two, g);
     }
 };
@@ -433,6 +439,9 @@ __global__ __launch_bounds__(64) void pool_rtab_kernel(PoolArgs a, RtabUse u)
     // address below is a compile-time offset): stage[8] leaf sums of a pass | tail[8] | merge stack | bag
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *stage = smem, *tail = smem + 8, *stack = smem + 16, *bag = smem + 16 + M6A_MEAN_STACK;
+    // the byte-row gathers address the bag by its absolute LDS offset: this kernel has no static LDS, so the dynamic
+    // block starts at 0 -- checked, not assumed
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)bag != RTAB_BAG_LDS) { if (threadIdx.x == 0) atomicExch(a.err, 4); return; }
     const int K = KT ? KT : a.K;
     const int lane = threadIdx.x;
     // blockIdx -> position in the bag-size order, XCD-aware: workgroups go round-robin over the 8 XCDs, so XCD x
