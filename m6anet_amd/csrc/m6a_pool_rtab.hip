@@ -259,6 +259,9 @@ __device__ __forceinline__ void rtab_chain_part(const PoolArgs &a, const RtabUse
             if (lane == 0) u.rank[s] = r;
             const uint32_t e = r + A - 1;                               // rank of the site's last draw
             // block b2 with RS[b2] <= e < RS[b2+1]: linear guess, then a 64-entry window of the directory
+            // (tried: guessing the window from p and the table's acceptance rate BEFORE r is known, so that its load
+            // travels with the two loads r needs -- two dependent round trips per site instead of three -- plus a
+            // look-ahead of bag size / slot / total three sites deep: 19 us slower per 125 k sites, 0.614 vs 0.595 ms)
             uint32_t b0 = (uint32_t)(((uint64_t)e * n_blk) / total);
             b0 = b0 > 32 ? b0 - 32 : 0;
             uint32_t b2, rs_b2;
