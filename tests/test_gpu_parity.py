@@ -747,6 +747,25 @@ def test_host_pointer_pipeline_matches_device_path(engines, orc, weights):
     assert np.allclose(rp2[sl], p, rtol=1e-5, atol=1e-8)
 
 
+def test_launch_timing_modes(engines):
+    """m6a_profile_enable: HIP events around the encoder launches, the pooling launches, or both (bench.py's live
+    roofline takes the encoder's inside the timed region and the pooling kernel's from extra steps)."""
+    import torch
+    eng = engines["hct116"]
+    dev = torch.device("cuda:0")
+    d = synthetic.make_sites(20000, 20, seed=3)
+    tX, tk, to = (torch.from_numpy(d[k]).to(dev) for k in ("X", "site_kmers", "off"))
+    for mode, want in ((True, (3, 3)), ("encoder", (3, 0)), ("pooling", (0, 3)), (False, (0, 0))):
+        eng.profile(mode)
+        for _ in range(3):
+            eng.infer(tX, tk, to, 100)
+        enc_ms, enc_n = eng.profile_read(0)
+        pool_ms, pool_n = eng.profile_read(1)
+        assert (enc_n, pool_n) == want
+        assert (enc_ms > 0) == (enc_n > 0) and (pool_ms > 0) == (pool_n > 0)
+    eng.profile(False)
+
+
 def test_host_offsets_hint_same_results_and_no_stream_sync(engines):
     """m6a_set_host_offsets: with the loader's host copy of off[] a device-pointer call takes the bag statistics from
     it (checked on the device) instead of reading them back.  Results are bit-identical either way, for uniform and
