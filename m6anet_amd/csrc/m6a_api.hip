@@ -216,7 +216,7 @@ struct m6a_ctx {
     uint32_t *h_hist = nullptr, *d_hist = nullptr;
     uint32_t *h_ctl = nullptr;                // [cursor HIST_BINS | slot_of_n 1025 | build_n 1024 | build_slot 1024]
     DevBuf ctl_dev, rt_rank, rt_order, reg_out;
-    // ragged pooling prepared ahead of the encoder (m6a_infer): rank / order computed on a side stream
+    // m6a_infer runs the pooling's set-up on a side stream next to the encoder (pool_setup_aside)
     bool side_work = false;                   // something is queued on s_prep that the main stream does not wait for
     const int64_t *hint_off = nullptr;        // m6a_set_host_offsets: host copy of the next device call's off[]
     hipEvent_t ev_ctl = nullptr;              // the last upload from h_ctl (the host rewrites it per call)
@@ -799,11 +799,11 @@ RtabUse rtab_use(m6a_ctx *c, int64_t nmax)
 }
 
 // Ragged bags, first half: decide whether this call pools through the per-bag-size index tables, build the ones
-// that are missing (on the context's stream) and launch the preparation -- every site's rank in its table and the
-// bag-size order -- on `stream`.  Needs only off[] and the histogram of query_bags / host_bag_range, not the read
-// probabilities, so m6a_infer runs it on a side stream next to the encoder (a latency chain on a few waves: 0.1 ms
-// that would otherwise sit between the two big kernels).  a: off, goff, n_groups, n_sites, T, K, err filled in.
-int rtab_prepare(m6a_ctx *c, PoolArgs a, int64_t nmax, int64_t gmax, uint32_t seed, hipStream_t stream, bool *use)
+// that are missing and launch the preparation -- every site's rank in its table and the bag-size order -- all on
+// the context's current stream.  Needs only off[] and the histogram of query_bags / host_bag_range, not the read
+// probabilities, so m6a_infer runs it on the side stream next to the encoder (pool_setup_aside; a latency chain on a
+// few waves: 0.1 ms that would otherwise sit between the two big kernels).  a: off, goff, n_groups, n_sites, T, K, err.
+int rtab_prepare(m6a_ctx *c, PoolArgs a, int64_t nmax, int64_t gmax, uint32_t seed, bool *use)
 {
     *use = false;
     const int T = a.T, K = a.K;
@@ -845,53 +845,25 @@ int rtab_prepare(m6a_ctx *c, PoolArgs a, int64_t nmax, int64_t gmax, uint32_t se
         for (int n = M6A_HIST_BINS - 1; n >= 0; n--)
             if ((n & 7) == x) { cur[n] = run; run += c->h_hist[n]; }
     std::memcpy(ctl_slot(c), c->rt.slot_of_n, sizeof c->rt.slot_of_n);
-    if (stream != c->stream) {
-        // everything queued so far (table builds, flush-group offsets, the previous call's pooling that still reads
-        // rank / order) comes first
-        HIPCHK(c, hipEventRecord(c->ev_main, c->stream));
-        HIPCHK(c, hipStreamWaitEvent(stream, c->ev_main, 0));
-    }
-    HIPCHK(c, hipMemcpyAsync(c->ctl_dev.p, c->h_ctl, (size_t)(M6A_HIST_BINS + M6A_RTAB_MAX_N + 1) * 4, hipMemcpyHostToDevice, stream));
-    HIPCHK(c, hipEventRecord(c->ev_ctl, stream));
+    HIPCHK(c, hipMemcpyAsync(c->ctl_dev.p, c->h_ctl, (size_t)(M6A_HIST_BINS + M6A_RTAB_MAX_N + 1) * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev_ctl, c->stream));
     const RtabUse u = rtab_use(c, nmax);
     const unsigned n_order_blocks = (unsigned)((S + 255) / 256);
     const unsigned n_chain_blocks = (unsigned)std::min<int64_t>((a.n_groups + 3) / 4, (int64_t)c->n_cu * 16);
-    hipLaunchKernelGGL(rtab_prep_kernel, dim3(n_order_blocks + n_chain_blocks), dim3(256), 0, stream, a, u,
+    hipLaunchKernelGGL(rtab_prep_kernel, dim3(n_order_blocks + n_chain_blocks), dim3(256), 0, c->stream, a, u,
                        (uint32_t *)c->ctl_dev.p, (uint32_t *)c->rt_order.p, n_order_blocks);
     HIPCHK(c, hipGetLastError());
-    if (stream != c->stream) HIPCHK(c, hipEventRecord(c->ev_prep, stream));
     *use = true;
     return M6A_OK;
 }
 
-// m6a_infer, device pointers: the ragged preparation goes to a side stream BEFORE the encoder is launched, so the
-// two overlap; launch_pool() for the same (off, S, ...) then only waits for its event.  Uniform bags have nothing
-// to prepare (their tables do not depend on the call).
-int pool_prepare_ahead(m6a_ctx *c, const int64_t *off, int64_t S, int T, int K, uint32_t seed, int64_t bs, int64_t spb)
-{
-    c->prep.ready = false;
-    if (S <= 0 || !c->s_prep) return M6A_OK;
-    int rc = ensure_groups(c, S, bs, spb);
-    if (rc) return rc;
-    const int64_t nmin = c->bag_min, nmax = c->bag_max, gmax = c->goff_key.gmax;
-    if (nmin < 0 || nmax > 0x7fffffff) return M6A_OK;        // launch_pool reports it
-    if (nmin == nmax && nmin >= 1 && nmin <= M6A_TABLE_MAX_N && K == 20 && gmax <= 4096) return M6A_OK;
-    PoolArgs a;
-    memset(&a, 0, sizeof a);
-    a.off = off; a.goff = (const int64_t *)c->goff.p; a.err = c->d_err;
-    a.n_groups = c->goff_key.G; a.n_sites = S; a.T = T; a.K = K;
-    bool use = false;
-    rc = rtab_prepare(c, a, nmax, gmax, seed, c->s_prep, &use);
-    if (rc) return rc;
-    c->prep.ready = true; c->prep.use = use;
-    c->prep.off = off; c->prep.S = S; c->prep.bs = bs; c->prep.spb = spb; c->prep.T = T; c->prep.K = K; c->prep.seed = seed;
-    return M6A_OK;
-}
-
+// dry: do everything the pooling of this call needs EXCEPT the pooling kernels -- flush-group offsets, the mean plan,
+// the MT19937 stream, index tables, and for ragged bags the rank / order preparation -- on the context's current stream.
+// m6a_infer runs it on the side stream while the encoder is busy (pool_setup_aside), then calls again for the kernels.
 int launch_pool(m6a_ctx *c, const float *rp, const int64_t *off, int64_t S, int T, int K, float thr,
-                uint32_t seed, int64_t bs, int64_t spb, float *site, double *mod)
+                uint32_t seed, int64_t bs, int64_t spb, float *site, double *mod, bool dry = false)
 {
-    // did m6a_infer already run the ragged preparation of exactly this call (pool_prepare_ahead)?  One-shot.
+    // did a dry run already do the ragged preparation of exactly this call?  One-shot.
     const bool prepared = c->prep.ready && c->prep.off == off && c->prep.S == S && c->prep.T == T && c->prep.K == K &&
                           c->prep.seed == seed && c->prep.bs == bs && c->prep.spb == spb;
     c->prep.ready = false;
@@ -918,13 +890,14 @@ int launch_pool(m6a_ctx *c, const float *rp, const int64_t *off, int64_t S, int 
         if (rc) return rc;
         plan_args(c, a);
         a.tab = (const uint32_t *)c->tab_reg.p; a.uniform_n = (int)nmin; a.jmax = (int)gmax;
+        a.reg_gpad = (a.n_groups + 63) / 64 * 64;
+        HIPCHK(c, c->reg_out.ensure((size_t)a.jmax * a.reg_gpad * 5));
+        if (dry) return M6A_OK;
         c->pool_variant = "table-reg";
         prof_begin(c, 1);
         // one wavefront = position j of 256 flush groups (4 sites per lane); blockIdx % jmax = j keeps a
         // position's index rows in one XCD's L2
         const int64_t wpj = (a.n_groups + 255) / 256;
-        a.reg_gpad = (a.n_groups + 63) / 64 * 64;
-        HIPCHK(c, c->reg_out.ensure((size_t)a.jmax * a.reg_gpad * 5));
         a.reg_site = (float *)c->reg_out.p;
         a.reg_cnt = (uint8_t *)c->reg_out.p + (size_t)a.jmax * a.reg_gpad * 4;
         hipLaunchKernelGGL(pool_reg_kernel, dim3((unsigned)(wpj * a.jmax)), dim3(64), 0, c->stream, a);
@@ -933,6 +906,7 @@ int launch_pool(m6a_ctx *c, const float *rp, const int64_t *off, int64_t S, int 
     } else if (uniform && c->plan.max_merge <= 15) {
         rc = ensure_table(c, seed, (int)nmin, T, K, (int)gmax);
         if (rc) return rc;
+        if (dry) return M6A_OK;
         plan_args(c, a);
         a.tab = (const uint32_t *)c->tab.p; a.uniform_n = (int)nmin; a.jmax = (int)gmax;
         // workgroups are bound to a position j: jmax x nbj of them, 5 resident per CU (LDS)
@@ -951,18 +925,27 @@ int launch_pool(m6a_ctx *c, const float *rp, const int64_t *off, int64_t S, int 
         // what 50 sites cost the scan kernels); otherwise the scan kernels replay the stream per site.
         const int64_t need = stream_need(gmax, T, K);
         bool use_rtab = false;
-        if (prepared) {
-            use_rtab = c->prep.use;                           // pool_prepare_ahead() decided (and, if so, built and launched)
+        if (prepared && !dry) {
+            use_rtab = c->prep.use;                           // the dry run decided (and, if so, built and launched)
         } else {
-            rc = rtab_prepare(c, a, nmax, gmax, seed, c->stream, &use_rtab);
+            rc = rtab_prepare(c, a, nmax, gmax, seed, &use_rtab);
             if (rc) return rc;
+        }
+        if (dry) {
+            c->prep.ready = true; c->prep.use = use_rtab;
+            c->prep.off = off; c->prep.S = S; c->prep.bs = bs; c->prep.spb = spb; c->prep.T = T; c->prep.K = K; c->prep.seed = seed;
+            if (!use_rtab) {                                  // the scan kernels' share of the set-up
+                rc = ensure_raw(c, seed, need);
+                if (rc) return rc;
+                HIPCHK(c, c->start_pos.ensure((size_t)S * sizeof(uint32_t)));
+            }
+            return M6A_OK;
         }
         if (use_rtab) {
             plan_args(c, a);
             a.raw = (const uint32_t *)c->raw.p; a.raw_len = c->raw_len;
             const RtabUse u = rtab_use(c, nmax);
             c->pool_variant = "ragged-table";
-            if (prepared) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_prep, 0));   // else it ran on this stream
             prof_begin(c, 1);
             const size_t lds = (size_t)(u.bag_cap + 16 + M6A_MEAN_STACK) * sizeof(float);
             const unsigned blocks = (unsigned)((S + 7) / 8 * 8);            // one wavefront (workgroup) per site
@@ -1218,6 +1201,26 @@ Rccl *rccl()
         const int e_ = (expr);                                                                          \
         if (e_ != 0) return fail((c), M6A_EHIP, "%s: %s", #expr, (R)->GetErrorString ? (R)->GetErrorString(e_) : "RCCL error"); \
     } while (0)
+
+// m6a_infer, device pointers, after the encoder has been launched: the pooling's set-up (a dry launch_pool) runs on the
+// side stream next to it -- in the steady state that is the ragged rank / order kernel (0.1 ms), in the first call the
+// MT19937 stream and the index tables as well (milliseconds, incl. host syncs that now wait for the side stream only).
+// The caller recorded ev_main on the context's stream BEFORE the encoder: the set-up orders itself behind everything
+// queued up to there (the previous call's pooling still reads what it rebuilds), not behind the encoder.
+int pool_setup_aside(m6a_ctx *c, const int64_t *off, int64_t S, int T, int K, uint32_t seed, int64_t bs, int64_t spb)
+{
+    c->prep.ready = false;
+    if (S <= 0 || !c->s_prep) return M6A_OK;
+    HIPCHK(c, hipStreamWaitEvent(c->s_prep, c->ev_main, 0));
+    hipStream_t main_stream = c->stream;
+    c->stream = c->s_prep;
+    const int rc = launch_pool(c, nullptr, off, S, T, K, 0.0f, seed, bs, spb, nullptr, nullptr, true);
+    c->stream = main_stream;
+    if (rc) { c->prep.ready = false; return rc; }
+    HIPCHK(c, hipEventRecord(c->ev_prep, c->s_prep));
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_prep, 0));
+    return M6A_OK;
+}
 
 void host_bag_range(m6a_ctx *c, const int64_t *off, int64_t S)
 {
@@ -1540,10 +1543,11 @@ int m6a_infer(m6a_ctx *c, const float *X, const uint8_t *km, const int64_t *off,
         const int64_t R = c->n_reads;
         float *p = rp;
         if (!p) { HIPCHK(c, c->rp_scratch.ensure((size_t)std::max<int64_t>(R, 1) * 4)); p = (float *)c->rp_scratch.p; }
-        rc = pool_prepare_ahead(c, off, S, T, K, seed, bs, spb);
-        if (rc) return rc;
+        HIPCHK(c, hipEventRecord(c->ev_main, c->stream));
         rc = launch_encode(c, X, km, off, S, R, p);
-        if (rc) { c->prep.ready = false; return rc; }
+        if (rc) return rc;
+        rc = pool_setup_aside(c, off, S, T, K, seed, bs, spb);
+        if (rc) return rc;
         return launch_pool(c, p, off, S, T, K, thr, seed, bs, spb, site, mod);
     }
     if (off[0] != 0) return fail(c, M6A_EINVAL, "off[0] must be 0");
