@@ -150,7 +150,7 @@ class M6ANetEngine:
         return self._L.m6a_last_encoder_variant(self._h).decode()
 
     def set_scan_driver(self, mode):
-        """0 auto, 1 one wavefront per flush group, 2 counting pass + one wavefront per site."""
+        """Ragged bags: 0 auto, 1 one wavefront per flush group, 2 counting pass + one wavefront per site, 3 index tables."""
         self._chk(self._L.m6a_set_scan_driver(self._h, int(mode)))
 
     def set_table_variant(self, mode):

@@ -747,6 +747,33 @@ def test_host_pointer_pipeline_matches_device_path(engines, orc, weights):
     assert np.allclose(rp2[sl], p, rtol=1e-5, atol=1e-8)
 
 
+def test_infer_equals_encode_then_pool_for_every_pooling_kernel(engines):
+    """m6a_infer sets the pooling up on a side stream while the encoder runs (a dry launch_pool); whatever kernel the
+    pooling takes -- forced scan drivers, index tables, both uniform-bag kernels -- the fused call must give what
+    m6a_encode_reads followed by m6a_site_pool gives, bit for bit, also when the kernel choice changes between calls."""
+    import torch
+    eng = engines["hek293t_glori"]
+    dev = torch.device("cuda:0")
+    try:
+        for bags, knobs in (((20, 120), [("scan", 1), ("scan", 2), ("scan", 3), ("scan", 0)]),
+                            (20, [("table", 1), ("table", 2), ("table", 0)])):
+            d = synthetic.make_sites(1500, bags, seed=21)
+            tX, tk, to = (torch.from_numpy(d[k]).to(dev) for k in ("X", "site_kmers", "off"))
+            for kind, v in knobs:
+                (eng.set_scan_driver if kind == "scan" else eng.set_table_variant)(v)
+                for T in (30, 64):
+                    rp, site, mod = eng.infer(tX, tk, to, T, seed=T)
+                    rp2 = eng.get_read_probability(tX, tk, to)
+                    site2, mod2 = eng.calculate_site_proba(rp2, to, T, seed=T)
+                    eng.sync()
+                    assert np.array_equal(rp.cpu().numpy(), rp2.cpu().numpy())
+                    assert np.array_equal(site.cpu().numpy(), site2.cpu().numpy())
+                    assert np.array_equal(mod.cpu().numpy(), mod2.cpu().numpy())
+    finally:
+        eng.set_scan_driver(0)
+        eng.set_table_variant(0)
+
+
 def test_launch_timing_modes(engines):
     """m6a_profile_enable: HIP events around the encoder launches, the pooling launches, or both (bench.py's live
     roofline takes the encoder's inside the timed region and the pooling kernel's from extra steps)."""
