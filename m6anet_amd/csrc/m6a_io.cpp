@@ -98,33 +98,51 @@ int parse_info(const std::string &dir, int rep, std::vector<SiteRef> &sites,
                std::unordered_map<std::string, size_t> *index)
 {
     const std::string path = dir + "/data.info";
-    FILE *f = fopen(path.c_str(), "r");
-    if (!f) return fail(M6A_IO_EIO, "cannot open %s", path.c_str());
-    char line[4096];
+    // the whole file in one read, rows split with memchr, integers with from_chars: fgets + sscanf took 0.1 s for the
+    // 141 k rows of a 900 MB dataset -- most of what the loader did NOT do in parallel
+    std::string text;
+    {
+        FILE *f = fopen(path.c_str(), "rb");
+        if (!f) return fail(M6A_IO_EIO, "cannot open %s", path.c_str());
+        char buf[1 << 16];
+        size_t k;
+        while ((k = fread(buf, 1, sizeof buf, f)) > 0) text.append(buf, k);
+        const bool bad = ferror(f) != 0;
+        fclose(f);
+        if (bad) return fail(M6A_IO_EIO, "cannot read %s", path.c_str());
+    }
+    const char *p = text.data(), *const end = p + text.size();
     bool first = true;
-    int rc = 0;
-    while (fgets(line, sizeof line, f)) {
+    sites.reserve(sites.size() + (size_t)std::count(p, end, '\n'));
+    while (p < end) {
+        const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+        const char *le = nl ? nl : end;                         // line = [p, le)
+        const char *next = nl ? nl + 1 : end;
         if (first) {          // header: transcript_id,transcript_position,start,end,n_reads
             first = false;
-            if (strncmp(line, "transcript_id,transcript_position,start,end,n_reads", 51) != 0) {
-                rc = fail(M6A_IO_EFORMAT, "%s: unexpected header", path.c_str());
-                break;
-            }
+            if (le - p < 51 || strncmp(p, "transcript_id,transcript_position,start,end,n_reads", 51) != 0)
+                return fail(M6A_IO_EFORMAT, "%s: unexpected header", path.c_str());
+            p = next;
             continue;
         }
-        char *c1 = strchr(line, ',');
-        if (!c1) continue;
-        std::string tx(line, c1 - line);
-        long long pos, start, end, n;
-        if (sscanf(c1 + 1, "%lld,%lld,%lld,%lld", &pos, &start, &end, &n) != 4) {
-            rc = fail(M6A_IO_EFORMAT, "%s: bad row '%s'", path.c_str(), line);
-            break;
+        const char *c1 = (const char *)memchr(p, ',', (size_t)(le - p));
+        if (!c1) { p = next; continue; }
+        long long v[4];
+        const char *q = c1 + 1;
+        bool ok = true;
+        for (int i = 0; i < 4 && ok; i++) {
+            const auto r = std::from_chars(q, le, v[i]);
+            ok = r.ec == std::errc() && (i == 3 || (r.ptr < le && *r.ptr == ','));
+            q = r.ptr + 1;
         }
+        if (!ok) return fail(M6A_IO_EFORMAT, "%s: bad row '%.*s'", path.c_str(), (int)std::min<ptrdiff_t>(le - p, 200), p);
+        const long long pos = v[0], start = v[1], end_b = v[2], n = v[3];
         size_t i;
         if (!index) {
             i = sites.size();
-            sites.push_back(SiteRef{tx, pos, 0, {}});
+            sites.push_back(SiteRef{std::string(p, c1 - p), pos, 0, {}});
         } else {
+            const std::string tx(p, c1 - p);
             const std::string key = tx + ":" + std::to_string(pos);
             auto it = index->find(key);
             if (it == index->end()) {
@@ -136,10 +154,10 @@ int parse_info(const std::string &dir, int rep, std::vector<SiteRef> &sites,
             }
         }
         sites[i].n_reads += n;
-        sites[i].parts.push_back(Part{rep, start, end});
+        sites[i].parts.push_back(Part{rep, start, end_b});
+        p = next;
     }
-    fclose(f);
-    return rc;
+    return 0;
 }
 
 // --- minimal JSON walker for one dataprep record: {"tx":{"pos":{"KMER":[[n,...],[n,...]]}}} -------
