@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <charconv>
+#include <chrono>
 #include <clocale>
 #include <cstdlib>
 #include <locale.h>
@@ -21,6 +22,7 @@
 #include <mutex>
 #include <set>
 #include <string>
+#include <string_view>
 #include <memory>
 #include <thread>
 #include <unordered_map>
@@ -86,21 +88,26 @@ const std::map<std::string, int> &vocab()
 }
 
 struct Part { int rep; int64_t start, end; };
+// one row of data.info.  `tx` points into the file's text (kept alive by the caller), and a site of a single input
+// directory keeps its one byte range inline: no heap allocation per row (three of them made the parse 0.4 us per row)
 struct SiteRef {
-    std::string tx;
+    std::string_view tx;
     int64_t pos;
     int64_t n_reads = 0;
-    std::vector<Part> parts;
+    Part one{-1, 0, 0};
+    std::vector<Part> more;              // replicates: one range per directory that has the site
+    const Part *parts_begin() const { return more.empty() ? &one : more.data(); }
+    size_t n_parts() const { return more.empty() ? (one.rep >= 0 ? 1 : 0) : more.size(); }
 };
 
 // `index` = nullptr for a single directory: every row is a new site, no union over replicates to build
 int parse_info(const std::string &dir, int rep, std::vector<SiteRef> &sites,
-               std::unordered_map<std::string, size_t> *index)
+               std::unordered_map<std::string, size_t> *index, std::string &text)
 {
     const std::string path = dir + "/data.info";
     // the whole file in one read, rows split with memchr, integers with from_chars: fgets + sscanf took 0.1 s for the
     // 141 k rows of a 900 MB dataset -- most of what the loader did NOT do in parallel
-    std::string text;
+    text.clear();                                           // the SiteRefs keep views into it
     {
         FILE *f = fopen(path.c_str(), "rb");
         if (!f) return fail(M6A_IO_EIO, "cannot open %s", path.c_str());
@@ -138,23 +145,23 @@ int parse_info(const std::string &dir, int rep, std::vector<SiteRef> &sites,
         if (!ok) return fail(M6A_IO_EFORMAT, "%s: bad row '%.*s'", path.c_str(), (int)std::min<ptrdiff_t>(le - p, 200), p);
         const long long pos = v[0], start = v[1], end_b = v[2], n = v[3];
         size_t i;
+        const std::string_view tx(p, (size_t)(c1 - p));
         if (!index) {
             i = sites.size();
-            sites.push_back(SiteRef{std::string(p, c1 - p), pos, 0, {}});
+            sites.push_back(SiteRef{tx, pos, 0, Part{rep, start, end_b}, {}});
         } else {
-            const std::string tx(p, c1 - p);
-            const std::string key = tx + ":" + std::to_string(pos);
+            const std::string key = std::string(tx) + ":" + std::to_string(pos);
             auto it = index->find(key);
             if (it == index->end()) {
                 i = sites.size();
                 index->emplace(key, i);
-                sites.push_back(SiteRef{tx, pos, 0, {}});
+                sites.push_back(SiteRef{tx, pos, 0, Part{-1, 0, 0}, {}});
             } else {
                 i = it->second;
             }
+            sites[i].more.push_back(Part{rep, start, end_b});
         }
         sites[i].n_reads += n;
-        sites[i].parts.push_back(Part{rep, start, end_b});
         p = next;
     }
     return 0;
@@ -375,6 +382,19 @@ inline int format_i64(long long v, char *buf)
     return (int)(std::to_chars(buf, buf + 24, v).ptr - buf);
 }
 
+// M6A_IO_TRACE=1: phase times of m6a_io_load_sites on stderr
+struct PhaseTrace {
+    bool on = getenv("M6A_IO_TRACE") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void mark(const char *what)
+    {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "m6a_io: %-28s %7.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
+        t = now;
+    }
+};
+
 int n_workers(int n_threads, int64_t items)
 {
     int n = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
@@ -396,6 +416,8 @@ int m6a_io_load_sites(const char *const *input_dirs, int n_dirs, int min_reads, 
     if (!input_dirs || n_dirs < 1) return fail(M6A_IO_EINVAL, "no input directory");
     if (n_norm < 0 || (n_norm > 0 && (!norm_kmers || !norm_mean || !norm_std))) return fail(M6A_IO_EINVAL, "bad normalisation arguments");
 
+    PhaseTrace trace;
+    std::vector<std::string> info_text((size_t)n_dirs);       // the data.info files: the SiteRefs point into them
     std::vector<SiteRef> all;
     std::unordered_map<std::string, size_t> index;
     std::vector<Mapped> json((size_t)n_dirs);
@@ -410,8 +432,10 @@ int m6a_io_load_sites(const char *const *input_dirs, int n_dirs, int min_reads, 
             }
         });
         int rc = 0;
-        for (int r = 0; r < n_dirs && !rc; r++) rc = parse_info(input_dirs[r], r, all, n_dirs > 1 ? &index : nullptr);
+        for (int r = 0; r < n_dirs && !rc; r++) rc = parse_info(input_dirs[r], r, all, n_dirs > 1 ? &index : nullptr, info_text[(size_t)r]);
+        trace.mark("data.info parsed");
         mapper.join();
+        trace.mark("data.json mapped (wait)");
         if (rc) return rc;
         if (map_rc) { g_err = map_err; return map_rc; }
     }
@@ -442,6 +466,7 @@ int m6a_io_load_sites(const char *const *input_dirs, int n_dirs, int min_reads, 
         return fail(M6A_IO_ENOMEM, "out of memory for %lld reads", (long long)R);
     }
 
+    trace.mark("filter, offsets, buffers");
     const int nw = n_workers(n_threads, S);
     std::vector<std::string> errs((size_t)nw);
     std::vector<int> rcs((size_t)nw, 0);
@@ -453,30 +478,32 @@ int m6a_io_load_sites(const char *const *input_dirs, int n_dirs, int min_reads, 
         int64_t s1 = (w == nw - 1) ? S : std::lower_bound(res->off.begin(), res->off.end() - 1, r_hi) - res->off.begin();
         for (int64_t s = s0; s < s1; s++) {
             const SiteRef &sr = sites[(size_t)s];
+            std::string tx(sr.tx);
             std::string kmer;
             int64_t row = res->off[(size_t)s];
-            for (const Part &pt : sr.parts) {
+            for (size_t ip = 0; ip < sr.n_parts(); ip++) {
+                const Part &pt = sr.parts_begin()[ip];
                 const Mapped &m = json[(size_t)pt.rep];
                 if (pt.start < 0 || pt.end > (int64_t)m.n || pt.start >= pt.end) {
-                    rcs[(size_t)w] = fail(M6A_IO_EFORMAT, "site %s:%lld: byte range outside data.json", sr.tx.c_str(), (long long)sr.pos);
+                    rcs[(size_t)w] = fail(M6A_IO_EFORMAT, "site %s:%lld: byte range outside data.json", tx.c_str(), (long long)sr.pos);
                     errs[(size_t)w] = g_err; return;
                 }
                 vals.clear();
                 std::string k;
                 int ncol = 0;
-                int rc = parse_record(m.p + pt.start, m.p + pt.end, sr.tx, sr.pos, k, vals, ncol);
+                int rc = parse_record(m.p + pt.start, m.p + pt.end, tx, sr.pos, k, vals, ncol);
                 if (rc) { rcs[(size_t)w] = rc; errs[(size_t)w] = g_err; return; }
                 if (kmer.empty()) kmer = k;
-                else if (kmer != k) { rcs[(size_t)w] = fail(M6A_IO_EFORMAT, "replicates disagree on the sequence of %s:%lld", sr.tx.c_str(), (long long)sr.pos); errs[(size_t)w] = g_err; return; }
+                else if (kmer != k) { rcs[(size_t)w] = fail(M6A_IO_EFORMAT, "replicates disagree on the sequence of %s:%lld", tx.c_str(), (long long)sr.pos); errs[(size_t)w] = g_err; return; }
                 if (kmer.size() != 7 || ncol != 10) {
                     // data prepared with n_neighbors != 1 (the reference's own slice for that case,
                     // data_utils.py:276-277, yields a 4-mer and fails too)
                     rcs[(size_t)w] = fail(M6A_IO_EFORMAT, "site %s:%lld: %zu-mer with %d columns; only dataprep n_neighbors=1 (7-mer, 10 columns) is supported",
-                                          sr.tx.c_str(), (long long)sr.pos, kmer.size(), ncol);
+                                          tx.c_str(), (long long)sr.pos, kmer.size(), ncol);
                     errs[(size_t)w] = g_err; return;
                 }
                 const int64_t nrow = (int64_t)vals.size() / 10;
-                if (row + nrow > res->off[(size_t)s + 1]) { rcs[(size_t)w] = fail(M6A_IO_EFORMAT, "site %s:%lld has more reads than data.info says", sr.tx.c_str(), (long long)sr.pos); errs[(size_t)w] = g_err; return; }
+                if (row + nrow > res->off[(size_t)s + 1]) { rcs[(size_t)w] = fail(M6A_IO_EFORMAT, "site %s:%lld has more reads than data.info says", tx.c_str(), (long long)sr.pos); errs[(size_t)w] = g_err; return; }
                 double mean[9], sd[9];
                 for (int c = 0; c < 3; c++) {
                     const std::string k5 = kmer.substr((size_t)c, 5);
@@ -495,14 +522,14 @@ int m6a_io_load_sites(const char *const *input_dirs, int n_dirs, int min_reads, 
                 }
                 row += nrow;
             }
-            if (row != res->off[(size_t)s + 1]) { rcs[(size_t)w] = fail(M6A_IO_EFORMAT, "site %s:%lld: data.info says %lld reads, data.json has %lld", sr.tx.c_str(), (long long)sr.pos, (long long)sr.n_reads, (long long)(row - res->off[(size_t)s])); errs[(size_t)w] = g_err; return; }
+            if (row != res->off[(size_t)s + 1]) { rcs[(size_t)w] = fail(M6A_IO_EFORMAT, "site %s:%lld: data.info says %lld reads, data.json has %lld", tx.c_str(), (long long)sr.pos, (long long)sr.n_reads, (long long)(row - res->off[(size_t)s])); errs[(size_t)w] = g_err; return; }
             for (int c = 0; c < 3; c++) {
                 auto it = vocab().find(kmer.substr((size_t)c, 5));
-                if (it == vocab().end()) { rcs[(size_t)w] = fail(M6A_IO_EFORMAT, "site %s:%lld: %s is not a DRACH context", sr.tx.c_str(), (long long)sr.pos, kmer.c_str()); errs[(size_t)w] = g_err; return; }
+                if (it == vocab().end()) { rcs[(size_t)w] = fail(M6A_IO_EFORMAT, "site %s:%lld: %s is not a DRACH context", tx.c_str(), (long long)sr.pos, kmer.c_str()); errs[(size_t)w] = g_err; return; }
                 res->site_kmers[(size_t)(3 * s + c)] = (uint8_t)it->second;
             }
             res->tx_pos[(size_t)s] = sr.pos;
-            res->tx_ids[(size_t)s] = sr.tx;
+            res->tx_ids[(size_t)s] = std::move(tx);
             res->kmer5[(size_t)s] = kmer.substr(1, 5);
         }
     };
@@ -510,6 +537,7 @@ int m6a_io_load_sites(const char *const *input_dirs, int n_dirs, int min_reads, 
     for (int w = 1; w < nw; w++) th.emplace_back(work, w);
     work(0);
     for (auto &t : th) t.join();
+    trace.mark("records parsed (workers)");
     for (int w = 0; w < nw; w++)
         if (rcs[(size_t)w]) { g_err = errs[(size_t)w]; delete res; return rcs[(size_t)w]; }
     res->view_owned();
