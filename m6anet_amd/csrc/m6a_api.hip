@@ -309,14 +309,14 @@ void build_fragments(const float *w, std::vector<float> &frag, std::vector<float
         for (int q = 0; q < 16; q++)
             frag[(120 + q) * 64 + lane] = w[O_W3 + (q & 3) + 8 * (q >> 2) + 4 * half];
     }
-    // 12-slot kernel: x-slot fragments W1'[u][st+4*half] (st<4), W1'[u][8]; and the per-unit rows the
+    // 12-slot kernel: x-slot fragments W1'[u][2st+half] (st<4), W1'[u][8]; and the per-unit rows the
     // per-site c vectors are folded from: W1'[u][9..14], b1'[u]  (w1 column 15 is the folded bias)
     frag2.assign(M6A_WFRAG2_FLOATS, 0.f);
     w1e.assign(M6A_W1E_FLOATS, 0.f);
     for (int lane = 0; lane < 64; lane++) {
         const int col = lane & 31, half = lane >> 5;
         for (int m = 0; m < 5; m++) {
-            for (int st = 0; st < 4; st++) frag2[(m * 4 + st) * 64 + lane] = w1[(32 * m + col) * 16 + st + 4 * half];   // K slot 2st+half <-> feature st + 4*half
+            for (int st = 0; st < 4; st++) frag2[(m * 4 + st) * 64 + lane] = w1[(32 * m + col) * 16 + 2 * st + half];
             frag2[(20 + m) * 64 + lane] = w1[(32 * m + col) * 16 + 8];
         }
     }
