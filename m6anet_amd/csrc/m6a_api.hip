@@ -214,6 +214,7 @@ struct m6a_ctx {
     // bag-size histogram of the last query_bags()/host_bag_range() (pinned; bins 0..1024, last = larger) and the
     // pinned staging of the small control arrays of the index-table path
     uint32_t *h_hist = nullptr, *d_hist = nullptr;
+    std::vector<uint32_t> hist_part;         // host_bag_range: eight interleaved histograms
     uint32_t *h_ctl = nullptr;                // [cursor HIST_BINS | slot_of_n 1025 | build_n 1024 | build_slot 1024]
     DevBuf ctl_dev, rt_rank, rt_order, reg_out;
     // m6a_infer runs the pooling's set-up on a side stream next to the encoder (pool_setup_aside)
@@ -788,13 +789,14 @@ int launch_encode(m6a_ctx *c, const float *X, const uint8_t *km, const int64_t *
     return M6A_OK;
 }
 
-RtabUse rtab_use(m6a_ctx *c, int64_t nmax)
+RtabUse rtab_use(m6a_ctx *c, int64_t nmax, uint32_t si_base = 0, uint32_t si_count = 0)
 {
     RtabUse u;
     u.C = c->rt.C; u.RS = c->rt.RS; u.slot_of_n = (const int32_t *)c->ctl_dev.p + M6A_HIST_BINS;
     u.rank = (uint32_t *)c->rt_rank.p; u.order = (const uint32_t *)c->rt_order.p;
     u.c_stride = c->rt.n_blk * 64; u.n_blk = (uint32_t)c->rt.n_blk;
     u.bag_cap = (int)std::max<int64_t>(64, (nmax + 63) / 64 * 64);
+    u.si_base = si_base; u.si_count = si_count;
     return u;
 }
 
@@ -809,7 +811,7 @@ int rtab_prepare(m6a_ctx *c, PoolArgs a, int64_t nmax, int64_t gmax, uint32_t se
     const int T = a.T, K = a.K;
     const int64_t S = a.n_sites;
     const int64_t need = stream_need(gmax, T, K);
-    // Default: per-bag-size index tables (pool_rtab_kernel) when every bag fits one (n <= 1024)
+    // Default: per-bag-size index tables (pool_rtab_kernel) when every bag fits one (n <= 4096)
     // and the work seen so far pays for the tables still lacking (a table = one pass over the stream, about
     // what 50 sites cost the scan kernels); otherwise the scan kernels replay the stream per site.
     if (nmax > M6A_RTAB_MAX_N || c->scan_driver == 1 || c->scan_driver == 2) {
@@ -839,11 +841,13 @@ int rtab_prepare(m6a_ctx *c, PoolArgs a, int64_t nmax, int64_t gmax, uint32_t se
     // sizes are dealt to the eighths by n mod 8, so every XCD gets the whole range of sizes and still owns the
     // tables of "its" sizes; largest first inside an eighth, so the longest sites do not start last.
     HIPCHK(c, hipEventSynchronize(c->ev_ctl));                // the previous call's upload from h_ctl (calls need not block any more)
+    // Bags above M6A_RTAB_SMALL_N reads come first, as a block of their own: launch_pool gives them a launch with the
+    // LDS bag they need (16 KB at 4 096 reads, nine sites per CU) and everybody else one with a small bag.
     uint32_t *cur = ctl_cursor(c);
     uint32_t run = 0;
+    for (int n = M6A_HIST_BINS - 1; n > M6A_RTAB_SMALL_N; n--) { cur[n] = run; run += c->h_hist[n]; }
     for (int x = 0; x < 8; x++)
-        for (int n = M6A_HIST_BINS - 1; n >= 0; n--)
-            if ((n & 7) == x) { cur[n] = run; run += c->h_hist[n]; }
+        for (int n = M6A_RTAB_SMALL_N - ((M6A_RTAB_SMALL_N - x) & 7); n >= 0; n -= 8) { cur[n] = run; run += c->h_hist[n]; }
     std::memcpy(ctl_slot(c), c->rt.slot_of_n, sizeof c->rt.slot_of_n);
     HIPCHK(c, hipMemcpyAsync(c->ctl_dev.p, c->h_ctl, (size_t)(M6A_HIST_BINS + M6A_RTAB_MAX_N + 1) * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipEventRecord(c->ev_ctl, c->stream));
@@ -920,7 +924,7 @@ int launch_pool(m6a_ctx *c, const float *rp, const int64_t *off, int64_t S, int 
         hipLaunchKernelGGL(pool_table_kernel, dim3(blocks), dim3(256), mean_lds, c->stream, a);
         prof_end(c, 1);
     } else {
-        // Ragged bags.  Default: per-bag-size index tables (pool_rtab_kernel) when every bag fits one (n <= 1024)
+        // Ragged bags.  Default: per-bag-size index tables (pool_rtab_kernel) when every bag fits one (n <= 4096)
         // and the work seen so far pays for the tables still lacking (a table = one pass over the stream, about
         // what 50 sites cost the scan kernels); otherwise the scan kernels replay the stream per site.
         const int64_t need = stream_need(gmax, T, K);
@@ -944,13 +948,21 @@ int launch_pool(m6a_ctx *c, const float *rp, const int64_t *off, int64_t S, int 
         if (use_rtab) {
             plan_args(c, a);
             a.raw = (const uint32_t *)c->raw.p; a.raw_len = c->raw_len;
-            const RtabUse u = rtab_use(c, nmax);
             c->pool_variant = "ragged-table";
+            // positions [0, n_big) of the bag-size order hold the bags above M6A_RTAB_SMALL_N reads (rtab_prepare)
+            int64_t n_big = 0;
+            for (int n = M6A_RTAB_SMALL_N + 1; n < M6A_HIST_BINS; n++) n_big += c->h_hist[n];
             prof_begin(c, 1);
-            const size_t lds = (size_t)(u.bag_cap + 16 + M6A_MEAN_STACK) * sizeof(float);
-            const unsigned blocks = (unsigned)((S + 7) / 8 * 8);            // one wavefront (workgroup) per site
-            if (K == 20) hipLaunchKernelGGL(pool_rtab_kernel<20>, dim3(blocks), dim3(64), lds, c->stream, a, u);
-            else hipLaunchKernelGGL(pool_rtab_kernel<0>, dim3(blocks), dim3(64), lds, c->stream, a, u);
+            auto launch = [&](int64_t base, int64_t count, int64_t cap_n) {
+                if (count <= 0) return;
+                const RtabUse u = rtab_use(c, cap_n, (uint32_t)base, (uint32_t)count);
+                const size_t lds = (size_t)(u.bag_cap + 16 + M6A_MEAN_STACK) * sizeof(float);
+                const unsigned blocks = (unsigned)((count + 7) / 8 * 8);    // one wavefront (workgroup) per site
+                if (K == 20) hipLaunchKernelGGL(pool_rtab_kernel<20>, dim3(blocks), dim3(64), lds, c->stream, a, u);
+                else hipLaunchKernelGGL(pool_rtab_kernel<0>, dim3(blocks), dim3(64), lds, c->stream, a, u);
+            };
+            launch(0, n_big, nmax);
+            launch(n_big, S - n_big, std::min<int64_t>(nmax, M6A_RTAB_SMALL_N));
             prof_end(c, 1);
             HIPCHK(c, hipGetLastError());
             return M6A_OK;
@@ -1237,8 +1249,8 @@ void host_bag_range(m6a_ctx *c, const int64_t *off, int64_t S)
         if (S > 0) c->h_hist[bin(mn)] = (uint32_t)S;           // uniform bags: nothing to count
     } else {
         // pass 2: eight interleaved histograms, so that runs of equal bag sizes do not serialise on one counter
-        static thread_local uint32_t part[8][M6A_HIST_BINS];
-        std::memset(part, 0, sizeof part);
+        c->hist_part.assign((size_t)8 * M6A_HIST_BINS, 0u);
+        uint32_t (*part)[M6A_HIST_BINS] = (uint32_t (*)[M6A_HIST_BINS])c->hist_part.data();
         int64_t s = 0;
         for (; s + 8 <= S; s += 8)
             for (int k = 0; k < 8; k++) part[k][bin(off[s + k + 1] - off[s + k])]++;

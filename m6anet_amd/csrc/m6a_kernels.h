@@ -12,7 +12,8 @@
 #define M6A_CSITE_MIN_BAG 16          // enc_csite_kernel: a 32-read tile must span <= 3 sites
 #define M6A_TABLE_MAX_N 32        // pool_table_kernel: byte offsets 8*idx must fit a byte; pool_reg_kernel: 32 register pairs
 #define M6A_REG_STACK 8           // pool_reg_kernel: merge stack entries held in registers
-#define M6A_RTAB_MAX_N 1024       // pool_rtab_kernel: bag sizes with an index table (LDS bag)
+#define M6A_RTAB_MAX_N 4096       // pool_rtab_kernel: bag sizes with an index table (LDS bag; u16 byte offsets reach 16 383 reads)
+#define M6A_RTAB_SMALL_N 1024     // ... bags above this get their own launch: their LDS bag would cost every site its occupancy
 #define M6A_RTAB_U8_MAX_N 256     // ... tables of bags up to this size hold index bytes, larger ones u16 byte offsets
 #define M6A_HIST_BINS (M6A_RTAB_MAX_N + 2)   // bag-size histogram: n = 0..1024, last bin = larger
 
@@ -89,6 +90,7 @@ struct RtabUse {
     int64_t c_stride;
     uint32_t n_blk;
     int bag_cap;                  // floats of LDS bag per wavefront
+    uint32_t si_base, si_count;   // this launch takes positions [si_base, si_base + si_count) of `order`
 };
 
 __global__ void enc_kernel(EncArgs a);

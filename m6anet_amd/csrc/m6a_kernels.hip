@@ -9,7 +9,7 @@
 //                      flush group finds where each site starts in the shared MT19937 word stream
 //                      (masked rejection), then one wavefront per site compacts its accepted draws
 //                      through LDS and multiplies the 20-term products; or one wavefront per group.
-//                      (Large ragged jobs with bags <= 1024 take pool_rtab_kernel, m6a_pool_rtab.hip,
+//                      (Large ragged jobs with bags <= 4096 take pool_rtab_kernel, m6a_pool_rtab.hip,
 //                      instead: per-bag-size index tables, no compaction at all.)
 //   pool_table_kernel  same result when every bag has the same size n <= 32: the accepted index
 //                      sequence is then identical in every flush group, so it is a precomputed table

@@ -453,8 +453,8 @@ __global__ __launch_bounds__(64) void pool_rtab_kernel(PoolArgs a, RtabUse u)
     // atomic work counter 1.58 ms, against 0.60 ms) -- the hardware dispatcher balances the workgroups better.
     const uint32_t chunk = gridDim.x >> 3;                 // gridDim.x is a multiple of 8
     const int64_t si = (int64_t)(blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
-    if (si >= a.n_sites) return;
-    const int64_t s = (int64_t)(uint32_t)uni((int)u.order[si]);
+    if (si >= (int64_t)u.si_count) return;
+    const int64_t s = (int64_t)(uint32_t)uni((int)u.order[(int64_t)u.si_base + si]);
     const int64_t r0 = uni64(a.off[s]);
     const int n = uni((int)(a.off[s + 1] - r0));
     const uint32_t rank = (uint32_t)uni((int)u.rank[s]);

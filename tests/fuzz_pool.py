@@ -37,9 +37,9 @@ def main():
         elif kind == 2:
             bags = g.integers(20, 700, size=S)
         elif kind == 3:
-            bags = g.choice([2, 3, 31, 32, 33, 63, 64, 65, 127, 128, 129, 255, 256, 257, 511, 512, 513, 1023, 1024], size=S)
+            bags = g.choice([2, 3, 31, 32, 33, 63, 64, 65, 127, 128, 129, 255, 256, 257, 511, 512, 513, 1023, 1024, 1025, 4095, 4096], size=S)
         elif kind == 4:
-            bags = np.where(g.random(S) < 0.05, g.integers(1025, 2500, size=S), g.integers(1, 200, size=S))
+            bags = np.where(g.random(S) < 0.05, g.integers(1025, 4500, size=S), g.integers(1, 200, size=S))
         else:
             bags = np.full(S, int(g.integers(33, 300)))
         T = int(g.choice([1, 2, 3, 7, 8, 9, 17, 33, 64, 100, 127, 129, 250, 257, 500, 1000, 1024, 1500, 3001]))
@@ -55,7 +55,7 @@ def main():
         want_site, want_mod = orc.site_pool(p, off, T, thr, seed=seed, batch_size=bs, save_per_batch=spb, n_samples=K, n_threads=8)
         uniform = bags.min() == bags.max() and bags.max() <= 32 and K == 20
         runs = [("table", 1, 0), ("table", 2, 0)] if uniform else [("scan", 0, 1), ("scan", 0, 2)]
-        if not uniform and bags.max() <= 1024:
+        if not uniform and bags.max() <= 4096:
             runs.append(("rtab", 0, 3))
         runs.append(("auto", 0, 0))
         n_cases += 1

@@ -214,7 +214,7 @@ def test_pool_uniform_table_vs_oracle(eng, orc, n, T):
 
 
 @pytest.mark.parametrize("bags", [
-    [33] * 40, [64] * 35, [65] * 33, [1000] * 3, [1024, 1025, 1500, 20], [20, 21] * 30,
+    [33] * 40, [64] * 35, [65] * 33, [1000] * 3, [1024, 1025, 1500, 20], [4096, 20, 4097, 30], [3000, 25] * 20 + [4096], [20, 21] * 30,
     [1, 2, 1, 20, 1, 40], list(range(20, 84)), [2048, 20, 4097],
     [0, 25, 0, 0, 1, 40, 0], [0] * 5 + [1024] + [0] * 3 + [2, 3] * 20,
 ])
@@ -226,7 +226,7 @@ def test_pool_scan_vs_oracle(eng, orc, bags):
             want_site, want_mod = orc.site_pool(p, off, T, THR, seed=11)
             for driver, name in ((1, "scan-group"), (2, "scan-site"), (3, "ragged-table"), (0, None)):
                 eng.set_scan_driver(driver)
-                if driver == 3 and max(bags) > 1024:          # index tables exist for bags of <= 1024 reads
+                if driver == 3 and max(bags) > 4096:          # index tables exist for bags of <= 4096 reads
                     with pytest.raises(Exception, match="M6A_EUNSUPPORTED"):
                         eng.calculate_site_proba(p, off, T, 20, THR, seed=11)
                     continue
@@ -373,7 +373,7 @@ def test_pool_ragged_random_configurations(eng, orc):
         want_site, want_mod = orc.site_pool(p, off, T, THR, seed=seed, batch_size=bs, save_per_batch=spb, n_threads=8)
         try:
             for driver in (1, 2, 3):
-                if driver == 3 and bags.max() > 1024:
+                if driver == 3 and bags.max() > 4096:
                     continue
                 eng.set_scan_driver(driver)
                 site, mod = eng.calculate_site_proba(p, off, T, 20, THR, seed=seed, batch_size=bs, save_per_batch=spb)
