@@ -187,15 +187,17 @@ int m6a_profile_read(m6a_ctx *ctx, int kind, double *total_ms, int64_t *n_launch
  * violates this reports M6A_EINVAL at the next sync).  Results agree to float32 rounding. */
 int m6a_set_encoder_variant(m6a_ctx *ctx, int mode);
 const char *m6a_last_encoder_variant(const m6a_ctx *ctx);   /* "general16" | "csite12" */
-/* Tuning knob for ragged bags: 0 = choose by available parallelism (default), 1 = one wavefront
- * per flush group, 2 = counting pass + one wavefront per site.  Results are identical. */
+/* Tuning knob for ragged bags: 0 = auto (default: per-bag-size index tables once the work seen pays for them, else
+ * the stream-replaying scan kernels, their driver chosen by the parallelism on offer), 1 = scan, one wavefront per
+ * flush group, 2 = scan, counting pass + one wavefront per site, 3 = index tables always (M6A_EUNSUPPORTED if a bag
+ * exceeds 4096 reads).  Results are identical. */
 int m6a_set_scan_driver(m6a_ctx *ctx, int mode);
 /* Tuning knob for uniform bags (n <= 32, n_samples = 20): 0 = auto (default: the register kernel
  * where it applies), 1 = LDS-gather kernel, 2 = register kernel (bags in VGPRs, draws through the
  * VGPR index mode).  Results are identical. */
 int m6a_set_table_variant(m6a_ctx *ctx, int mode);
 /* pooling kernel variant used by the last pool/infer call:
- * "table-reg" | "table" | "scan-group" | "scan-site" */
+ * "table-reg" | "table" (uniform bags) | "ragged-table" | "scan-group" | "scan-site" (ragged bags) */
 const char *m6a_last_pool_variant(const m6a_ctx *ctx);
 
 const char *m6a_version(void);

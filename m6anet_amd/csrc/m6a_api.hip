@@ -211,11 +211,11 @@ struct m6a_ctx {
     unsigned long long *d_minmax = nullptr;
     unsigned long long *h_minmax = nullptr;   // pinned
     int *h_err = nullptr;                     // pinned
-    // bag-size histogram of the last query_bags()/host_bag_range() (pinned; bins 0..1024, last = larger) and the
+    // bag-size histogram of the last query_bags()/host_bag_range() (pinned; bins 0..M6A_RTAB_MAX_N, last = larger) and the
     // pinned staging of the small control arrays of the index-table path
     uint32_t *h_hist = nullptr, *d_hist = nullptr;
     std::vector<uint32_t> hist_part;         // host_bag_range: eight interleaved histograms
-    uint32_t *h_ctl = nullptr;                // [cursor HIST_BINS | slot_of_n 1025 | build_n 1024 | build_slot 1024]
+    uint32_t *h_ctl = nullptr;                // [cursor HIST_BINS | slot_of_n MAX_N+1 | build_n MAX_N | build_slot MAX_N]
     DevBuf ctl_dev, rt_rank, rt_order, reg_out;
     // m6a_infer runs the pooling's set-up on a side stream next to the encoder (pool_setup_aside)
     bool side_work = false;                   // something is queued on s_prep that the main stream does not wait for
@@ -565,7 +565,7 @@ int32_t *ctl_build_n(m6a_ctx *c) { return ctl_slot(c) + M6A_RTAB_MAX_N + 1; }
 int32_t *ctl_build_slot(m6a_ctx *c) { return ctl_build_n(c) + M6A_RTAB_MAX_N; }
 constexpr size_t kCtlWords = M6A_HIST_BINS + (M6A_RTAB_MAX_N + 1) + 2 * M6A_RTAB_MAX_N;
 
-// bag sizes (2..1024) of `hist` that have no table yet for (seed, T*K, a stream of >= need words)
+// bag sizes (2..M6A_RTAB_MAX_N) of `hist` that have no table yet for (seed, T*K, a stream of >= need words)
 int rtab_missing(const m6a_ctx *c, uint32_t seed, int T, int K, int64_t need, const uint32_t *hist, int *n_distinct)
 {
     const bool valid = c->rt.valid && c->rt.seed == seed && c->rt.A == (int64_t)T * K && c->raw_seed == seed &&
@@ -660,6 +660,7 @@ int ensure_table_reg(m6a_ctx *c, uint32_t seed, int n, int T, int K, int jmax)
 {
     auto &k = c->tab_reg_key;
     if (k.valid && k.seed == seed && k.n == n && k.T == T && k.K == K && k.jmax >= jmax) return M6A_OK;
+    k.valid = false;                                       // the table is rewritten below: a failure must not leave the old key standing
     const size_t per_j = (size_t)(T + 8) * K;              // K = 20: a multiple of 4 bytes
     const size_t bytes = (size_t)jmax * per_j + 256;
     HIPCHK(c, c->tab_reg.ensure(bytes));
@@ -1264,6 +1265,15 @@ void host_bag_range(m6a_ctx *c, const int64_t *off, int64_t S)
     c->bag_min = S > 0 ? mn : 0; c->bag_max = mx; c->n_reads = off[S];
 }
 
+// m6a_set_host_offsets is one-shot: whichever entry point runs next consumes the hint -- on its device-pointer branch
+// through bag_stats, on every other path (host pointers, argument errors) by leaving this scope.  A pointer that stayed
+// armed would describe some later call's off[] wrongly (or point at memory the caller has freed by then).
+struct HintScope {
+    m6a_ctx *c;
+    explicit HintScope(m6a_ctx *ctx) : c(ctx) {}
+    ~HintScope() { if (c) c->hint_off = nullptr; }
+};
+
 int check_pool_args(m6a_ctx *c, int64_t S, int T, int K, int rng_mode, int64_t bs, int64_t spb)
 {
     if (!c) return M6A_EINVAL;
@@ -1477,6 +1487,7 @@ int m6a_prepare_host_io(m6a_ctx *c)
 
 int m6a_encode_reads(m6a_ctx *c, const float *X, const uint8_t *km, const int64_t *off, int64_t S, float *rp)
 {
+    HintScope hint_scope(c);
     if (!c) return M6A_EINVAL;
     if (S < 0) return fail(c, M6A_EINVAL, "n_sites < 0");
     if (S == 0) return M6A_OK;
@@ -1506,6 +1517,7 @@ int m6a_encode_reads(m6a_ctx *c, const float *X, const uint8_t *km, const int64_
 int m6a_site_pool(m6a_ctx *c, const float *rp, const int64_t *off, int64_t S, int T, int K, float thr,
                   uint32_t seed, int rng_mode, int64_t bs, int64_t spb, float *site, double *mod)
 {
+    HintScope hint_scope(c);
     int rc = check_pool_args(c, S, T, K, rng_mode, bs, spb);
     if (rc) return rc;
     if (S == 0) return M6A_OK;
@@ -1540,6 +1552,7 @@ int m6a_site_pool(m6a_ctx *c, const float *rp, const int64_t *off, int64_t S, in
 int m6a_infer(m6a_ctx *c, const float *X, const uint8_t *km, const int64_t *off, int64_t S, int T, int K,
               float thr, uint32_t seed, int rng_mode, int64_t bs, int64_t spb, float *rp, float *site, double *mod)
 {
+    HintScope hint_scope(c);
     int rc = check_pool_args(c, S, T, K, rng_mode, bs, spb);
     if (rc) return rc;
     if (S == 0) return M6A_OK;
@@ -1582,6 +1595,7 @@ int m6a_infer(m6a_ctx *c, const float *X, const uint8_t *km, const int64_t *off,
 
 int m6a_bag_forward(m6a_ctx *c, const float *X, const uint8_t *km, int64_t B, int bag, float *site)
 {
+    HintScope hint_scope(c);
     if (!c) return M6A_EINVAL;
     if (B < 0 || bag < 1) return fail(c, M6A_EINVAL, "n_bags must be >= 0 and bag >= 1");
     if (B == 0) return M6A_OK;
@@ -1722,6 +1736,7 @@ int check_validate_args(m6a_ctx *c, int64_t S, int T, int K)
 int m6a_validate_pool(m6a_ctx *c, const float *rp, const int64_t *off, int64_t S, int T, int K, uint32_t seed,
                       float *y, float *avg)
 {
+    HintScope hint_scope(c);
     int rc = check_validate_args(c, S, T, K);
     if (rc) return rc;
     if (S == 0) return M6A_OK;
@@ -1756,6 +1771,7 @@ int m6a_validate_pool(m6a_ctx *c, const float *rp, const int64_t *off, int64_t S
 int m6a_validate(m6a_ctx *c, const float *X, const uint8_t *km, const int64_t *off, int64_t S, int T, int K,
                  uint32_t seed, float *rp, float *y, float *avg)
 {
+    HintScope hint_scope(c);
     int rc = check_validate_args(c, S, T, K);
     if (rc) return rc;
     if (S == 0) return M6A_OK;
@@ -1875,8 +1891,9 @@ int m6a_comm_destroy(m6a_ctx *c)
     Rccl *R = rccl();
     HIPCHK(c, hipSetDevice(c->device));
     (void)hipStreamSynchronize(c->stream);
-    RCCLCHK(c, R, R->CommDestroy(c->comm));
-    c->comm = nullptr; c->comm_world = 0;
+    void *comm = c->comm;
+    c->comm = nullptr; c->comm_world = 0;                  // whatever CommDestroy says: m6a_destroy must not destroy it again
+    RCCLCHK(c, R, R->CommDestroy(comm));
     return M6A_OK;
 }
 
@@ -1893,20 +1910,26 @@ int m6a_gather(m6a_ctx *c, const float *site, const double *mod, const int64_t *
     Rccl *R = rccl();
     HIPCHK(c, hipSetDevice(c->device));
     // one grouped exchange: every rank (dst included) sends its two arrays, dst posts the matching receives at the
-    // shards' offsets -- direct peer-to-peer writes over xGMI, no ring, no padding
+    // shards' offsets -- direct peer-to-peer writes over xGMI, no ring, no padding.  A failing Send/Recv must not leave
+    // the thread's RCCL group open (every later RCCL call of the thread would queue into it): remember the first
+    // error, always close the group.
     RCCLCHK(c, R, R->GroupStart());
-    if (mine > 0) {
-        RCCLCHK(c, R, R->Send(site, (size_t)mine, 7 /* ncclFloat32 */, dst, c->comm, c->stream));
-        RCCLCHK(c, R, R->Send(mod, (size_t)mine, 8 /* ncclFloat64 */, dst, c->comm, c->stream));
-    }
+    int first = 0;
+    const char *what = "";
+    auto op = [&](int e, const char *w) { if (e != 0 && first == 0) { first = e; what = w; } return first == 0; };
+    if (mine > 0)
+        (void)(op(R->Send(site, (size_t)mine, 7 /* ncclFloat32 */, dst, c->comm, c->stream), "ncclSend(site_prob)") &&
+               op(R->Send(mod, (size_t)mine, 8 /* ncclFloat64 */, dst, c->comm, c->stream), "ncclSend(mod_ratio)"));
     if (me == dst)
-        for (int r = 0; r < W; r++) {
+        for (int r = 0; r < W && first == 0; r++) {
             const int64_t n = cuts[r + 1] - cuts[r];
             if (n <= 0) continue;
-            RCCLCHK(c, R, R->Recv(site_all + (cuts[r] - cuts[0]), (size_t)n, 7, r, c->comm, c->stream));
-            RCCLCHK(c, R, R->Recv(mod_all + (cuts[r] - cuts[0]), (size_t)n, 8, r, c->comm, c->stream));
+            (void)(op(R->Recv(site_all + (cuts[r] - cuts[0]), (size_t)n, 7, r, c->comm, c->stream), "ncclRecv(site_prob)") &&
+                   op(R->Recv(mod_all + (cuts[r] - cuts[0]), (size_t)n, 8, r, c->comm, c->stream), "ncclRecv(mod_ratio)"));
         }
-    RCCLCHK(c, R, R->GroupEnd());
+    const int e_end = R->GroupEnd();
+    if (first != 0) return fail(c, M6A_EHIP, "%s: %s", what, R->GetErrorString ? R->GetErrorString(first) : "RCCL error");
+    if (e_end != 0) return fail(c, M6A_EHIP, "ncclGroupEnd: %s", R->GetErrorString ? R->GetErrorString(e_end) : "RCCL error");
     return M6A_OK;
 }
 

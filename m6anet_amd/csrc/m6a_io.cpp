@@ -23,6 +23,7 @@
 #include <set>
 #include <string>
 #include <string_view>
+#include <limits>
 #include <memory>
 #include <thread>
 #include <unordered_map>
@@ -188,13 +189,24 @@ struct Cursor {
     // threads -- so: Clinger's exact fast path for <= 15 significant digits and |exp10| <= 22,
     // glibc strtod_l on a cached "C" locale for everything else -- on a NUL-terminated copy of the
     // token: the mapped file is not NUL-terminated, and only [0-9+-.eE] is a JSON / eventalign number
-    // (strtod alone would also take "inf", "nan" and hex floats).)
+    // (strtod alone would also take "inf", "nan" and hex floats); NaN / Infinity / -Infinity, which Python's
+    // json module reads and writes, are recognised by name.)
     bool num(double &v)
     {
         ws();
         const char *q = p;
         bool neg = false;
         if (q < e && (*q == '-' || *q == '+')) { neg = *q == '-'; ++q; }
+        // the three non-finite literals Python's json.loads takes (and json.dumps writes): NaN, Infinity, -Infinity
+        if (q < e && (*q == 'N' || *q == 'I')) {
+            if (e - q >= 3 && std::memcmp(q, "NaN", 3) == 0 && q == p) { v = std::numeric_limits<double>::quiet_NaN(); p = q + 3; return true; }
+            if (e - q >= 8 && std::memcmp(q, "Infinity", 8) == 0 && (q == p || neg)) {
+                v = neg ? -std::numeric_limits<double>::infinity() : std::numeric_limits<double>::infinity();
+                p = q + 8;
+                return true;
+            }
+            return false;
+        }
         uint64_t mant = 0;
         int nd = 0, frac = 0;
         bool dot = false, any = false;
@@ -664,6 +676,9 @@ int m6a_io_open_store(const char *path, m6a_sites **out)
     bool good = s->vOff[0] == 0 && s->vOff[h.S] == h.R && txo[0] == 0 && txo[h.S] == h.tx_bytes;
     for (int64_t i = 0; good && i < h.S; i++) good = s->vOff[i + 1] >= s->vOff[i] && txo[i + 1] >= txo[i];
     if (!good) { delete s; return fail(M6A_IO_EFORMAT, "%s: inconsistent offsets", path); }
+    // k-mer ids index the encoder's 66-row embedding table on the GPU: a corrupt byte must not get that far
+    for (int64_t i = 0; good && i < 3 * h.S; i++) good = s->vK[i] < 66;
+    if (!good) { delete s; return fail(M6A_IO_EFORMAT, "%s: k-mer id out of range (vocabulary has 66 entries)", path); }
     s->tx_ids.resize((size_t)h.S); s->kmer5.resize((size_t)h.S);
     for (int64_t i = 0; i < h.S; i++) {
         s->tx_ids[(size_t)i].assign(b + l.txb + txo[i], (size_t)(txo[i + 1] - txo[i]));

@@ -15,7 +15,7 @@
 #define M6A_RTAB_MAX_N 4096       // pool_rtab_kernel: bag sizes with an index table (LDS bag; u16 byte offsets reach 16 383 reads)
 #define M6A_RTAB_SMALL_N 1024     // ... bags above this get their own launch: their LDS bag would cost every site its occupancy
 #define M6A_RTAB_U8_MAX_N 256     // ... tables of bags up to this size hold index bytes, larger ones u16 byte offsets
-#define M6A_HIST_BINS (M6A_RTAB_MAX_N + 2)   // bag-size histogram: n = 0..1024, last bin = larger
+#define M6A_HIST_BINS (M6A_RTAB_MAX_N + 2)   // bag-size histogram: n = 0..M6A_RTAB_MAX_N, last bin = larger
 
 // weight of histogram bin i in the hash bag_verify_kernel compares (splitmix64 finaliser: NOT linear in i -- a linear weight
 // would only re-check the total number of reads)

@@ -8,8 +8,9 @@
 // v[base + M0].  No LDS gather at all: the inner loop is 1-2 SALU + 2 VALU per draw of 4 sites
 // (v_pk_mul_f32 advances two sites), against 5 VALU + 4.25 LDS instructions per draw of 8 sites in
 // the LDS kernel, whose floor is the LDS pipe (0.57 ms per 1 M sites x T=1000, 0.93 ms measured).
-// This one is bound by VALU issue: an indexed v_pk_mul_f32 issues every ~6 cycles per wavefront
-// (tools/gpr_index_bench.hip), i.e. ~0.43 ms; measured 0.50 ms.
+// This one is bound by VALU issue: a v_pk_mul_f32 costs ~7 cycles per wavefront on this part, indexed or
+// not (tools/gpr_variants_gen.py, profiles/r02_gpr_variants.txt): 14 cycles per draw of 4 sites, 0.445 ms
+// per 1 M sites x T=1000 measured.
 //
 // The compiler cannot express "this instruction's source register is v[128 + M0]" and has no
 // register class beyond 32 dwords, so the core is one hand-written assembly block with its own

@@ -311,7 +311,7 @@ __device__ __forceinline__ void rtab_order_part(const int64_t *off, int64_t n_si
 
 // One launch for both preparations of a call -- they are independent, the chain walk is a latency chain on few
 // waves and the ordering a burst of atomics, so they overlap: workgroups [0, n_order_blocks) order the sites, the
-// rest walk the flush groups.  Also zeroes the consumer's per-XCD work counters.
+// rest walk the flush groups.
 __global__ __launch_bounds__(256) void rtab_prep_kernel(PoolArgs a, RtabUse u, uint32_t *cursor, uint32_t *order, unsigned n_order_blocks)
 {
     if (blockIdx.x < n_order_blocks) {

@@ -90,10 +90,25 @@ def load_sites_native(input_dirs, min_reads=DEFAULT_MIN_READS, norm_path=None, n
 STORE_SUFFIX = ".m6astore"
 
 
+def norm_digest(norm):
+    """Content hash of a set of normalisation factors (dict kmer -> (mean[3], std[3]), or None): what a binary site
+    store's header records, so that two different files with the same name cannot be confused."""
+    import hashlib
+    if not norm:
+        return "none"
+    h = hashlib.sha256()
+    for k in sorted(norm):
+        h.update(k.encode())
+        h.update(np.ascontiguousarray(norm[k][0], np.float64).tobytes())
+        h.update(np.ascontiguousarray(norm[k][1], np.float64).tobytes())
+    return h.hexdigest()[:24]
+
+
 def store_tag(norm_path, min_reads=DEFAULT_MIN_READS):
     """What a binary site store was built with (it holds NORMALISED features of the sites that passed the
-    read-count filter): checked when the store is opened for a model."""
-    return "%s min_reads=%d" % (os.path.basename(str(norm_path)), min_reads)
+    read-count filter): the content hash of the normalisation factors -- "none" for un-normalised features, which is
+    what the reference feeds when --norm_path is absent -- and the filter.  Checked whenever the store is opened."""
+    return "norm=%s min_reads=%d" % (norm_digest(load_norm_factors(norm_path)), min_reads)
 
 
 def pack_sites(input_dirs, out_path, min_reads=DEFAULT_MIN_READS, norm_path=None, n_threads=0):
@@ -109,12 +124,15 @@ def pack_sites(input_dirs, out_path, min_reads=DEFAULT_MIN_READS, norm_path=None
 
 def open_store(path, norm_path=None, min_reads=DEFAULT_MIN_READS):
     """Maps a binary site store (zero-copy views into the page cache).  Refuses a store that was normalised with
-    other factors / another read-count filter than the ones asked for."""
+    other factors / another read-count filter than this run's: norm_path=None means the run expects UN-normalised
+    features (the reference's behaviour without --norm_path), so a normalised store is refused then too."""
     from . import _io
     nat = _io.NativeSites(store=path)
-    if norm_path is not None and nat.tag != store_tag(norm_path, min_reads):
-        raise ValueError("%s was packed with '%s', this run needs '%s': re-run `m6anet_amd pack`"
-                         % (path, nat.tag, store_tag(norm_path, min_reads)))
+    want = store_tag(norm_path, min_reads)
+    if nat.tag != want:
+        nat.close()
+        raise ValueError("%s was packed with '%s', this run needs '%s' (normalisation factors %s): re-run `m6anet_amd pack`"
+                         % (path, nat.tag, want, norm_path))
     return SiteBatch(nat.X, nat.site_kmers, nat.off, None, nat.tx_pos, None, None, native=nat)
 
 
