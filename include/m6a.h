@@ -115,6 +115,36 @@ int m6a_infer(m6a_ctx *ctx, const float *X, const uint8_t *site_kmers, const int
               uint32_t seed, int rng_mode, int64_t batch_size, int64_t save_per_batch,
               float *read_prob, float *site_prob, double *mod_ratio);
 
+/* Streaming form of m6a_infer: the batch loop of run_inference (m6anet/utils/inference_utils.py:33-54) fed as the
+ * DataLoader produces it, so a reference-side binding keeps its loader and its loop.
+ *   m6a_job_begin   the arguments calculate_site_proba / the flush test get per job (inference_utils.py:47,54);
+ *                   expect_sites / expect_reads size the device arrays up front (0 = unknown: they grow);
+ *                   m6a_set_job_offset applies as in m6a_infer.
+ *   m6a_job_feed    one batch = the arguments of m6a_encode_reads (inference_utils.py:35-37): X [r][9], site_kmers [n][3],
+ *                   off [n+1] batch-local CSR offsets (off[0] = 0).  ASYNCHRONOUS: host rows are copied into a pinned
+ *                   ring (the buffers are the caller's again on return), cross PCIe while earlier chunks are being
+ *                   encoded, and the encoder is queued per chunk of <= ~130 k reads.  X / site_kmers may be host or
+ *                   device pointers (both of a kind; device rows are read in place, stream-ordered); off is ALWAYS a
+ *                   host pointer -- it is the loader's n_reads vector (data_utils.py:499).  Batches of any size, in
+ *                   job order.
+ *   m6a_job_end     pools all sites fed so far exactly as m6a_infer would (same flush groups, same random stream) and
+ *                   delivers read_prob [R] (or NULL), site_prob [S], mod_ratio [S] -- all host (synchronous) or all
+ *                   device (the call still synchronises).  Closes the job, also on error.  Results are bit-identical
+ *                   to one m6a_infer over the concatenated batches whenever both pick the same encoder kernel:
+ *                   always when every bag has >= 16 reads (datasets are filtered to >= 20, data_utils.py:129) or when
+ *                   m6a_set_encoder_variant pins it (the choice is made per chunk here, per job there; the two
+ *                   kernels agree to float32 rounding); site_prob / mod_ratio are in every case exactly
+ *                   m6a_site_pool of the job's read probabilities.
+ *   m6a_job_size    sites / reads fed so far;  m6a_job_abort drops an open job.
+ * A feed that fails voids the job: later feeds and m6a_job_end return its code.  While a job is open the other
+ * compute entry points of the context return M6A_EINVAL. */
+int m6a_job_begin(m6a_ctx *ctx, int n_iters, int n_samples, float read_proba_threshold, uint32_t seed, int rng_mode,
+                  int64_t batch_size, int64_t save_per_batch, int64_t expect_sites, int64_t expect_reads);
+int m6a_job_feed(m6a_ctx *ctx, const float *X, const uint8_t *site_kmers, const int64_t *off, int64_t n_sites);
+int m6a_job_size(const m6a_ctx *ctx, int64_t *n_sites, int64_t *n_reads);
+int m6a_job_end(m6a_ctx *ctx, float *read_prob, float *site_prob, double *mod_ratio);
+int m6a_job_abort(m6a_ctx *ctx);
+
 /* MILModel.forward on fixed-size bags (m6anet/model/model.py:155-164 ->
  * SigmoidProdPooling.forward, pooling_blocks.py:127-129): X [B*bag][9], site_kmers [B][3],
  * site_prob[b] = 1 - prod_k (1 - p[b*bag+k]) in float32, left to right. */
@@ -163,11 +193,15 @@ int m6a_shard_plan(const int64_t *off, int64_t n_sites, int64_t batch_size, int6
  *   m6a_comm_unique_id   rank 0 makes the 128-byte RCCL id (ncclGetUniqueId); the launcher hands it to every rank
  *                        by whatever transport it has (its process group, MPI, a file);
  *   m6a_comm_init        ncclCommInitRank on the context's device -- one communicator per context;
- *   m6a_gather           device pointers; shard_site_off [world+1] (HOST) are the cuts of m6a_shard_plan;
+ *   m6a_gather           shard_site_off [world+1] (always a HOST array) are the cuts of m6a_shard_plan;
  *                        site_prob / mod_ratio hold this rank's shard_site_off[rank+1] - shard_site_off[rank] sites;
  *                        site_all / mod_all [shard_site_off[world]] are written on rank dst only (may be NULL
  *                        elsewhere).  ONE grouped send/recv exchange on the context's stream, ragged shards land at
- *                        their offsets without padding; stream-ordered, the caller synchronises (m6a_sync).
+ *                        their offsets without padding.  Data pointers all device (stream-ordered, the caller
+ *                        synchronises with m6a_sync) or all host (staged through the context, synchronous), as everywhere;
+ *   m6a_gather_reads     the same exchange for the per-read output (data.indiv_proba.csv needs it on the rank that
+ *                        writes): read_prob holds this rank's shard_read_off[rank+1] - shard_read_off[rank] reads
+ *                        (shard_read_off[r] = off[shard_site_off[r]] of the job's CSR offsets), read_all on dst;
  * RCCL is bound at run time (dlopen of librccl; M6A_RCCL_LIB names a specific copy): a process that never calls
  * these needs no RCCL.  M6A_EUNSUPPORTED if the library cannot be found. */
 #define M6A_COMM_ID_BYTES 128
@@ -175,7 +209,10 @@ int m6a_comm_unique_id(void *id_out);
 int m6a_comm_init(m6a_ctx *ctx, const void *unique_id, int rank, int world_size);
 int m6a_gather(m6a_ctx *ctx, const float *site_prob, const double *mod_ratio, const int64_t *shard_site_off,
                int dst, float *site_all, double *mod_all);
+int m6a_gather_reads(m6a_ctx *ctx, const float *read_prob, const int64_t *shard_read_off, int dst, float *read_all);
 int m6a_comm_destroy(m6a_ctx *ctx);
+/* HIP devices visible to this process (0 if none / no runtime): what a launcher sizes `world` against. */
+int m6a_device_count(void);
 
 /* Per-kernel timing with HIP events on the context's stream (bench.py's live roofline).
  * kind: 0 = read encoder, 1 = site pooling.  on: 0 off, 1 both kinds, 2 the encoder only, 3 the pooling only (two events per

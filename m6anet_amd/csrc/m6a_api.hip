@@ -235,6 +235,27 @@ struct m6a_ctx {
     DevBuf sX, sK, sOff, sP, sSite, sMod, val_idx, val_y, val_avg, sOffChunk;
     Staging stg;
     uint32_t rt_credit_seed = 0; int64_t rt_credit_A = 0, rt_credit = 0;   // sites pooled on the scan kernels while tables were missing
+    // streaming job (m6a_job_begin / m6a_job_feed / m6a_job_end): the reference's batch loop fed as it is produced
+    struct Job {
+        bool open = false;
+        int failed = 0;                       // first error of a feed: the job is void, m6a_job_end reports it
+        int T = 0, K = 0; float thr = 0.f; uint32_t seed = 0; int64_t bs = 1, spb = 1;
+        std::vector<int64_t> off;             // the job's CSR offsets so far, host [S+1]
+        int64_t S = 0, R = 0;                 // sites / reads fed so far (R == off[S])
+        // ring of sub-slots carved out of the pinned staging ring, each mirrored by a device sub-slot:
+        // [off_local i64 (cap_sites+1) | off_global i64 (cap_sites+1) | site_kmers u8 cap_sites*3 | X f32 cap_reads*9]
+        int n_sub = 0; size_t sub_bytes = 0, o_goff = 0, o_km = 0, o_x = 0;
+        int64_t cap_sites = 0, cap_reads = 0;
+        std::vector<char *> pin;
+        std::vector<hipEvent_t> ev_h2d, ev_enc;
+        std::vector<char> used;               // sub-slot has carried a chunk of this job (its events are live)
+        int64_t item = 0;                     // chunks flushed so far: chunk k uses sub-slot k % n_sub
+        int64_t fill_sites = 0, fill_reads = 0, fill_min = INT64_MAX;   // the chunk being filled
+        bool cur_ready = false;               // the current sub-slot's previous DMA has been waited for
+        int64_t chunks = 0;
+    } job;
+    DevBuf gSite, gMod, gP;                   // host-pointer m6a_gather / m6a_gather_reads: what rank dst receives
+    DevBuf jX, jP, jOff;                      // device sub-slots; read probabilities [R] and CSR offsets [S+1] of the job
     void *comm = nullptr;                     // ncclComm_t
     int comm_rank = 0, comm_world = 0;
     Profiler prof;
@@ -1164,6 +1185,40 @@ int staged_outputs(m6a_ctx *c, int64_t S, float *site, double *mod)
     return M6A_OK;
 }
 
+// A large device array into the caller's pageable memory: DMA of piece k+1 into a pinned slot while the copy threads
+// deliver piece k (a plain hipMemcpy from device to pageable memory runs at a third of the link).  Orders itself
+// behind everything queued on the context's stream; returns when the data is in `host`.
+int d2h_through_ring(m6a_ctx *c, void *host, const void *dev, size_t bytes)
+{
+    if (!bytes) return M6A_OK;
+    Staging &g = c->stg;
+    if (!g.ready || bytes < ((size_t)1 << 20)) {
+        HIPCHK(c, hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return M6A_OK;
+    }
+    const size_t piece = (size_t)g.chunk_reads * 4;              // bytes per pin_out slot
+    HIPCHK(c, hipEventRecord(c->ev_main, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(g.s_d2h, c->ev_main, 0));
+    const size_t np_ = (bytes + piece - 1) / piece;
+    for (size_t k = 0; k < np_ + 1; k++) {                       // piece k-1 is delivered while piece k is on the link; slot k % 3 was piece k-3's
+        if (k < np_) {
+            const int slot = (int)(k % kStageSlots);
+            const size_t a = k * piece, n = std::min(piece, bytes - a);
+            HIPCHK(c, hipMemcpyAsync(g.pin_out[slot], (const char *)dev + a, n, hipMemcpyDeviceToHost, g.s_d2h));
+            HIPCHK(c, hipEventRecord(g.ev_d2h[slot], g.s_d2h));
+        }
+        if (k >= 1) {
+            const size_t q = k - 1;
+            const int slot = (int)(q % kStageSlots);
+            const size_t a = q * piece, n = std::min(piece, bytes - a);
+            HIPCHK(c, hipEventSynchronize(g.ev_d2h[slot]));
+            g.pool->copy((char *)host + a, g.pin_out[slot], n);
+        }
+    }
+    return M6A_OK;
+}
+
 // ---- RCCL, bound at run time ---------------------------------------------------------------------------------
 // (types restated from rccl.h so the library builds and loads without RCCL: NCCL_UNIQUE_ID_BYTES = 128,
 // ncclFloat32 = 7, ncclFloat64 = 8, ncclSuccess = 0)
@@ -1263,6 +1318,188 @@ void host_bag_range(m6a_ctx *c, const int64_t *off, int64_t S)
         }
     }
     c->bag_min = S > 0 ? mn : 0; c->bag_max = mx; c->n_reads = off[S];
+}
+
+// ---- streaming job: the reference's batch loop (inference_utils.py:33-54) fed as the loader produces it ----------
+// A device buffer that grows and KEEPS its contents (the job's read probabilities and CSR offsets: their final size
+// is not known while batches arrive).  Growth is geometric, so a job pays for it O(log) times; every stream that may
+// still be writing the old block is drained first.
+int grow_keep(m6a_ctx *c, DevBuf &b, size_t used_bytes, size_t need_bytes)
+{
+    if (need_bytes <= b.cap) return M6A_OK;
+    const size_t want = std::max(need_bytes + need_bytes / 8 + 256, b.cap * 2);
+    void *np_ = nullptr;
+    HIPCHK(c, hipMalloc(&np_, want));
+    if (b.p && used_bytes) {
+        if (c->stg.s_h2d) HIPCHK(c, hipStreamSynchronize(c->stg.s_h2d));
+        HIPCHK(c, hipMemcpyAsync(np_, b.p, used_bytes, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    if (b.p) (void)hipFree(b.p);
+    b.p = np_; b.cap = want;
+    return M6A_OK;
+}
+
+int job_setup_ring(m6a_ctx *c)
+{
+    auto &j = c->job;
+    int rc = ensure_staging(c);
+    if (rc) return rc;
+    if (j.n_sub) return M6A_OK;
+    Staging &g = c->stg;
+    const size_t slot_bytes = (size_t)g.chunk_reads * M6A_N_FEATURES * 4;
+    const int per_slot = slot_bytes >= ((size_t)20 << 20) ? 5 : slot_bytes >= ((size_t)8 << 20) ? 2 : 1;
+    j.sub_bytes = (slot_bytes / (size_t)per_slot) & ~(size_t)4095;
+    j.cap_sites = 4096;
+    j.o_goff = (size_t)(j.cap_sites + 1) * 8;
+    j.o_km = 2 * j.o_goff;
+    j.o_x = (j.o_km + (size_t)j.cap_sites * 3 + 255) & ~(size_t)255;
+    if (j.sub_bytes < j.o_x + ((size_t)1 << 16)) return fail(c, M6A_EINVAL, "M6A_STAGE_MB too small for the streaming ring");
+    j.cap_reads = (int64_t)((j.sub_bytes - j.o_x) / (M6A_N_FEATURES * 4));
+    for (int i = 0; i < kStageSlots; i++)
+        for (int k = 0; k < per_slot; k++) j.pin.push_back(g.pin_in[i] + (size_t)k * j.sub_bytes);
+    const int n = (int)j.pin.size();
+    HIPCHK(c, c->jX.ensure((size_t)n * j.sub_bytes));
+    for (int i = 0; i < n; i++) {
+        hipEvent_t a = nullptr, b = nullptr;
+        HIPCHK(c, hipEventCreateWithFlags(&a, hipEventDisableTiming));
+        j.ev_h2d.push_back(a);
+        HIPCHK(c, hipEventCreateWithFlags(&b, hipEventDisableTiming));
+        j.ev_enc.push_back(b);
+    }
+    j.used.assign((size_t)n, 0);
+    j.n_sub = n;
+    return M6A_OK;
+}
+
+// the pinned sub-slot the next rows go into; its previous DMA (n_sub chunks ago) must have left it
+int job_acquire(m6a_ctx *c, char **pin)
+{
+    auto &j = c->job;
+    const int sub = (int)(j.item % j.n_sub);
+    if (!j.cur_ready) {
+        if (j.used[(size_t)sub]) HIPCHK(c, hipEventSynchronize(j.ev_h2d[(size_t)sub]));
+        j.cur_ready = true;
+    }
+    *pin = j.pin[(size_t)sub];
+    return M6A_OK;
+}
+
+// Sends the chunk being filled: offsets, k-mer ids and features cross PCIe on the copy stream while earlier chunks are
+// being encoded; the encoder of this chunk is queued on the context's stream behind the copy.  dX / dK non-null: the
+// chunk's features and k-mer ids are already on the device (a device-pointer feed), only the offsets travel.
+int job_flush(m6a_ctx *c, const float *dX = nullptr, const uint8_t *dK = nullptr)
+{
+    auto &j = c->job;
+    Staging &g = c->stg;
+    if (j.fill_sites == 0) return M6A_OK;
+    const int sub = (int)(j.item % j.n_sub);
+    char *pin = j.pin[(size_t)sub];
+    char *dev = (char *)c->jX.p + (size_t)sub * j.sub_bytes;
+    const int64_t ns = j.fill_sites, nr = j.fill_reads, s0 = j.S - ns, r0 = j.R - nr;
+    int rc = grow_keep(c, c->jP, (size_t)r0 * 4, (size_t)std::max<int64_t>(j.R, 1) * 4);
+    if (rc) return rc;
+    rc = grow_keep(c, c->jOff, (size_t)(s0 + 1) * 8, (size_t)(j.S + 1) * 8);
+    if (rc) return rc;
+    if (j.used[(size_t)sub]) HIPCHK(c, hipStreamWaitEvent(g.s_h2d, j.ev_enc[(size_t)sub], 0));   // the encoder that read this device sub-slot
+    HIPCHK(c, hipMemcpyAsync(dev, pin, (size_t)(ns + 1) * 8, hipMemcpyHostToDevice, g.s_h2d));
+    HIPCHK(c, hipMemcpyAsync((int64_t *)c->jOff.p + s0, pin + j.o_goff, (size_t)(ns + 1) * 8, hipMemcpyHostToDevice, g.s_h2d));
+    if (!dX) {
+        HIPCHK(c, hipMemcpyAsync(dev + j.o_km, pin + j.o_km, (size_t)ns * 3, hipMemcpyHostToDevice, g.s_h2d));
+        if (nr) HIPCHK(c, hipMemcpyAsync(dev + j.o_x, pin + j.o_x, (size_t)nr * M6A_N_FEATURES * 4, hipMemcpyHostToDevice, g.s_h2d));
+    }
+    HIPCHK(c, hipEventRecord(j.ev_h2d[(size_t)sub], g.s_h2d));
+    HIPCHK(c, hipStreamWaitEvent(c->stream, j.ev_h2d[(size_t)sub], 0));
+    if (nr) {
+        c->bag_min = j.fill_min; c->n_reads = nr;             // what launch_encode looks at (kernel choice)
+        rc = launch_encode(c, dX ? dX : (const float *)(dev + j.o_x), dK ? dK : (const uint8_t *)(dev + j.o_km), (const int64_t *)dev, ns, nr,
+                           (float *)c->jP.p + r0);
+        if (rc) return rc;
+    }
+    HIPCHK(c, hipEventRecord(j.ev_enc[(size_t)sub], c->stream));
+    j.used[(size_t)sub] = 1;
+    j.item++; j.chunks++;
+    j.fill_sites = 0; j.fill_reads = 0; j.fill_min = INT64_MAX; j.cur_ready = false;
+    return M6A_OK;
+}
+
+// rows [i, i+k) of a batch join the chunk being filled: CSR offsets (chunk-local for the encoder, job-global for the
+// pooling) are written into the pinned sub-slot, the job's host copy of off[] grows
+void job_append_offsets(m6a_ctx *c, char *pin, const int64_t *off, int64_t i, int64_t k)
+{
+    auto &j = c->job;
+    int64_t *ol = (int64_t *)pin, *og = (int64_t *)(pin + j.o_goff);
+    if (j.fill_sites == 0) { ol[0] = 0; og[0] = j.R; }
+    const int64_t base = off[i], lbase = j.fill_reads, gbase = j.R;
+    int64_t mn = j.fill_min;
+    for (int64_t t = 0; t < k; t++) {
+        const int64_t e = off[i + t + 1] - base, n = off[i + t + 1] - off[i + t];
+        ol[j.fill_sites + t + 1] = lbase + e;
+        og[j.fill_sites + t + 1] = gbase + e;
+        j.off.push_back(gbase + e);
+        mn = n < mn ? n : mn;
+    }
+    j.fill_min = mn;
+    const int64_t nr = off[i + k] - base;
+    j.fill_sites += k; j.fill_reads += nr; j.S += k; j.R += nr;
+}
+
+int job_feed_impl(m6a_ctx *c, const float *X, const uint8_t *km, const int64_t *off, int64_t n, bool dev)
+{
+    auto &j = c->job;
+    if (off[0] != 0) return fail(c, M6A_EINVAL, "off[0] must be 0");
+    for (int64_t s = 0; s < n; s++) if (off[s + 1] < off[s]) return fail(c, M6A_EINVAL, "off[] must be non-decreasing");
+    int rc;
+    if (dev) {
+        // features already on the device: every piece of <= cap_sites sites is a chunk of its own, read in place
+        rc = job_flush(c);
+        if (rc) return rc;
+        for (int64_t i = 0; i < n;) {
+            char *pin;
+            rc = job_acquire(c, &pin);
+            if (rc) return rc;
+            const int64_t k = std::min<int64_t>(n - i, j.cap_sites);
+            const int64_t r0 = off[i];
+            job_append_offsets(c, pin, off, i, k);
+            rc = job_flush(c, X + r0 * M6A_N_FEATURES, km + i * 3);
+            if (rc) return rc;
+            i += k;
+        }
+        return M6A_OK;
+    }
+    for (int64_t i = 0; i < n;) {
+        char *pin;
+        rc = job_acquire(c, &pin);
+        if (rc) return rc;
+        const int64_t room_s = j.cap_sites - j.fill_sites, room_r = j.cap_reads - j.fill_reads;
+        const int64_t lim = std::min<int64_t>(n, i + room_s);
+        // the most sites of the batch that still fit this chunk
+        const int64_t k = (std::upper_bound(off + i, off + lim + 1, off[i] + room_r) - (off + i)) - 1;
+        if (k <= 0) {
+            if (j.fill_sites == 0)
+                return fail(c, M6A_EUNSUPPORTED, "a site of %lld reads does not fit a streaming chunk (%lld reads): use m6a_infer",
+                            (long long)(off[i + 1] - off[i]), (long long)j.cap_reads);
+            rc = job_flush(c);
+            if (rc) return rc;
+            continue;
+        }
+        const int64_t r0 = off[i], nr = off[i + k] - r0;
+        std::memcpy(pin + j.o_x + (size_t)j.fill_reads * M6A_N_FEATURES * 4, X + r0 * M6A_N_FEATURES, (size_t)nr * M6A_N_FEATURES * 4);
+        std::memcpy(pin + j.o_km + (size_t)j.fill_sites * 3, km + i * 3, (size_t)k * 3);
+        job_append_offsets(c, pin, off, i, k);
+        i += k;
+        if (j.fill_sites == j.cap_sites || j.fill_reads == j.cap_reads) {
+            rc = job_flush(c);
+            if (rc) return rc;
+        }
+    }
+    return M6A_OK;
+}
+
+int job_busy(m6a_ctx *c)
+{
+    if (c->job.open) return fail(c, M6A_EINVAL, "a streaming job is open on this context (m6a_job_end or m6a_job_abort first)");
+    return M6A_OK;
 }
 
 // m6a_set_host_offsets is one-shot: whichever entry point runs next consumes the hint -- on its device-pointer branch
@@ -1411,7 +1648,9 @@ void m6a_destroy(m6a_ctx *c)
     if (c->h_ctl) (void)hipHostFree(c->h_ctl);
     if (c->rt.C) (void)hipFree(c->rt.C);
     if (c->rt.RS) (void)hipFree(c->rt.RS);
-    for (DevBuf *b : {&c->ctl_dev, &c->rt_rank, &c->rt_order, &c->sOffChunk, &c->reg_out}) b->release();
+    for (DevBuf *b : {&c->ctl_dev, &c->rt_rank, &c->rt_order, &c->sOffChunk, &c->reg_out, &c->jX, &c->jP, &c->jOff, &c->gSite, &c->gMod, &c->gP}) b->release();
+    for (auto e : c->job.ev_h2d) (void)hipEventDestroy(e);
+    for (auto e : c->job.ev_enc) (void)hipEventDestroy(e);
     release_staging(c);
     if (c->comm) { Rccl *R = rccl(); if (R->CommDestroy) (void)R->CommDestroy(c->comm); c->comm = nullptr; }
     if (c->s_prep) (void)hipStreamDestroy(c->s_prep);
@@ -1488,6 +1727,7 @@ int m6a_prepare_host_io(m6a_ctx *c)
 int m6a_encode_reads(m6a_ctx *c, const float *X, const uint8_t *km, const int64_t *off, int64_t S, float *rp)
 {
     HintScope hint_scope(c);
+    if (c && c->job.open) return job_busy(c);
     if (!c) return M6A_EINVAL;
     if (S < 0) return fail(c, M6A_EINVAL, "n_sites < 0");
     if (S == 0) return M6A_OK;
@@ -1518,6 +1758,7 @@ int m6a_site_pool(m6a_ctx *c, const float *rp, const int64_t *off, int64_t S, in
                   uint32_t seed, int rng_mode, int64_t bs, int64_t spb, float *site, double *mod)
 {
     HintScope hint_scope(c);
+    if (c && c->job.open) return job_busy(c);
     int rc = check_pool_args(c, S, T, K, rng_mode, bs, spb);
     if (rc) return rc;
     if (S == 0) return M6A_OK;
@@ -1553,6 +1794,7 @@ int m6a_infer(m6a_ctx *c, const float *X, const uint8_t *km, const int64_t *off,
               float thr, uint32_t seed, int rng_mode, int64_t bs, int64_t spb, float *rp, float *site, double *mod)
 {
     HintScope hint_scope(c);
+    if (c && c->job.open) return job_busy(c);
     int rc = check_pool_args(c, S, T, K, rng_mode, bs, spb);
     if (rc) return rc;
     if (S == 0) return M6A_OK;
@@ -1593,9 +1835,116 @@ int m6a_infer(m6a_ctx *c, const float *X, const uint8_t *km, const int64_t *off,
     return staged_outputs(c, S, site, mod);
 }
 
+int m6a_job_begin(m6a_ctx *c, int T, int K, float thr, uint32_t seed, int rng_mode, int64_t bs, int64_t spb,
+                  int64_t expect_sites, int64_t expect_reads)
+{
+    int rc = check_pool_args(c, 0, T, K, rng_mode, bs, spb);
+    if (rc) return rc;
+    HintScope hint_scope(c);
+    rc = job_busy(c);
+    if (rc) return rc;
+    if (expect_sites < 0 || expect_reads < 0) return fail(c, M6A_EINVAL, "expected sizes must be >= 0 (0 = unknown)");
+    if (!base_is_group_start(c->job_offset, bs, spb))
+        return fail(c, M6A_EINVAL, "job offset %lld does not start a flush group for batch_size=%lld save_per_batch=%lld",
+                    (long long)c->job_offset, (long long)bs, (long long)spb);
+    HIPCHK(c, hipSetDevice(c->device));
+    rc = job_setup_ring(c);
+    if (rc) return rc;
+    auto &j = c->job;
+    j.T = T; j.K = K; j.thr = thr; j.seed = seed; j.bs = bs; j.spb = spb;
+    j.off.clear();
+    j.off.reserve((size_t)std::max<int64_t>(expect_sites, 1 << 16) + 1);
+    j.off.push_back(0);
+    j.S = j.R = 0; j.item = 0; j.chunks = 0; j.failed = 0;
+    j.fill_sites = j.fill_reads = 0; j.fill_min = INT64_MAX; j.cur_ready = false;
+    std::fill(j.used.begin(), j.used.end(), 0);
+    // the ring may still carry DMAs of an earlier host-pointer call or job on other streams: start from idle
+    HIPCHK(c, hipStreamSynchronize(c->stg.s_h2d));
+    if (expect_reads) { rc = grow_keep(c, c->jP, 0, (size_t)expect_reads * 4); if (rc) return rc; }
+    if (expect_sites) { rc = grow_keep(c, c->jOff, 0, (size_t)(expect_sites + 1) * 8); if (rc) return rc; }
+    j.open = true;
+    return M6A_OK;
+}
+
+int m6a_job_feed(m6a_ctx *c, const float *X, const uint8_t *km, const int64_t *off, int64_t n_sites)
+{
+    if (!c) return M6A_EINVAL;
+    auto &j = c->job;
+    if (!j.open) return fail(c, M6A_EINVAL, "no streaming job is open (m6a_job_begin)");
+    if (j.failed) return j.failed;                                   // message of the first failure is still in place
+    if (n_sites < 0) return fail(c, M6A_EINVAL, "n_sites < 0");
+    if (n_sites == 0) return M6A_OK;
+    if (!km || !off) return fail(c, M6A_EINVAL, "null pointer argument");
+    if (!X && off[n_sites] != 0) return fail(c, M6A_EINVAL, "null pointer argument");
+    const bool dev = is_device_ptr(X);
+    if (dev != is_device_ptr(km)) return fail(c, M6A_EINVAL, "X and site_kmers must be both host or both device pointers");
+    if (is_device_ptr(off)) return fail(c, M6A_EINVAL, "m6a_job_feed takes off[] as a HOST pointer");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int rc = job_feed_impl(c, X, km, off, n_sites, dev);
+    if (rc) j.failed = rc;
+    return rc;
+}
+
+int m6a_job_size(const m6a_ctx *c, int64_t *n_sites, int64_t *n_reads)
+{
+    if (!c) return M6A_EINVAL;
+    if (n_sites) *n_sites = c->job.open ? c->job.S : 0;
+    if (n_reads) *n_reads = c->job.open ? c->job.R : 0;
+    return M6A_OK;
+}
+
+int m6a_job_abort(m6a_ctx *c)
+{
+    if (!c) return M6A_EINVAL;
+    if (!c->job.open) return M6A_OK;
+    c->job.open = false;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->stg.s_h2d) HIPCHK(c, hipStreamSynchronize(c->stg.s_h2d));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return M6A_OK;
+}
+
+int m6a_job_end(m6a_ctx *c, float *rp, float *site, double *mod)
+{
+    if (!c) return M6A_EINVAL;
+    auto &j = c->job;
+    if (!j.open) return fail(c, M6A_EINVAL, "no streaming job is open (m6a_job_begin)");
+    HintScope hint_scope(c);
+    HIPCHK(c, hipSetDevice(c->device));
+    struct Closer { m6a_ctx *c; ~Closer() { (void)m6a_job_abort(c); } } closer{c};     // whatever happens, the job ends here
+    if (j.failed) return j.failed;
+    int rc = job_flush(c);
+    if (rc) return rc;
+    const int64_t S = j.S, R = j.R;
+    if (S == 0) return M6A_OK;
+    if (!site || !mod) return fail(c, M6A_EINVAL, "null pointer argument");
+    const bool dev = is_device_ptr(site);
+    if (dev != is_device_ptr(mod) || (rp && R > 0 && dev != is_device_ptr(rp)))
+        return fail(c, M6A_EINVAL, "read_prob, site_prob, mod_ratio must be all host or all device pointers");
+    host_bag_range(c, j.off.data(), S);
+    float *d_site = site; double *d_mod = mod;
+    if (!dev) {
+        HIPCHK(c, c->sSite.ensure((size_t)S * 4));
+        HIPCHK(c, c->sMod.ensure((size_t)S * 8));
+        d_site = (float *)c->sSite.p; d_mod = (double *)c->sMod.p;
+    }
+    Prefault pf_rp, pf_out;
+    if (!dev && rp) pf_rp.start(rp, (size_t)R * 4, 2);
+    if (!dev) pf_out.start(mod, (size_t)S * 8, 1);
+    rc = launch_pool(c, (const float *)c->jP.p, (const int64_t *)c->jOff.p, S, j.T, j.K, j.thr, j.seed, j.bs, j.spb, d_site, d_mod);
+    if (rc) return rc;
+    if (dev) {
+        if (rp && R) HIPCHK(c, hipMemcpyAsync(rp, c->jP.p, (size_t)R * 4, hipMemcpyDeviceToDevice, c->stream));
+        return sync_and_check(c);
+    }
+    if (rp && R) { rc = d2h_through_ring(c, rp, c->jP.p, (size_t)R * 4); if (rc) return rc; }
+    return staged_outputs(c, S, site, mod);
+}
+
 int m6a_bag_forward(m6a_ctx *c, const float *X, const uint8_t *km, int64_t B, int bag, float *site)
 {
     HintScope hint_scope(c);
+    if (c && c->job.open) return job_busy(c);
     if (!c) return M6A_EINVAL;
     if (B < 0 || bag < 1) return fail(c, M6A_EINVAL, "n_bags must be >= 0 and bag >= 1");
     if (B == 0) return M6A_OK;
@@ -1737,6 +2086,7 @@ int m6a_validate_pool(m6a_ctx *c, const float *rp, const int64_t *off, int64_t S
                       float *y, float *avg)
 {
     HintScope hint_scope(c);
+    if (c && c->job.open) return job_busy(c);
     int rc = check_validate_args(c, S, T, K);
     if (rc) return rc;
     if (S == 0) return M6A_OK;
@@ -1772,6 +2122,7 @@ int m6a_validate(m6a_ctx *c, const float *X, const uint8_t *km, const int64_t *o
                  uint32_t seed, float *rp, float *y, float *avg)
 {
     HintScope hint_scope(c);
+    if (c && c->job.open) return job_busy(c);
     int rc = check_validate_args(c, S, T, K);
     if (rc) return rc;
     if (S == 0) return M6A_OK;
@@ -1897,40 +2248,125 @@ int m6a_comm_destroy(m6a_ctx *c)
     return M6A_OK;
 }
 
-int m6a_gather(m6a_ctx *c, const float *site, const double *mod, const int64_t *cuts, int dst, float *site_all, double *mod_all)
+namespace {
+
+struct GatherArray { const void *src; void *out; int dtype; size_t esz; const char *name; };
+
+// ONE grouped exchange on the context's stream: every rank (dst included) sends its slice of each array, dst posts the
+// matching receives at the shards' offsets -- direct peer-to-peer writes over xGMI, no ring, no padding.  A failing
+// Send/Recv must not leave the thread's RCCL group open (every later RCCL call of the thread would queue into it):
+// remember the first error, always close the group.  All pointers are device pointers.
+int gather_group(m6a_ctx *c, const GatherArray *arr, int n_arr, const int64_t *cuts, int dst)
 {
-    if (!c) return M6A_EINVAL;
-    if (!c->comm) return fail(c, M6A_EINVAL, "m6a_comm_init has not run on this context");
-    const int W = c->comm_world, me = c->comm_rank;
-    if (!cuts || dst < 0 || dst >= W) return fail(c, M6A_EINVAL, "bad gather arguments");
-    for (int r = 0; r < W; r++) if (cuts[r + 1] < cuts[r]) return fail(c, M6A_EINVAL, "shard_site_off must be non-decreasing");
-    const int64_t mine = cuts[me + 1] - cuts[me];
-    if (mine > 0 && (!site || !mod)) return fail(c, M6A_EINVAL, "null pointer argument");
-    if (me == dst && cuts[W] > cuts[0] && (!site_all || !mod_all)) return fail(c, M6A_EINVAL, "rank dst needs site_all and mod_all");
     Rccl *R = rccl();
-    HIPCHK(c, hipSetDevice(c->device));
-    // one grouped exchange: every rank (dst included) sends its two arrays, dst posts the matching receives at the
-    // shards' offsets -- direct peer-to-peer writes over xGMI, no ring, no padding.  A failing Send/Recv must not leave
-    // the thread's RCCL group open (every later RCCL call of the thread would queue into it): remember the first
-    // error, always close the group.
+    const int W = c->comm_world, me = c->comm_rank;
+    const int64_t mine = cuts[me + 1] - cuts[me];
     RCCLCHK(c, R, R->GroupStart());
     int first = 0;
     const char *what = "";
     auto op = [&](int e, const char *w) { if (e != 0 && first == 0) { first = e; what = w; } return first == 0; };
     if (mine > 0)
-        (void)(op(R->Send(site, (size_t)mine, 7 /* ncclFloat32 */, dst, c->comm, c->stream), "ncclSend(site_prob)") &&
-               op(R->Send(mod, (size_t)mine, 8 /* ncclFloat64 */, dst, c->comm, c->stream), "ncclSend(mod_ratio)"));
+        for (int a = 0; a < n_arr && first == 0; a++)
+            op(R->Send(arr[a].src, (size_t)mine, arr[a].dtype, dst, c->comm, c->stream), arr[a].name);
     if (me == dst)
         for (int r = 0; r < W && first == 0; r++) {
             const int64_t n = cuts[r + 1] - cuts[r];
             if (n <= 0) continue;
-            (void)(op(R->Recv(site_all + (cuts[r] - cuts[0]), (size_t)n, 7, r, c->comm, c->stream), "ncclRecv(site_prob)") &&
-                   op(R->Recv(mod_all + (cuts[r] - cuts[0]), (size_t)n, 8, r, c->comm, c->stream), "ncclRecv(mod_ratio)"));
+            for (int a = 0; a < n_arr && first == 0; a++)
+                op(R->Recv((char *)arr[a].out + (size_t)(cuts[r] - cuts[0]) * arr[a].esz, (size_t)n, arr[a].dtype, r, c->comm, c->stream), arr[a].name);
         }
     const int e_end = R->GroupEnd();
-    if (first != 0) return fail(c, M6A_EHIP, "%s: %s", what, R->GetErrorString ? R->GetErrorString(first) : "RCCL error");
+    if (first != 0) return fail(c, M6A_EHIP, "RCCL send/recv of %s: %s", what, R->GetErrorString ? R->GetErrorString(first) : "RCCL error");
     if (e_end != 0) return fail(c, M6A_EHIP, "ncclGroupEnd: %s", R->GetErrorString ? R->GetErrorString(e_end) : "RCCL error");
     return M6A_OK;
+}
+
+int check_gather_args(m6a_ctx *c, const int64_t *cuts, int dst)
+{
+    if (!c->comm) return fail(c, M6A_EINVAL, "m6a_comm_init has not run on this context");
+    const int W = c->comm_world;
+    if (!cuts || dst < 0 || dst >= W) return fail(c, M6A_EINVAL, "bad gather arguments");
+    if (is_device_ptr(cuts)) return fail(c, M6A_EINVAL, "shard offsets are a HOST array");
+    for (int r = 0; r < W; r++) if (cuts[r + 1] < cuts[r]) return fail(c, M6A_EINVAL, "shard offsets must be non-decreasing");
+    return M6A_OK;
+}
+
+}  // namespace
+
+int m6a_gather(m6a_ctx *c, const float *site, const double *mod, const int64_t *cuts, int dst, float *site_all, double *mod_all)
+{
+    if (!c) return M6A_EINVAL;
+    int rc = check_gather_args(c, cuts, dst);
+    if (rc) return rc;
+    if (c->job.open) return job_busy(c);
+    const int W = c->comm_world, me = c->comm_rank;
+    const int64_t mine = cuts[me + 1] - cuts[me], total = cuts[W] - cuts[0];
+    if (mine > 0 && (!site || !mod)) return fail(c, M6A_EINVAL, "null pointer argument");
+    if (me == dst && total > 0 && (!site_all || !mod_all)) return fail(c, M6A_EINVAL, "rank dst needs site_all and mod_all");
+    HIPCHK(c, hipSetDevice(c->device));
+    const bool recv = me == dst && total > 0;
+    const bool dev = mine > 0 ? is_device_ptr(site) : recv ? is_device_ptr(site_all) : true;
+    if ((mine > 0 && dev != is_device_ptr(mod)) || (recv && (dev != is_device_ptr(site_all) || dev != is_device_ptr(mod_all))))
+        return fail(c, M6A_EINVAL, "site_prob, mod_ratio, site_all, mod_all must be all host or all device pointers");
+    GatherArray arr[2] = {{site, site_all, 7 /* ncclFloat32 */, 4, "site_prob"}, {mod, mod_all, 8 /* ncclFloat64 */, 8, "mod_ratio"}};
+    if (dev) return gather_group(c, arr, 2, cuts, dst);
+    // host arrays: staged through the context's device buffers, synchronous
+    if (mine > 0) {
+        HIPCHK(c, c->sSite.ensure((size_t)mine * 4));
+        HIPCHK(c, c->sMod.ensure((size_t)mine * 8));
+        HIPCHK(c, hipMemcpyAsync(c->sSite.p, site, (size_t)mine * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->sMod.p, mod, (size_t)mine * 8, hipMemcpyHostToDevice, c->stream));
+        arr[0].src = c->sSite.p; arr[1].src = c->sMod.p;
+    }
+    if (recv) {
+        HIPCHK(c, c->gSite.ensure((size_t)total * 4));
+        HIPCHK(c, c->gMod.ensure((size_t)total * 8));
+        arr[0].out = c->gSite.p; arr[1].out = c->gMod.p;
+    }
+    rc = gather_group(c, arr, 2, cuts, dst);
+    if (rc) return rc;
+    if (recv) {
+        rc = d2h_through_ring(c, site_all, c->gSite.p, (size_t)total * 4);
+        if (rc) return rc;
+        rc = d2h_through_ring(c, mod_all, c->gMod.p, (size_t)total * 8);
+        if (rc) return rc;
+    }
+    return sync_and_check(c);
+}
+
+int m6a_gather_reads(m6a_ctx *c, const float *rp, const int64_t *cuts, int dst, float *rp_all)
+{
+    if (!c) return M6A_EINVAL;
+    int rc = check_gather_args(c, cuts, dst);
+    if (rc) return rc;
+    if (c->job.open) return job_busy(c);
+    const int W = c->comm_world, me = c->comm_rank;
+    const int64_t mine = cuts[me + 1] - cuts[me], total = cuts[W] - cuts[0];
+    if (mine > 0 && !rp) return fail(c, M6A_EINVAL, "null pointer argument");
+    if (me == dst && total > 0 && !rp_all) return fail(c, M6A_EINVAL, "rank dst needs read_all");
+    HIPCHK(c, hipSetDevice(c->device));
+    const bool recv = me == dst && total > 0;
+    const bool dev = mine > 0 ? is_device_ptr(rp) : recv ? is_device_ptr(rp_all) : true;
+    if (mine > 0 && recv && dev != is_device_ptr(rp_all)) return fail(c, M6A_EINVAL, "read_prob and read_all must be both host or both device pointers");
+    GatherArray arr[1] = {{rp, rp_all, 7 /* ncclFloat32 */, 4, "read_prob"}};
+    if (dev) return gather_group(c, arr, 1, cuts, dst);
+    if (mine > 0) {
+        HIPCHK(c, c->sP.ensure((size_t)mine * 4));
+        HIPCHK(c, hipMemcpyAsync(c->sP.p, rp, (size_t)mine * 4, hipMemcpyHostToDevice, c->stream));
+        arr[0].src = c->sP.p;
+    }
+    if (recv) { HIPCHK(c, c->gP.ensure((size_t)total * 4)); arr[0].out = c->gP.p; }
+    rc = gather_group(c, arr, 1, cuts, dst);
+    if (rc) return rc;
+    if (recv) { rc = d2h_through_ring(c, rp_all, c->gP.p, (size_t)total * 4); if (rc) return rc; }
+    return sync_and_check(c);
+}
+
+int m6a_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
 }
 
 int m6a_profile_enable(m6a_ctx *c, int on)

@@ -182,9 +182,9 @@ class M6ANetEngine:
         self._chk(self._L.m6a_comm_destroy(self._h))
 
     def gather(self, site, mod, cuts, dst=0, out=None):
-        """site_prob / mod_ratio of this rank's shard (torch tensors on the context's GPU) to rank `dst` in ONE
-        grouped RCCL exchange on the context's stream; returns (site_all, mod_all) on dst, (None, None) elsewhere."""
-        import torch
+        """site_prob / mod_ratio of this rank's shard to rank `dst` in ONE grouped RCCL exchange on the context's
+        stream; returns (site_all, mod_all) on dst, (None, None) elsewhere.  torch tensors on the context's GPU
+        (stream-ordered: `sync()` before reading) or numpy arrays (staged by the library, synchronous)."""
         rank, world = self._comm
         cuts = np.ascontiguousarray(cuts, np.int64)
         assert cuts.size == world + 1
@@ -192,11 +192,27 @@ class M6ANetEngine:
         total = int(cuts[-1] - cuts[0])
         sa = ma = None
         if rank == dst:
-            sa, ma = out if out is not None else (torch.empty(total, dtype=torch.float32, device=site.device),
-                                                  torch.empty(total, dtype=torch.float64, device=site.device))
+            sa, ma = out if out is not None else (self._out(aS.is_dev, total, np.float32, "float32"),
+                                                  self._out(aS.is_dev, total, np.float64, "float64"))
+        oS = _Arg(sa, np.float32, "float32") if sa is not None else None
+        oM = _Arg(ma, np.float64, "float64") if ma is not None else None
         self._chk(self._L.m6a_gather(self._h, aS.ptr, aM.ptr, cuts.ctypes.data, int(dst),
-                                     sa.data_ptr() if sa is not None else None, ma.data_ptr() if ma is not None else None))
+                                     oS.ptr if oS else None, oM.ptr if oM else None))
         return sa, ma
+
+    def gather_reads(self, read_prob, read_cuts, dst=0, out=None):
+        """The per-read output of this rank's shard to rank `dst` (include/m6a.h: m6a_gather_reads); read_cuts [world+1]
+        = off[site cuts] of the job's CSR offsets.  Returns read_all on dst, None elsewhere."""
+        rank, world = self._comm
+        cuts = np.ascontiguousarray(read_cuts, np.int64)
+        assert cuts.size == world + 1
+        aP = _Arg(read_prob, np.float32, "float32")
+        ra = None
+        if rank == dst:
+            ra = out if out is not None else self._out(aP.is_dev, int(cuts[-1] - cuts[0]), np.float32, "float32")
+        oP = _Arg(ra, np.float32, "float32") if ra is not None else None
+        self._chk(self._L.m6a_gather_reads(self._h, aP.ptr, cuts.ctypes.data, int(dst), oP.ptr if oP else None))
+        return ra
 
     def prepare_host_io(self):
         """Pin the staging ring of the host-pointer path now (otherwise the first numpy-array call does it)."""
@@ -273,6 +289,48 @@ class M6ANetEngine:
                                     aP.ptr if aP else None, aS.ptr, aM.ptr))
         return rp, site, mod
 
+    # -- the same job, streamed: run_inference's batch loop (inference_utils.py:33-54) feeds as the loader produces --------
+    def job_begin(self, n_iters, n_samples=N_SAMPLES, read_proba_threshold=DEFAULT_READ_THRESHOLD, seed=0, batch_size=16,
+                  save_per_batch=2, expect_sites=0, expect_reads=0):
+        """Opens a streaming job (include/m6a.h: m6a_job_begin); feed batches with `job_feed`, finish with `job_end`."""
+        self._chk(self._L.m6a_job_begin(self._h, int(n_iters), int(n_samples), float(np.float32(read_proba_threshold)),
+                                        int(seed) & 0xffffffff, _lib.RNG_NUMPY, int(batch_size), int(save_per_batch),
+                                        int(expect_sites), int(expect_reads)))
+        self._job_dev = False
+
+    def job_feed(self, X, site_kmers, off):
+        """One batch: X [r,9], site_kmers [n,3] (numpy or torch-on-GPU), off [n+1] batch-local CSR offsets (host).
+        Asynchronous: returns once the rows are in the pinned ring; the arrays are the caller's again."""
+        aX, aK = _Arg(X, np.float32, "float32"), _Arg(site_kmers, np.uint8, "uint8")
+        o = off if (isinstance(off, np.ndarray) and off.dtype == np.int64 and off.flags.c_contiguous) else \
+            np.ascontiguousarray(off.cpu().numpy() if _is_torch(off) else off, dtype=np.int64)
+        n = o.size - 1
+        if aK.size != 3 * n or aX.size != 9 * int(o[-1]):
+            raise ValueError("batch shapes disagree: X [off[-1], 9], site_kmers [n_sites, 3], off [n_sites + 1]")
+        self._job_dev = self._job_dev or aX.is_dev
+        self._chk(self._L.m6a_job_feed(self._h, aX.ptr, aK.ptr, o.ctypes.data, n))
+
+    def job_size(self):
+        S, R = C.c_int64(), C.c_int64()
+        self._chk(self._L.m6a_job_size(self._h, C.byref(S), C.byref(R)))
+        return S.value, R.value
+
+    def job_end(self, want_read_probs=True, device_outputs=None):
+        """Pools everything fed and returns (read_probs or None, site_probs, mod_ratios) -- numpy arrays, or torch
+        tensors on the GPU when the job was fed device tensors (or device_outputs=True)."""
+        S, R = self.job_size()
+        dev = self._job_dev if device_outputs is None else bool(device_outputs)
+        rp = self._out(dev, R, np.float32, "float32") if want_read_probs else None
+        site = self._out(dev, S, np.float32, "float32")
+        mod = self._out(dev, S, np.float64, "float64")
+        aP = _Arg(rp, np.float32, "float32") if rp is not None else None
+        aS, aM = _Arg(site, np.float32, "float32"), _Arg(mod, np.float64, "float64")
+        self._chk(self._L.m6a_job_end(self._h, aP.ptr if aP else None, aS.ptr, aM.ptr))
+        return rp, site, mod
+
+    def job_abort(self):
+        self._chk(self._L.m6a_job_abort(self._h))
+
     def forward(self, X, kmer, bag=N_SAMPLES):
         """Site probability of fixed-size bags: X [B, bag, 9], kmer [B, 3] -> [B]."""
         aX, aK = _Arg(X, np.float32, "float32"), _Arg(kmer, np.uint8, "uint8")
@@ -322,6 +380,11 @@ def comm_unique_id():
     if rc != 0:
         raise _lib.M6AError(rc, L.m6a_last_error(None).decode())
     return bytes(buf.raw)
+
+
+def device_count():
+    """HIP devices visible to this process (include/m6a.h: m6a_device_count)."""
+    return int(_lib.load().m6a_device_count())
 
 
 def flush_groups(n_sites, batch_size=16, save_per_batch=2):

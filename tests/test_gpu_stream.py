@@ -1,0 +1,259 @@
+"""GPU tests of round 3: the streaming job API (m6a_job_begin / feed / end), INTEGRATION.md's stub executed as
+written, the statistical read-probability guard at full size, and the multi-GPU split of the product CLI.
+
+Bars as in tests/test_gpu_parity.py: read probabilities rtol 1e-5 / atol 1e-8 (m6anet/tests/test_inference.py:32),
+site probabilities and mod_ratio bit-exact given the same read probabilities."""
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from m6anet_amd import _lib, synthetic                      # noqa: E402
+from m6anet_amd.constants import DEFAULT_READ_THRESHOLD     # noqa: E402
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+THR = np.float32(DEFAULT_READ_THRESHOLD)
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import m6a_oracle
+    m6a_oracle.build()
+    return m6a_oracle
+
+
+@pytest.fixture(scope="module")
+def engines(weights):
+    from m6anet_amd.engine import M6ANetEngine
+    return {name: M6ANetEngine(weights=w) for name, w in weights.items()}
+
+
+@pytest.fixture(scope="module")
+def eng(engines):
+    return engines["hct116"]
+
+
+def feed_in_batches(eng, d, batch, **begin):
+    off = d["off"]
+    S = len(off) - 1
+    eng.job_begin(**begin)
+    for s0 in range(0, S, batch):
+        s1 = min(S, s0 + batch)
+        eng.job_feed(d["X"][off[s0]:off[s1]], d["site_kmers"][s0:s1], off[s0:s1 + 1] - off[s0])
+    assert eng.job_size() == (S, int(off[-1]))
+    return eng.job_end()
+
+
+# ------------------------------------------------------------------ streaming job ----------------------------------
+@pytest.mark.parametrize("bag,S,T", [(20, 5000, 1000), ((20, 90), 3000, 200), ((16, 700), 900, 50)])
+@pytest.mark.parametrize("batch", [16, 1, 999, 10**9])
+def test_job_stream_equals_infer(eng, bag, S, T, batch):
+    """The reference's batch loop fed batch by batch == ONE m6a_infer over the whole job, bit for bit (every bag has
+    >= 16 reads, so both pick the 12-slot encoder), whatever the batch size -- 16 like the reference's DataLoader, single
+    sites, batches that straddle chunks, the whole job at once."""
+    d = synthetic.make_sites(S, bag, seed=S + T)
+    want = eng.infer(d["X"], d["site_kmers"], d["off"], T, read_proba_threshold=THR, seed=3, batch_size=16, save_per_batch=2)
+    got = feed_in_batches(eng, d, batch, n_iters=T, read_proba_threshold=THR, seed=3, batch_size=16, save_per_batch=2)
+    for g, w, name in zip(got, want, ("read_prob", "site_prob", "mod_ratio")):
+        assert g.dtype == w.dtype and np.array_equal(g, w), name
+
+
+def test_job_stream_small_and_empty_bags(eng, orc, weights):
+    """Bags below 16 reads, single reads and empty sites among the batches: a chunk then takes the general encoder
+    where the whole-job call might not, so read probabilities are held to the oracle's bar and the pooling to
+    bit-equality with m6a_site_pool of the job's own read probabilities; with the encoder pinned, to m6a_infer."""
+    g = np.random.Generator(np.random.PCG64(77))
+    bags = g.integers(0, 40, size=4000)
+    bags[::97] = 0
+    d = synthetic.make_sites(len(bags), seed=5, n_reads=bags)
+    kw = dict(n_iters=120, read_proba_threshold=THR, seed=0, batch_size=7, save_per_batch=3)
+    rp, site, mod = feed_in_batches(eng, d, 16, **kw)
+    want_rp = orc.encode_reads(weights["hct116"], d["X"], d["site_kmers"], d["off"], n_threads=8)
+    assert np.allclose(rp, want_rp, rtol=1e-5, atol=1e-8)
+    s2, m2 = eng.calculate_site_proba(rp, d["off"], 120, 20, THR, 0, 7, 3)
+    assert np.array_equal(site, s2, equal_nan=True) and np.array_equal(mod, m2, equal_nan=True)
+    o_site, o_mod = orc.site_pool(rp, d["off"], 120, THR, batch_size=7, save_per_batch=3)
+    assert np.array_equal(site, o_site, equal_nan=True) and np.array_equal(mod, o_mod, equal_nan=True)
+    eng.set_encoder_variant(1)
+    try:
+        a = feed_in_batches(eng, d, 33, **kw)
+        b = eng.infer(d["X"], d["site_kmers"], d["off"], 120, 20, THR, 0, 7, 3)
+    finally:
+        eng.set_encoder_variant(0)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y, equal_nan=True)
+
+
+def test_job_stream_grows_and_reuses(eng):
+    """A job much larger than what the context has seen (device arrays grow while chunks are in flight), with and
+    without size hints, then a small job on the same context: all equal m6a_infer."""
+    d = synthetic.make_sites(300_000, 20, seed=9)
+    want = eng.infer(d["X"], d["site_kmers"], d["off"], 100)
+    got = feed_in_batches(eng, d, 5000, n_iters=100)
+    hinted = feed_in_batches(eng, d, 4096, n_iters=100, expect_sites=300_000, expect_reads=6_000_000)
+    for g, h, w in zip(got, hinted, want):
+        assert np.array_equal(g, w) and np.array_equal(h, w)
+    small = synthetic.make_sites(50, (20, 60), seed=2)
+    w2 = eng.infer(small["X"], small["site_kmers"], small["off"], 30)
+    g2 = feed_in_batches(eng, small, 16, n_iters=30)
+    for g, w in zip(g2, w2):
+        assert np.array_equal(g, w)
+
+
+def test_job_stream_device_batches_and_job_offset(eng):
+    """Batches that already live on the GPU are read in place; a shard of a larger job (m6a_set_job_offset) streams
+    like any other job."""
+    import torch
+    d = synthetic.make_sites(6000, (20, 50), seed=4)
+    off = d["off"]
+    eng.set_stream(None)
+    want = eng.infer(d["X"], d["site_kmers"], off, 64)
+    X, km = torch.from_numpy(d["X"]).cuda(), torch.from_numpy(d["site_kmers"]).cuda()
+    eng.job_begin(64)
+    for s0 in range(0, 6000, 512):
+        s1 = min(6000, s0 + 512)
+        eng.job_feed(X[off[s0]:off[s1]], km[s0:s1], off[s0:s1 + 1] - off[s0])
+    rp, site, mod = eng.job_end()
+    assert rp.is_cuda and site.is_cuda
+    for g, w in zip((rp, site, mod), want):
+        assert np.array_equal(g.cpu().numpy(), w)
+    # mixed: host batches, then device batches, host outputs
+    eng.job_begin(64)
+    eng.job_feed(d["X"][:off[1000]], d["site_kmers"][:1000], off[:1001])
+    eng.job_feed(X[off[1000]:], km[1000:], off[1000:] - off[1000])
+    got = eng.job_end(device_outputs=False)
+    for g, w in zip(got, want):
+        assert np.array_equal(g, w)
+    # second half of the job as a shard of its own
+    from m6anet_amd.engine import shard_plan
+    cut = int(shard_plan(off, 2)[1])
+    eng.set_job_offset(cut)
+    try:
+        part = {"X": d["X"][off[cut]:], "site_kmers": d["site_kmers"][cut:], "off": off[cut:] - off[cut]}
+        got = feed_in_batches(eng, part, 16, n_iters=64)
+    finally:
+        eng.set_job_offset(0)
+    assert np.array_equal(got[1], want[1][cut:]) and np.array_equal(got[2], want[2][cut:])
+
+
+def test_job_stream_errors(eng):
+    d = synthetic.make_sites(40, 20, seed=1)
+    with pytest.raises(_lib.M6AError, match="no streaming job"):
+        eng.job_feed(d["X"], d["site_kmers"], d["off"])
+    with pytest.raises(_lib.M6AError, match="no streaming job"):
+        eng.job_end()
+    eng.job_begin(10)
+    with pytest.raises(_lib.M6AError, match="streaming job is open"):
+        eng.infer(d["X"], d["site_kmers"], d["off"], 10)
+    with pytest.raises(_lib.M6AError, match="streaming job is open"):
+        eng.job_begin(10)
+    eng.job_feed(d["X"], d["site_kmers"], d["off"])
+    bad = d["off"].copy()
+    bad[0] = 1
+    with pytest.raises(_lib.M6AError) as e1:
+        eng._chk(eng._L.m6a_job_feed(eng._h, d["X"].ctypes.data, d["site_kmers"].ctypes.data, bad.ctypes.data, 40))
+    assert e1.value.code == -1
+    with pytest.raises(_lib.M6AError) as e2:                      # the job is void: feeds and the end report the first failure
+        eng.job_feed(d["X"], d["site_kmers"], d["off"])
+    assert e2.value.code == -1
+    with pytest.raises(_lib.M6AError):
+        eng.job_end()
+    got = feed_in_batches(eng, d, 16, n_iters=10)                 # and the context is usable again
+    want = eng.infer(d["X"], d["site_kmers"], d["off"], 10)
+    for g, w in zip(got, want):
+        assert np.array_equal(g, w)
+    eng.job_begin(10)
+    eng.job_abort()
+    assert eng.job_size() == (0, 0)
+    eng.job_begin(10)                                             # an empty job ends cleanly
+    rp, site, mod = eng.job_end()
+    assert rp.size == 0 and site.size == 0 and mod.size == 0
+    with pytest.raises(_lib.M6AError, match="does not fit a streaming chunk"):
+        big = synthetic.make_sites(1, 200_000, seed=1)
+        eng.job_begin(10)
+        try:
+            eng.job_feed(big["X"], big["site_kmers"], big["off"])
+        finally:
+            eng.job_abort()
+
+
+# ------------------------------------------------------------------ INTEGRATION.md, as written ---------------------
+def integration_stub():
+    text = open(os.path.join(REPO, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```python\n(.*?)```", text, flags=re.S)
+    stub = [b for b in blocks if "class HipModel" in b]
+    assert len(stub) == 1, "INTEGRATION.md must hold exactly one HipModel block"
+    return stub[0]
+
+
+def state_dict_of(w):
+    """The checkpoint a reference user would torch.load, rebuilt from the flat blob (include/m6a.h layout)."""
+    import torch
+    shapes = [("read_level_encoder.1.embedding_layer.weight", (66, 2)), ("read_level_encoder.3.layers.0.weight", (150, 15)),
+              ("read_level_encoder.3.layers.0.bias", (150,)), ("read_level_encoder.3.layers.1.weight", (150,)),
+              ("read_level_encoder.3.layers.1.bias", (150,)), ("read_level_encoder.3.layers.1.running_mean", (150,)),
+              ("read_level_encoder.3.layers.1.running_var", (150,)), ("read_level_encoder.4.layers.0.weight", (32, 150)),
+              ("read_level_encoder.4.layers.0.bias", (32,)), ("pooling_filter.probability_layer.0.weight", (1, 32)),
+              ("pooling_filter.probability_layer.0.bias", (1,))]
+    sd, at = {}, 0
+    for k, shp in shapes:
+        n = int(np.prod(shp))
+        sd[k] = torch.from_numpy(w[at:at + n].reshape(shp).copy())
+        at += n
+    assert at == w.size
+    return sd
+
+
+def test_integration_stub_as_written(golden, weights, monkeypatch):
+    """INTEGRATION.md section 1's hip_backend.py, executed verbatim, driven the way section 2 wires it into the
+    reference's loop on the bundled data: DataLoader-shaped batches of 16 sites (features (R,9) f32, kmers (R,3) int64
+    per READ, n_reads (S,) int64) -- streaming and call for call -- against the reference's captured outputs."""
+    import torch
+    monkeypatch.setenv("M6A_HIP_LIB", _lib.LIB_PATH)
+    _lib.load()                                   # one HIP runtime per process (see _lib._preload_hip_runtime)
+    ns = {}
+    exec(compile(integration_stub(), "INTEGRATION.md:hip_backend.py", "exec"), ns)
+    HipModel = ns["HipModel"]
+    b = golden("bundled_inputs.npz")
+    X, km, off = b["X"], b["site_kmers"], b["off"]
+    S = len(off) - 1
+    want_rp = golden("bundled_readprob.npz")["hct116"]
+    site_g = golden("bundled_site.npz")
+    model = HipModel(state_dict_of(weights["hct116"]))
+
+    def batches(bs):
+        for s0 in range(0, S, bs):
+            s1 = min(S, s0 + bs)
+            n_reads = torch.from_numpy(np.diff(off[s0:s1 + 1]))
+            kmers = torch.from_numpy(np.repeat(km[s0:s1].astype(np.int64), n_reads.numpy(), axis=0))
+            yield torch.from_numpy(X[off[s0]:off[s1]]), kmers, n_reads
+
+    keys = [k[:-5] for k in site_g.files if k.endswith("_site")]
+    assert len(keys) >= 6
+    import m6anet_amd.engine as E
+    probs = [want_rp[off[s]:off[s + 1]] for s in range(S)]
+    for key in keys:                              # e.g. T5_bs16_spb2_seed0: six full reference runs at n_processes=1
+        T, bs, spb, seed = (int(x) for x in re.match(r"T(\d+)_bs(\d+)_spb(\d+)_seed(\d+)", key).groups())
+        model.begin(T, THR, seed, bs, spb)
+        for f, k, n in batches(bs):
+            model.feed(f, k, n)
+        rp, site, mod = model.end()
+        assert np.allclose(rp, want_rp, rtol=1e-5, atol=1e-8), key
+        assert np.allclose(site, site_g[key + "_site"], rtol=0, atol=1e-5), key          # north_star's bar, end to end
+        # the reference's site probabilities come from ITS read probabilities: pool those for the bit-exact comparison
+        site2, mod2 = model.site_probabilities(probs, T, 20, THR, seed, bs, spb)
+        assert np.array_equal(site2, site_g[key + "_site"]), key
+        assert np.array_equal(mod2, site_g[key + "_mod"]), key
+    # call for call, the second wiring of section 2: one encoder call per batch, one pooling call per flush group
+    rp = np.concatenate([model.read_probabilities(f, k, n) for f, k, n in batches(16)])
+    assert np.allclose(rp, want_rp, rtol=1e-5, atol=1e-8)
+    goff = E.flush_groups(S, 16, 2)
+    for g0, g1 in zip(goff[:-1], goff[1:]):
+        site, mod = model.site_probabilities(probs[g0:g1], 5, 20, THR, 0, int(g1 - g0), 2)
+        assert np.array_equal(site, site_g["T5_bs16_spb2_seed0_site"][g0:g1])
+        assert np.array_equal(mod, site_g["T5_bs16_spb2_seed0_mod"][g0:g1])
+    ns["_L"].m6a_destroy(model._h)
