@@ -106,7 +106,7 @@ def live_traffic(workload, kernel_name, timeout_s=240):
         d = tempfile.mkdtemp(prefix="m6a_pmc_")
         try:
             cmd = ["rocprofv3", "--pmc", ctr, "--kernel-trace", "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
-                   "--workload", workload, "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-live-traffic"]
+                   "--workload", workload, "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-live-traffic", "--no-ragged-extra"]
             subprocess.run(cmd, capture_output=True, timeout=timeout_s, env=dict(os.environ, TMPDIR=os.environ.get("TMPDIR", "/tmp")))
             dbs = glob.glob(os.path.join(d, "**", "*_results.db"), recursive=True)
             if not dbs:
@@ -244,6 +244,295 @@ def _free_port():
     return p
 
 
+def measured_gather_ceiling(bag):
+    """The random-gather ceiling of a one-gather-per-draw pooling kernel on THIS box, measured now: tools/rg_probe
+    (tools/ragged_gather_probe.hip, built by __graft_entry__.build()) times nothing but ds_read_b32 gathers at random
+    indices of an n-entry LDS bag plus the multiplies, 8 waves per SIMD, for a ladder of n.  Every site draws T*K
+    times whatever its bag size, so the ceiling over a mix of sizes is the harmonic mean of the per-size rates."""
+    exe = os.path.join(REPO, "tools", "rg_probe")
+    if not os.path.exists(exe):
+        return None
+    try:
+        out = subprocess.run([exe], capture_output=True, text=True, timeout=120).stdout
+    except (subprocess.SubprocessError, OSError):
+        return None
+    pts = []
+    for line in out.splitlines():
+        f = line.split()
+        if line.startswith("ds_read_b32") and "gathers/s" in line:
+            try:
+                n = int(line.split("n=")[1].split()[0])
+                pts.append((n, float(f[f.index("T") - 1]) * 1e12))
+            except (ValueError, IndexError):
+                pass
+    if len(pts) < 2:
+        return None
+    pts.sort()
+    lo, hi = (bag, bag) if not isinstance(bag, tuple) else bag
+    ns = np.arange(lo, hi + 1)
+    inv = np.interp(ns, [p[0] for p in pts], [1.0 / p[1] for p in pts])
+    return {"rate": float(1.0 / inv.mean()), "points": {str(n): r / 1e12 for n, r in pts},
+            "source": "tools/rg_probe run by this bench (random ds_read_b32 gathers from an n-entry LDS bag, 8 waves/SIMD; "
+                      "harmonic mean over bag sizes %d..%d)" % (lo, hi)}
+
+
+def smi_snapshot():
+    """Clock and power as rocm-smi reports them right now (None if the tool is missing)."""
+    try:
+        o = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--json"], capture_output=True, text=True, timeout=20).stdout
+        d = json.loads(o)
+        card = d.get("card0") or next(iter(d.values()))
+        keep = {k: v for k, v in card.items() if any(t in k.lower() for t in ("sclk", "mclk", "power"))}
+        return keep or card
+    except Exception as e:                                   # noqa: BLE001 -- a diagnostic, never fatal
+        return {"error": repr(e)[:200]}
+
+
+class Bench:
+    """One workload on this rank: data resident in HBM, engine, the step, and the timed regions."""
+
+    def __init__(self, args, workload, S, bag, T, rank, world, local_rank, dev, backend):
+        import torch
+        from m6anet_amd import synthetic
+        from m6anet_amd.constants import DEFAULT_READ_THRESHOLD
+        from m6anet_amd.engine import M6ANetEngine, load_weights, shard_plan
+        self.torch, self.args, self.workload = torch, args, workload
+        self.S, self.bag, self.T, self.rank, self.world, self.dev, self.backend = S, bag, T, rank, world, dev, backend
+        self.spec = WORKLOADS[workload]
+        self.thr = np.float32(DEFAULT_READ_THRESHOLD)
+        self.weights = load_weights(self.spec["model"])
+        # this rank's shard of the world*S-site job: flush-group-aligned cut of the global site range, balanced by reads
+        self.n_reads_job = synthetic.bag_sizes(world * S, bag)
+        self.off_job = np.zeros(world * S + 1, np.int64)
+        np.cumsum(self.n_reads_job, out=self.off_job[1:])
+        self.cuts = shard_plan(self.off_job, world)
+        a, b = int(self.cuts[rank]), int(self.cuts[rank + 1])
+        d = synthetic.make_sites(b - a, seed=20250328 + rank, n_reads=self.n_reads_job[a:b])
+        self.X = torch.from_numpy(d["X"]).to(dev)
+        self.km = torch.from_numpy(d["site_kmers"]).to(dev)
+        self.off = torch.from_numpy(d["off"]).to(dev)
+        self.Sr, self.R = b - a, int(d["off"][-1])
+        self.off_host = np.ascontiguousarray(d["off"], dtype=np.int64)
+        self.host_offsets = os.environ.get("M6A_BENCH_HOST_OFFSETS", "1") != "0"
+        eng = M6ANetEngine(weights=self.weights, device=local_rank)
+        if args.enc_variant:
+            eng.set_encoder_variant(args.enc_variant)
+        if args.scan_driver:
+            eng.set_scan_driver(args.scan_driver)
+        eng.use_torch_stream()
+        eng.set_job_offset(a)
+        self.eng = eng
+        self.rp = torch.empty(self.R, dtype=torch.float32, device=dev)
+        self.site = torch.empty(self.Sr, dtype=torch.float32, device=dev)
+        self.mod = torch.empty(self.Sr, dtype=torch.float64, device=dev)
+        self.gather = None
+        self.dist = None
+        self.gather_kind = "none"
+
+    def compute(self):
+        # the loader's host copy of the CSR offsets rides along (every step: its statistics are recomputed from it on
+        # the host, the device array is checked against them on the GPU), so the call has nothing to read back and the
+        # steps queue back to back; M6A_BENCH_HOST_OFFSETS=0: the library reads the statistics back itself (one stream
+        # sync per step)
+        if self.host_offsets:
+            self.eng.set_host_offsets(self.off_host)
+        self.eng.infer(self.X, self.km, self.off, self.T, 20, self.thr, 0, 16, 2, out=(self.rp, self.site, self.mod))
+
+    def step(self):
+        self.compute()
+        if self.gather is not None:
+            if self.backend == "nccl":
+                self.gather.start(self.site, self.mod)
+            else:
+                self.eng.sync()
+                self.gather.start(self.site.cpu(), self.mod.cpu())
+
+    def fence(self):
+        if self.gather is not None:
+            self.gather.drain()          # every gather issued so far has completed
+        self.torch.cuda.synchronize(self.dev)
+        if self.dist is not None:
+            self.dist.barrier()
+            self.torch.cuda.synchronize(self.dev)
+
+    def timed(self, n):
+        self.fence()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            self.step()
+        self.fence()
+        return time.perf_counter() - t0
+
+    def max_over_ranks(self, *vals):
+        if self.dist is None:
+            return vals
+        t = self.torch.tensor(list(vals), dtype=self.torch.float64, device=self.dev if self.backend == "nccl" else "cpu")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return tuple(float(x) for x in t.tolist())
+
+    # the job's one exchange: site_prob + mod_ratio to rank 0, once per step, issued async and double-buffered so the
+    # exchange of step i overlaps the compute of step i+1.  Default: the C ABI's own RCCL communicator (m6a_gather, one
+    # grouped send/recv over xGMI); if the library cannot bind RCCL, or its self-test fails, torch.distributed's gather.
+    def setup_exchange(self, dist, mdist):
+        self.dist = dist
+        want = os.environ.get("M6A_BENCH_GATHER", "native")
+        why = None
+        if self.backend != "nccl":
+            self.gather = mdist.SiteGather(self.cuts, "cpu", dst=0)
+            self.gather_kind = self.backend
+            return
+        if want == "native":
+            # NativeGather's constructor and self-test are collective and end with the same verdict on every rank
+            try:
+                g = mdist.NativeGather(self.eng, self.cuts, self.dev, dst=0)
+                why = g.self_test()
+                if why is None:
+                    self.gather, self.gather_kind = g, "RCCL (m6a_gather: the C ABI's own communicator, one grouped send/recv)"
+                    return
+            except Exception as e:                           # noqa: BLE001 -- any failure here means: fall back
+                why = "%s: %s" % (type(e).__name__, str(e)[:200])
+            if self.rank == 0:
+                print("bench: native m6a_gather not usable (%s); falling back to torch.distributed's gather" % why, file=sys.stderr)
+        self.gather = mdist.SiteGather(self.cuts, self.dev, dst=0)
+        self.gather_kind = "RCCL (torch.distributed)" + ("; native m6a_gather unavailable -- %s" % why if why else "")
+
+    def run(self, steps, warmup, min_seconds=0.0):
+        """Cold call, warm-up, the timed region (HIP events around the encoder launches inside it), extra steps with
+        events around the pooling launches; optionally a sustained leg of at least `min_seconds`."""
+        eng = self.eng
+        # the cold call: whatever the context did not set up at creation (flush-group offsets, output staging, tables of
+        # bag sizes it could not know) is built inside
+        self.fence()
+        t0 = time.perf_counter()
+        self.step()
+        self.fence()
+        first_call_ms = (time.perf_counter() - t0) * 1e3
+        for _ in range(warmup):
+            self.step()
+        # HIP events around every launch of the dominant kernel (the encoder) inside the timed region -- roofline.achieved
+        # comes from them; the pooling kernel is timed the same way over a few extra steps after it (every pair of events
+        # costs the stream ~10 us per step, and the headline pays only for the pair it needs)
+        self.fence()
+        eng.profile("encoder")
+        dt = self.timed(steps)
+        enc_ms, enc_n = eng.profile_read(0)
+        eng.profile("pooling")
+        self.timed(min(steps, 10))
+        pool_ms, pool_n = eng.profile_read(1)
+        eng.profile(False)
+        eng.sync()
+        sustained = None
+        if min_seconds > 0:
+            smi, n_done, t_all = None, 0, 0.0
+            while t_all < min_seconds:
+                if smi is None and t_all >= 0.7 * min_seconds:
+                    # sample while the GPU is loaded: queue a leg, ask rocm-smi, then wait for the leg
+                    self.fence()
+                    t0 = time.perf_counter()
+                    for _ in range(steps):
+                        self.step()
+                    smi = smi_snapshot() if self.rank == 0 else {}
+                    self.fence()
+                    t_leg = time.perf_counter() - t0
+                else:
+                    t_leg = self.timed(steps)
+                t_all += t_leg
+                n_done += steps
+            t_all, = self.max_over_ranks(t_all)
+            sustained = {"seconds": t_all, "steps": n_done, "ms_per_step": t_all / n_done * 1e3, "rocm_smi_under_load": smi}
+        dt, first_call_ms = self.max_over_ranks(dt, first_call_ms)
+        return {"dt": dt, "first_call_ms": first_call_ms, "enc_ms": enc_ms, "enc_n": enc_n, "pool_ms": pool_ms, "pool_n": pool_n,
+                "sustained": sustained}
+
+    def verify(self):
+        """rank 0 recomputes the WHOLE job unsharded on its GPU and compares the gathered arrays bit for bit"""
+        from m6anet_amd import synthetic
+        from m6anet_amd.engine import M6ANetEngine
+        torch = self.torch
+        got = self.gather.finish() if self.gather is not None else (self.site, self.mod)
+        if self.rank != 0:
+            return None
+        parts = [synthetic.make_sites(int(self.cuts[r + 1] - self.cuts[r]), seed=20250328 + r,
+                                      n_reads=self.n_reads_job[int(self.cuts[r]):int(self.cuts[r + 1])]) for r in range(self.world)]
+        wX = torch.from_numpy(np.concatenate([p["X"] for p in parts])).to(self.dev)
+        wk = torch.from_numpy(np.concatenate([p["site_kmers"] for p in parts])).to(self.dev)
+        whole = M6ANetEngine(weights=self.weights, device=self.dev.index or 0)
+        _, w_site, w_mod = whole.infer(wX, wk, torch.from_numpy(self.off_job).to(self.dev), self.T, 20, self.thr, 0, 16, 2, want_read_probs=False)
+        whole.sync()
+        ok = bool(np.array_equal(got[0].cpu().numpy(), w_site.cpu().numpy()) and np.array_equal(got[1].cpu().numpy(), w_mod.cpu().numpy()))
+        whole.close()
+        return ok
+
+    def report(self, r, steps, traffic=True, gather_ceiling=True):
+        """The measured quantities of one workload as the keys of the bench line."""
+        eng, args, spec = self.eng, self.args, self.spec
+        world, S, T, bag, R, Sr = self.world, self.S, self.T, self.bag, self.R, self.Sr
+        total_sites = int(self.cuts[-1])
+        enc_avg_ms = r["enc_ms"] / max(r["enc_n"], 1)
+        pool_avg_ms = r["pool_ms"] / max(r["pool_n"], 1)
+        enc_tflops = ENC_FLOP_PER_READ * R / (enc_avg_ms * 1e-3) / 1e12
+        enc_gbps = ENC_BYTES_PER_READ * R / (enc_avg_ms * 1e-3) / 1e9
+        draws = Sr * T * 20
+        enc_kernel = {"csite12": "enc_csite_kernel", "general16": "enc_kernel"}.get(eng.last_encoder_variant, "enc_kernel")
+        tr = None
+        if world == 1 and traffic:
+            default_shape = S == spec["sites"] and T == 1000 and (self.workload == "ragged" or bag == spec["bag"])
+            if default_shape and not args.no_live_traffic:
+                tr = live_traffic(self.workload, enc_kernel)
+            if tr is None:
+                tr = measured_traffic(S, bag)
+                if tr is not None:
+                    tr = dict(tr, source="%s (%s) -- committed, not measured by this run" % (tr["file"], tr["source"]))
+        pool_kernel = {"table-reg": "pool_reg_kernel", "table": "pool_table_kernel", "ragged-table": "pool_rtab_kernel"}.get(
+            eng.last_pool_variant, "pool_scan_kernels")
+        proof = pool_roofline(eng.last_pool_variant, draws, pool_avg_ms, r["pool_n"])
+        if gather_ceiling and eng.last_pool_variant == "ragged-table" and self.rank == 0:
+            m = measured_gather_ceiling(bag)
+            if m is not None and proof["achieved"]:
+                proof["measured_ceiling"] = {"peak": m["rate"] / 1e12, "unit": "T draws/s", "frac": proof["achieved"] * 1e12 / m["rate"],
+                                             "source": m["source"], "T_gathers_per_s_by_bag_size": m["points"]}
+        value = total_sites * steps / r["dt"]
+        out = {
+            "value": value,
+            "ms_per_step": r["dt"] / steps * 1e3,
+            "first_call_ms": r["first_call_ms"],
+            # a real job is ONE call on a fresh context: sites / the cold call (what m6a_create did not prepare is inside)
+            "value_one_shot": total_sites / (r["first_call_ms"] * 1e-3),
+            "roofline": {"kernel": "read encoder (%s)" % eng.last_encoder_variant, "bound": "mfma", "achieved": enc_tflops,
+                         "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": enc_tflops / PEAK_F32_TFLOPS,
+                         "traffic": tr["traffic_bytes_per_launch"] if tr else None,
+                         "traffic_source": tr["source"] if tr else None,
+                         "algorithmic_bytes_per_launch": ENC_BYTES_PER_READ * R,
+                         "avg_launch_ms": enc_avg_ms, "launches": r["enc_n"],
+                         "algorithmic_flop_per_read": ENC_FLOP_PER_READ, "reads_per_launch": R,
+                         "hbm_view": {"achieved": enc_gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                                      "frac": enc_gbps / PEAK_HBM_GBPS, "algorithmic_bytes_per_read": ENC_BYTES_PER_READ}},
+            "pool_roofline": proof,
+            "kernels": {enc_kernel: {"avg_ms": enc_avg_ms, "launches": r["enc_n"]},
+                        pool_kernel: {"avg_ms": pool_avg_ms, "launches": r["pool_n"], "timed_in": "extra steps after the timed region",
+                                      "Gdraws_per_s": draws / (pool_avg_ms * 1e-3) / 1e9 if pool_avg_ms else None}},
+        }
+        if r["sustained"]:
+            su = r["sustained"]
+            out["value_sustained"] = total_sites * su["steps"] / su["seconds"]
+            out["sustained"] = su
+        return out
+
+    def config(self):
+        spec, bag, world = self.spec, self.bag, self.world
+        bag_txt = "%d reads" % bag if not isinstance(bag, tuple) else "%d..%d reads" % bag
+        return {"workload": "synthetic %d DRACH sites x %s per GPU, %s weights, num_iterations=%d, numpy-stream replay "
+                            "(batch_size 16, save_per_batch 2, seed 0); %s%s"
+                            % (self.S, bag_txt, spec["model"], self.T, spec["config"],
+                               " x%d GPUs%s" % (world, " (configs[3])" if self.workload == "uniform" else " (configs[4])") if world > 1 else ""),
+                "sites_per_gpu": self.S, "reads_per_site": list(bag) if isinstance(bag, tuple) else bag, "reads_rank0": self.R,
+                "num_iterations": self.T,
+                "bag_statistics": "host copy of off[] per step, device-checked (m6a_set_host_offsets)" if self.host_offsets else "read back per step",
+                "pool_kernel": self.eng.last_pool_variant, "encoder_kernel": self.eng.last_encoder_variant,
+                "sharding": "contiguous flush-group-aligned site shards balanced by reads, 1 gather of site_prob + mod_ratio to rank 0 per step "
+                            "over %s" % self.gather_kind if self.gather is not None else "none"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -253,7 +542,12 @@ def main():
     ap.add_argument("--sites", type=int, default=None, help="sites per GPU (default: the workload's)")
     ap.add_argument("--reads", type=int, default=None, help="uniform workload: reads per site (default 20)")
     ap.add_argument("--iters", type=int, default=1000, help="num_iterations")
+    ap.add_argument("--min-seconds", type=float, default=0.0,
+                    help="after the timed region keep stepping for at least this long and report value_sustained plus rocm-smi's "
+                         "clock / power under load (the K-step region is tens of milliseconds: inside one DVFS window)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ragged-extra", action="store_true",
+                    help="default run only: skip the extra `ragged` key (configs[4]'s per-GPU shape, ~10 steps after the headline)")
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="do not re-run under rocprofv3 for roofline.traffic; quote the committed profiles/*_enc_traffic.json instead")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
@@ -274,194 +568,148 @@ def main():
                "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(subprocess.call(cmd))
 
-    import torch
-    from m6anet_amd import dist as mdist, synthetic
-    from m6anet_amd.constants import DEFAULT_READ_THRESHOLD
-    from m6anet_amd.engine import M6ANetEngine, load_weights, shard_plan
-
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    backend = os.environ.get("M6A_BENCH_BACKEND", "nccl")
-    if backend != "nccl":
-        local_rank %= max(torch.cuda.device_count(), 1)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        mdist.init_from_env(backend, device_id=dev if backend == "nccl" else None)
 
     spec = WORKLOADS[args.workload]
     S = args.sites or spec["sites"]
     bag = spec["bag"] if args.workload == "ragged" else (args.reads or spec["bag"])
     T = args.iters
-    thr = np.float32(DEFAULT_READ_THRESHOLD)
-    weights = load_weights(spec["model"])
+    line = {"metric": "DRACH sites/sec at num_iterations=%d" % T, "value": None, "unit": "sites/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": {"workload": "%s (%s)" % (args.workload, spec["config"])}}
+    printed = []
 
-    # this rank's shard of the world*S-site job: flush-group-aligned cut of the global site range, balanced by reads
-    n_reads_job = synthetic.bag_sizes(world * S, bag)
-    off_job = np.zeros(world * S + 1, np.int64)
-    np.cumsum(n_reads_job, out=off_job[1:])
-    cuts = shard_plan(off_job, world)
-    a, b = int(cuts[rank]), int(cuts[rank + 1])
-    d = synthetic.make_sites(b - a, seed=20250328 + rank, n_reads=n_reads_job[a:b])
-    X = torch.from_numpy(d["X"]).to(dev)
-    km = torch.from_numpy(d["site_kmers"]).to(dev)
-    off = torch.from_numpy(d["off"]).to(dev)
-    Sr, R = b - a, int(d["off"][-1])
+    def emit(error=None):
+        """rank 0's ONE JSON line -- also when the run does not get to its end (a rank died, an exchange hung): the
+        driver then still reads what was measured and why the rest is missing."""
+        if rank != 0 or printed:
+            return
+        printed.append(1)
+        if error:
+            line["error"] = error
+        print(json.dumps(line), flush=True)
 
-    eng = M6ANetEngine(weights=weights, device=local_rank)
-    if args.enc_variant:
-        eng.set_encoder_variant(args.enc_variant)
-    if args.scan_driver:
-        eng.set_scan_driver(args.scan_driver)
-    eng.use_torch_stream()
-    eng.set_job_offset(a)
-    rp = torch.empty(R, dtype=torch.float32, device=dev)
-    site = torch.empty(Sr, dtype=torch.float32, device=dev)
-    mod = torch.empty(Sr, dtype=torch.float64, device=dev)
-    # the job's one exchange: site_prob + mod_ratio to rank 0, one packed gather per step (RCCL);
-    # issued async and double-buffered so the exchange of step i overlaps the compute of step i+1
-    # (M6A_BENCH_GATHER=native: the same exchange on the C ABI's own RCCL communicator, m6a_gather)
-    native_gather = os.environ.get("M6A_BENCH_GATHER", "torch") == "native" and backend == "nccl"
-    if world > 1 and native_gather:
-        gather = mdist.NativeGather(eng, cuts, dev, dst=0)
-    else:
-        gather = mdist.SiteGather(cuts, dev if backend == "nccl" else "cpu", dst=0) if world > 1 else None
+    # Fail-safe for the multi-rank run: torch.distributed.run terminates every rank when one of them dies, and a stuck
+    # exchange never returns.  A watchdog thread prints rank 0's line with what is known and leaves with a non-zero code,
+    # on SIGTERM or at the deadline.  The signal reaches it through the wake-up descriptor: the main thread may be blocked
+    # inside a collective (no Python handler runs there), the C-level handler still writes the signal number to the socket.
+    import signal
+    import threading
+    deadline = float(os.environ.get("M6A_BENCH_TIMEOUT", "1500"))
+    done = threading.Event()
+    rsock, wsock = socket.socketpair()
+    wsock.setblocking(False)
 
-    off_host = np.ascontiguousarray(d["off"], dtype=np.int64)
-    host_offsets = os.environ.get("M6A_BENCH_HOST_OFFSETS", "1") != "0"
+    def watchdog():
+        rsock.settimeout(deadline)
+        try:
+            data = rsock.recv(1)
+        except socket.timeout:
+            emit("watchdog: no result after %.0f s (M6A_BENCH_TIMEOUT); a rank or an exchange is stuck" % deadline)
+            os._exit(3)
+        if done.is_set():
+            return
+        emit("terminated by the launcher (signal %d): another rank failed" % (data[0] if data else 0))
+        os._exit(4)
 
-    def step():
-        # the loader's host copy of the CSR offsets rides along (every step: its statistics are recomputed from it on
-        # the host, the device array is checked against them on the GPU), so the call has nothing to read back and the
-        # steps queue back to back; M6A_BENCH_HOST_OFFSETS=0: the library reads the statistics back itself (one stream
-        # sync per step)
-        if host_offsets:
-            eng.set_host_offsets(off_host)
-        eng.infer(X, km, off, T, 20, thr, 0, 16, 2, out=(rp, site, mod))
+    if world > 1:
+        signal.signal(signal.SIGTERM, lambda signum, frame: None)
+        signal.set_wakeup_fd(wsock.fileno(), warn_on_full_buffer=False)
+        threading.Thread(target=watchdog, daemon=True).start()
+
+    def finish():
+        done.set()
+        try:
+            wsock.send(b"\0")
+        except OSError:
+            pass
+
+    try:
+        run(args, line, rank, world, local_rank, S, bag, T)
+    except BaseException as e:                                # noqa: BLE001 -- the line must come out whatever happened
+        if isinstance(e, SystemExit) and not e.code:
+            raise
+        import traceback
+        traceback.print_exc()
+        emit("%s: %s" % (type(e).__name__, str(e)[:400]))
+        finish()
+        sys.stdout.flush()
+        sys.stderr.flush()
         if world > 1:
-            if backend == "nccl":
-                gather.start(site, mod)
-            else:
-                eng.sync()
-                gather.start(site.cpu(), mod.cpu())
+            os._exit(1)
+        sys.exit(1)
+    finish()
+    emit()
 
-    def fence():
-        if gather is not None:
-            gather.drain()          # every gather issued so far has completed
+
+def run(args, line, rank, world, local_rank, S, bag, T):
+    import torch
+    from m6anet_amd import dist as mdist
+
+    backend = os.environ.get("M6A_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    b = Bench(args, args.workload, S, bag, T, rank, world, local_rank, dev, backend)
+    line["config"] = b.config()
+    # M6A_BENCH_FORCE_EXCHANGE=1 (under a launcher's environment): form the process group and run the exchange at world
+    # size 1 too -- the one-GPU test box drives the RCCL leg of the N-GPU run that way
+    multi = world > 1 or (os.environ.get("M6A_BENCH_FORCE_EXCHANGE") == "1" and "RANK" in os.environ)
+    if multi:
+        # before any rank depends on another: this rank's own cold call and a few compute-only steps
+        t0 = time.perf_counter()
+        b.compute()
         torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize(dev)
+        cold = (time.perf_counter() - t0) * 1e3
+        t0 = time.perf_counter()
+        for _ in range(5):
+            b.compute()
+        torch.cuda.synchronize(dev)
+        local_ms = (time.perf_counter() - t0) / 5 * 1e3
+        line["rank0_local"] = {"cold_call_ms": cold, "ms_per_step": local_ms, "sites_per_s": b.Sr / (local_ms * 1e-3),
+                               "note": "rank 0's own shard, no exchange, measured before the process group is formed"}
+        import torch.distributed as dist
+        mdist.init_from_env(backend, device_id=dev if backend == "nccl" else None)
+        b.setup_exchange(dist, mdist)
+        line["config"] = b.config()
 
-    # the cold call: MT19937 stream / index tables are built for this (seed, T, bag sizes), then cached
-    fence()
-    t0 = time.perf_counter()
-    step()
-    fence()
-    first_call_ms = (time.perf_counter() - t0) * 1e3
-    for _ in range(args.warmup):
-        step()
-    fence()
-    # HIP events around every launch of the dominant kernel (the encoder) inside the timed region -- roofline.achieved comes
-    # from them; the pooling kernel is timed the same way over a few extra steps after it (every pair of events costs
-    # the stream ~10 us per step, and the headline pays only for the pair it needs)
-    eng.profile("encoder")
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
-    enc_ms, enc_n = eng.profile_read(0)
-    eng.profile("pooling")
-    for _ in range(min(args.steps, 10)):
-        step()
-    fence()
-    pool_ms, pool_n = eng.profile_read(1)
-    eng.profile(False)
-    eng.sync()
-    if world > 1:
-        tmax = torch.tensor([dt, first_call_ms], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt, first_call_ms = float(tmax[0].item()), float(tmax[1].item())
-
-    verified = None
-    if args.verify:
-        got = gather.finish() if gather is not None else (site, mod)
-        if rank == 0:
-            parts = [synthetic.make_sites(int(cuts[r + 1] - cuts[r]), seed=20250328 + r, n_reads=n_reads_job[int(cuts[r]):int(cuts[r + 1])])
-                     for r in range(world)]
-            wX = torch.from_numpy(np.concatenate([p["X"] for p in parts])).to(dev)
-            wk = torch.from_numpy(np.concatenate([p["site_kmers"] for p in parts])).to(dev)
-            whole = M6ANetEngine(weights=weights, device=local_rank)
-            _, w_site, w_mod = whole.infer(wX, wk, torch.from_numpy(off_job).to(dev), T, 20, thr, 0, 16, 2, want_read_probs=False)
-            whole.sync()
-            verified = bool(np.array_equal(got[0].cpu().numpy(), w_site.cpu().numpy()) and
-                            np.array_equal(got[1].cpu().numpy(), w_mod.cpu().numpy()))
-            whole.close()
-
+    if os.environ.get("M6A_BENCH_TEST_KILL_RANK") == str(rank):   # test hook: this rank dies before the timed region
+        os._exit(9)
+    r = b.run(args.steps, args.warmup, args.min_seconds)
+    if multi:
+        # every rank made its cold call alone above; what run() timed first was only the first call WITH the exchange
+        r["first_call_ms"], = b.max_over_ranks(cold)
+    verified = b.verify() if args.verify else None
     if rank == 0:
-        total_sites = int(cuts[-1])
-        enc_avg_ms = enc_ms / max(enc_n, 1)
-        pool_avg_ms = pool_ms / max(pool_n, 1)
-        enc_tflops = ENC_FLOP_PER_READ * R / (enc_avg_ms * 1e-3) / 1e12
-        enc_gbps = ENC_BYTES_PER_READ * R / (enc_avg_ms * 1e-3) / 1e9
-        draws = Sr * T * 20
-        bag_txt = "%d reads" % bag if not isinstance(bag, tuple) else "%d..%d reads" % bag
-        enc_kernel = {"csite12": "enc_csite_kernel", "general16": "enc_kernel"}.get(eng.last_encoder_variant, "enc_kernel")
-        tr = None
-        if world == 1:
-            default_shape = S == spec["sites"] and T == 1000 and (args.workload == "ragged" or bag == spec["bag"])
-            if default_shape and not args.no_live_traffic:
-                tr = live_traffic(args.workload, enc_kernel)
-            if tr is None:
-                tr = measured_traffic(S, bag)
-                if tr is not None:
-                    tr = dict(tr, source="%s (%s) -- committed, not measured by this run" % (tr["file"], tr["source"]))
-        pool_kernel = {"table-reg": "pool_reg_kernel", "table": "pool_table_kernel", "ragged-table": "pool_rtab_kernel"}.get(
-            eng.last_pool_variant, "pool_scan_kernels")
-        out = {
-            "metric": "DRACH sites/sec at num_iterations=%d" % T,
-            "value": total_sites * args.steps / dt,
-            "unit": "sites/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "synthetic %d DRACH sites x %s per GPU, %s weights, num_iterations=%d, numpy-stream replay "
-                                   "(batch_size 16, save_per_batch 2, seed 0); %s%s"
-                                   % (S, bag_txt, spec["model"], T, spec["config"],
-                                      " x%d GPUs%s" % (world, " (configs[3])" if args.workload == "uniform" else " (configs[4])") if world > 1 else ""),
-                       "sites_per_gpu": S, "reads_per_site": list(bag) if isinstance(bag, tuple) else bag, "reads_rank0": R,
-                       "num_iterations": T, "bag_statistics": "host copy of off[] per step, device-checked (m6a_set_host_offsets)" if host_offsets else "read back per step",
-                       "pool_kernel": eng.last_pool_variant, "encoder_kernel": eng.last_encoder_variant,
-                       "sharding": "contiguous flush-group-aligned site shards balanced by reads, 1 %s gather/step"
-                                   % (("RCCL (m6a_gather)" if native_gather else "RCCL (torch.distributed)") if backend == "nccl" else backend)
-                                   if world > 1 else "none"},
-            "first_call_ms": first_call_ms,
-            "verify": verified,
-            "roofline": {"kernel": "read encoder (%s)" % eng.last_encoder_variant, "bound": "mfma", "achieved": enc_tflops,
-                         "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": enc_tflops / PEAK_F32_TFLOPS,
-                         "traffic": tr["traffic_bytes_per_launch"] if tr else None,
-                         "traffic_source": tr["source"] if tr else None,
-                         "algorithmic_bytes_per_launch": ENC_BYTES_PER_READ * R,
-                         "avg_launch_ms": enc_avg_ms, "launches": enc_n,
-                         "algorithmic_flop_per_read": ENC_FLOP_PER_READ, "reads_per_launch": R,
-                         "hbm_view": {"achieved": enc_gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                                      "frac": enc_gbps / PEAK_HBM_GBPS, "algorithmic_bytes_per_read": ENC_BYTES_PER_READ}},
-            "pool_roofline": pool_roofline(eng.last_pool_variant, draws, pool_avg_ms, pool_n),
-            "kernels": {enc_kernel: {"avg_ms": enc_avg_ms, "launches": enc_n},
-                        pool_kernel: {"avg_ms": pool_avg_ms, "launches": pool_n, "timed_in": "extra steps after the timed region",
-                                      "Gdraws_per_s": draws / (pool_avg_ms * 1e-3) / 1e9 if pool_avg_ms else None}},
-        }
+        rep = b.report(r, args.steps)
+        line.update({"value": rep.pop("value"), "ms_per_step": rep.pop("ms_per_step"), "config": b.config(),
+                     "first_call_ms": rep.pop("first_call_ms"), "value_one_shot": rep.pop("value_one_shot"), "verify": verified})
+        line.update(rep)
+        default_run = (world == 1 and args.workload == "uniform" and S == WORKLOADS["uniform"]["sites"] and T == 1000 and
+                       bag == WORKLOADS["uniform"]["bag"])
+        if default_run and not args.no_ragged_extra:
+            # the path real data takes (bags are never uniform), in the same record: configs[4]'s per-GPU shape
+            del b.X, b.rp
+            b.eng.close()
+            torch.cuda.empty_cache()
+            rs = WORKLOADS["ragged"]
+            rb = Bench(args, "ragged", rs["sites"], rs["bag"], 1000, 0, 1, local_rank, dev, backend)
+            rr = rb.run(10, 3, args.min_seconds)
+            rg = rb.report(rr, 10, traffic=False)
+            rg["config"] = rb.config()
+            rg["steps"], rg["warmup"] = 10, 3
+            line["ragged"] = rg
+            rb.eng.close()
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = run_cpu_baseline_subprocess(args.workload, T)
-        print(json.dumps(out), flush=True)
-    if world > 1:
+            line["cpu_baseline"] = run_cpu_baseline_subprocess(args.workload, T)
+    if multi:
+        import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
 

@@ -234,6 +234,7 @@ struct m6a_ctx {
     // host-pointer staging
     DevBuf sX, sK, sOff, sP, sSite, sMod, val_idx, val_y, val_avg, sOffChunk;
     Staging stg;
+    int rt_presize = 0;                       // warm_default: allocate the index-table arena for this many bag sizes
     uint32_t rt_credit_seed = 0; int64_t rt_credit_A = 0, rt_credit = 0;   // sites pooled on the scan kernels while tables were missing
     // streaming job (m6a_job_begin / m6a_job_feed / m6a_job_end): the reference's batch loop fed as it is produced
     struct Job {
@@ -256,6 +257,7 @@ struct m6a_ctx {
     } job;
     DevBuf gSite, gMod, gP;                   // host-pointer m6a_gather / m6a_gather_reads: what rank dst receives
     DevBuf jX, jP, jOff;                      // device sub-slots; read probabilities [R] and CSR offsets [S+1] of the job
+    std::thread warm;                         // m6a_create's background set-up for the default job parameters (settle() joins it)
     void *comm = nullptr;                     // ncclComm_t
     int comm_rank = 0, comm_world = 0;
     Profiler prof;
@@ -621,7 +623,7 @@ int ensure_rtab(m6a_ctx *c, uint32_t seed, int T, int K, int64_t gmax, const uin
     const int want = (fresh ? 1 : rt.used) + (int)todo.size();
     if (fresh || want > rt.cap) {
         int new_cap = std::max(want, fresh ? 0 : rt.cap * 2);
-        new_cap = std::min(std::max(new_cap, 32), M6A_RTAB_MAX_N + 1);
+        new_cap = std::min(std::max(new_cap, std::max(32, c->rt_presize)), M6A_RTAB_MAX_N + 1);
         size_t free_b = 0, total_b = 0;
         HIPCHK(c, hipMemGetInfo(&free_b, &total_b));
         const size_t held = fresh ? 0 : (size_t)rt.cap * slot_bytes;
@@ -1241,16 +1243,20 @@ Rccl *rccl()
     static Rccl r;
     static std::once_flag once;
     std::call_once(once, [] {
+        // M6A_RCCL_LIB names THE copy to use (nothing else is tried); otherwise the usual names
         std::vector<std::string> names;
-        if (const char *e = getenv("M6A_RCCL_LIB")) names.push_back(e);
-        for (const char *n : {"librccl.so.1", "librccl.so"}) names.push_back(n);
-        names.push_back("/opt/rocm/lib/librccl.so.1");
+        const char *e = getenv("M6A_RCCL_LIB");
+        if (e && *e) names.push_back(e);
+        else {
+            for (const char *n : {"librccl.so.1", "librccl.so"}) names.push_back(n);
+            names.push_back("/opt/rocm/lib/librccl.so.1");
+        }
         for (size_t i = 0; i < names.size() && !r.h; i++) {
             // a copy that is already mapped (e.g. PyTorch's) wins: it is bound to the process's HIP runtime
             r.h = dlopen(names[i].c_str(), RTLD_NOW | RTLD_NOLOAD);
         }
         for (size_t i = 0; i < names.size() && !r.h; i++) r.h = dlopen(names[i].c_str(), RTLD_NOW | RTLD_LOCAL);
-        if (!r.h) { r.err = "librccl not found (set M6A_RCCL_LIB)"; return; }
+        if (!r.h) { r.err = e && *e ? std::string("cannot load M6A_RCCL_LIB=") + e : std::string("librccl not found (set M6A_RCCL_LIB)"); return; }
         auto sym = [&](const char *n) { void *p = dlsym(r.h, n); if (!p && r.err.empty()) r.err = std::string("librccl lacks ") + n; return p; };
         r.GetUniqueId = (int (*)(RcclId *))sym("ncclGetUniqueId");
         r.CommInitRank = (int (*)(void **, int, RcclId, int))sym("ncclCommInitRank");
@@ -1549,6 +1555,37 @@ int sync_and_check(m6a_ctx *c)
     return M6A_OK;
 }
 
+// Every entry point that touches the stream or the sampling state waits for m6a_create's background set-up first.
+inline void settle(m6a_ctx *c) { if (c && c->warm.joinable()) c->warm.join(); }
+
+// Background half of m6a_create: everything a first call with the reference's DEFAULT job parameters would otherwise
+// build inside the call -- seed 0 (scripts/inference.py:60), num_iterations 1000 (:56), 20 samples
+// (inference_utils.py:54), batch_size 16 x save_per_batch 2 (:46-50) -> flush groups of <= 32 sites: the pairwise-sum
+// plan, the MT19937 stream, the index-table arena (sized for M6A_WARM_SLOTS bag sizes, default 512: 1.4 GB of a 288 GB
+// part) and the tables of the smallest legal bag (min_reads = 20, constants.py:14).  Runs on the side stream from its
+// own thread, so neither m6a_create nor the caller's loader waits for it; a first call with other parameters simply
+// rebuilds what differs, exactly as before.  M6A_WARMUP=0 turns it off.
+void warm_default(m6a_ctx *c)
+{
+    if (hipSetDevice(c->device) != hipSuccess) { (void)hipGetLastError(); return; }
+    const uint32_t seed = 0;
+    const int T = 1000, K = 20, n = 20;
+    const int64_t gmax = 32;
+    hipStream_t main_stream = c->stream;
+    c->stream = c->s_prep;
+    int rc = ensure_mean_plan(c, T);
+    if (!rc) rc = ensure_raw(c, seed, stream_need(gmax, T, K));
+    if (!rc) {
+        const char *e = getenv("M6A_WARM_SLOTS");
+        c->rt_presize = e && atoi(e) > 0 ? std::min(atoi(e), M6A_RTAB_MAX_N + 1) : 512;
+        rc = ensure_table_reg(c, seed, n, T, K, (int)gmax);
+        c->rt_presize = 0;
+    }
+    (void)hipStreamSynchronize(c->s_prep);
+    c->stream = main_stream;
+    if (rc) { c->tab_reg_key.valid = false; c->err.clear(); }   // not an error of anybody's call: the first call builds what it needs
+}
+
 }  // namespace
 
 // =================================================================================================
@@ -1620,6 +1657,10 @@ int m6a_create(m6a_ctx **out, const float *weights, size_t n_floats, int device_
     CRCHK(hipHostMalloc((void **)&c->h_ctl, kCtlWords * 4, hipHostMallocDefault));
     for (int n = 0; n <= M6A_RTAB_MAX_N; n++) c->rt.slot_of_n[n] = -1;
 #undef CRCHK
+    const char *w = getenv("M6A_WARMUP");
+    if (!(w && w[0] == '0')) {
+        try { c->warm = std::thread(warm_default, c); } catch (...) { /* no thread: the first call sets up what it needs */ }
+    }
     *out = c;
     return M6A_OK;
 }
@@ -1627,6 +1668,7 @@ int m6a_create(m6a_ctx **out, const float *weights, size_t n_floats, int device_
 void m6a_destroy(m6a_ctx *c)
 {
     if (!c) return;
+    settle(c);
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (int k = 0; k < 2; k++) {
@@ -1663,6 +1705,7 @@ void m6a_destroy(m6a_ctx *c)
 
 int m6a_set_stream(m6a_ctx *c, void *hip_stream)
 {
+    settle(c);
     if (!c) return M6A_EINVAL;
     c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
     return M6A_OK;
@@ -1712,6 +1755,7 @@ int m6a_set_table_variant(m6a_ctx *c, int mode)
 
 int m6a_sync(m6a_ctx *c)
 {
+    settle(c);
     if (!c) return M6A_EINVAL;
     HIPCHK(c, hipSetDevice(c->device));
     return sync_and_check(c);
@@ -1719,6 +1763,7 @@ int m6a_sync(m6a_ctx *c)
 
 int m6a_prepare_host_io(m6a_ctx *c)
 {
+    settle(c);
     if (!c) return M6A_EINVAL;
     HIPCHK(c, hipSetDevice(c->device));
     return ensure_staging(c);
@@ -1726,6 +1771,7 @@ int m6a_prepare_host_io(m6a_ctx *c)
 
 int m6a_encode_reads(m6a_ctx *c, const float *X, const uint8_t *km, const int64_t *off, int64_t S, float *rp)
 {
+    settle(c);
     HintScope hint_scope(c);
     if (c && c->job.open) return job_busy(c);
     if (!c) return M6A_EINVAL;
@@ -1757,6 +1803,7 @@ int m6a_encode_reads(m6a_ctx *c, const float *X, const uint8_t *km, const int64_
 int m6a_site_pool(m6a_ctx *c, const float *rp, const int64_t *off, int64_t S, int T, int K, float thr,
                   uint32_t seed, int rng_mode, int64_t bs, int64_t spb, float *site, double *mod)
 {
+    settle(c);
     HintScope hint_scope(c);
     if (c && c->job.open) return job_busy(c);
     int rc = check_pool_args(c, S, T, K, rng_mode, bs, spb);
@@ -1793,6 +1840,7 @@ int m6a_site_pool(m6a_ctx *c, const float *rp, const int64_t *off, int64_t S, in
 int m6a_infer(m6a_ctx *c, const float *X, const uint8_t *km, const int64_t *off, int64_t S, int T, int K,
               float thr, uint32_t seed, int rng_mode, int64_t bs, int64_t spb, float *rp, float *site, double *mod)
 {
+    settle(c);
     HintScope hint_scope(c);
     if (c && c->job.open) return job_busy(c);
     int rc = check_pool_args(c, S, T, K, rng_mode, bs, spb);
@@ -1838,6 +1886,7 @@ int m6a_infer(m6a_ctx *c, const float *X, const uint8_t *km, const int64_t *off,
 int m6a_job_begin(m6a_ctx *c, int T, int K, float thr, uint32_t seed, int rng_mode, int64_t bs, int64_t spb,
                   int64_t expect_sites, int64_t expect_reads)
 {
+    settle(c);
     int rc = check_pool_args(c, 0, T, K, rng_mode, bs, spb);
     if (rc) return rc;
     HintScope hint_scope(c);
@@ -1868,6 +1917,7 @@ int m6a_job_begin(m6a_ctx *c, int T, int K, float thr, uint32_t seed, int rng_mo
 
 int m6a_job_feed(m6a_ctx *c, const float *X, const uint8_t *km, const int64_t *off, int64_t n_sites)
 {
+    settle(c);
     if (!c) return M6A_EINVAL;
     auto &j = c->job;
     if (!j.open) return fail(c, M6A_EINVAL, "no streaming job is open (m6a_job_begin)");
@@ -1895,6 +1945,7 @@ int m6a_job_size(const m6a_ctx *c, int64_t *n_sites, int64_t *n_reads)
 
 int m6a_job_abort(m6a_ctx *c)
 {
+    settle(c);
     if (!c) return M6A_EINVAL;
     if (!c->job.open) return M6A_OK;
     c->job.open = false;
@@ -1906,6 +1957,7 @@ int m6a_job_abort(m6a_ctx *c)
 
 int m6a_job_end(m6a_ctx *c, float *rp, float *site, double *mod)
 {
+    settle(c);
     if (!c) return M6A_EINVAL;
     auto &j = c->job;
     if (!j.open) return fail(c, M6A_EINVAL, "no streaming job is open (m6a_job_begin)");
@@ -1943,6 +1995,7 @@ int m6a_job_end(m6a_ctx *c, float *rp, float *site, double *mod)
 
 int m6a_bag_forward(m6a_ctx *c, const float *X, const uint8_t *km, int64_t B, int bag, float *site)
 {
+    settle(c);
     HintScope hint_scope(c);
     if (c && c->job.open) return job_busy(c);
     if (!c) return M6A_EINVAL;
@@ -2085,6 +2138,7 @@ int check_validate_args(m6a_ctx *c, int64_t S, int T, int K)
 int m6a_validate_pool(m6a_ctx *c, const float *rp, const int64_t *off, int64_t S, int T, int K, uint32_t seed,
                       float *y, float *avg)
 {
+    settle(c);
     HintScope hint_scope(c);
     if (c && c->job.open) return job_busy(c);
     int rc = check_validate_args(c, S, T, K);
@@ -2121,6 +2175,7 @@ int m6a_validate_pool(m6a_ctx *c, const float *rp, const int64_t *off, int64_t S
 int m6a_validate(m6a_ctx *c, const float *X, const uint8_t *km, const int64_t *off, int64_t S, int T, int K,
                  uint32_t seed, float *rp, float *y, float *avg)
 {
+    settle(c);
     HintScope hint_scope(c);
     if (c && c->job.open) return job_busy(c);
     int rc = check_validate_args(c, S, T, K);
@@ -2222,6 +2277,7 @@ int m6a_comm_unique_id(void *id_out)
 
 int m6a_comm_init(m6a_ctx *c, const void *unique_id, int rank, int world)
 {
+    settle(c);
     if (!c) return M6A_EINVAL;
     if (!unique_id || world < 1 || rank < 0 || rank >= world) return fail(c, M6A_EINVAL, "bad communicator arguments");
     if (c->comm) return fail(c, M6A_EINVAL, "the context already has a communicator");
@@ -2237,6 +2293,7 @@ int m6a_comm_init(m6a_ctx *c, const void *unique_id, int rank, int world)
 
 int m6a_comm_destroy(m6a_ctx *c)
 {
+    settle(c);
     if (!c) return M6A_EINVAL;
     if (!c->comm) return M6A_OK;
     Rccl *R = rccl();
@@ -2295,6 +2352,7 @@ int check_gather_args(m6a_ctx *c, const int64_t *cuts, int dst)
 
 int m6a_gather(m6a_ctx *c, const float *site, const double *mod, const int64_t *cuts, int dst, float *site_all, double *mod_all)
 {
+    settle(c);
     if (!c) return M6A_EINVAL;
     int rc = check_gather_args(c, cuts, dst);
     if (rc) return rc;
@@ -2336,6 +2394,7 @@ int m6a_gather(m6a_ctx *c, const float *site, const double *mod, const int64_t *
 
 int m6a_gather_reads(m6a_ctx *c, const float *rp, const int64_t *cuts, int dst, float *rp_all)
 {
+    settle(c);
     if (!c) return M6A_EINVAL;
     int rc = check_gather_args(c, cuts, dst);
     if (rc) return rc;
@@ -2381,6 +2440,7 @@ int m6a_profile_enable(m6a_ctx *c, int on)
 
 int m6a_profile_read(m6a_ctx *c, int kind, double *total_ms, int64_t *n_launches)
 {
+    settle(c);
     if (!c || kind < 0 || kind > 1 || !total_ms || !n_launches) return M6A_EINVAL;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -106,21 +106,67 @@ def gather_sites(site, mod, cuts, dst=0, group=None, buffers=None):
 class NativeGather:
     """The same exchange on the C ABI's own communicator (include/m6a.h: m6a_comm_init / m6a_gather): one grouped
     ncclSend/ncclRecv over xGMI, shards written at their offsets without padding.  The 128-byte RCCL id travels
-    over the launcher's process group (any backend).  `start`/`drain` mirror SiteGather so bench.py can use either."""
+    over the launcher's process group (any backend).  `start`/`drain` mirror SiteGather so bench.py can use either.
+    Construction is collective and ends the same way on every rank: all succeed or all raise."""
 
     def __init__(self, engine, cuts, device, dst=0):
         import torch
         import torch.distributed as dist
         from .engine import comm_unique_id
-        self.engine, self.cuts, self.dst = engine, np.asarray(cuts, np.int64), dst
-        rank, world = dist.get_rank(), dist.get_world_size()
-        ident = [comm_unique_id() if rank == 0 else None]
+        self.engine, self.cuts, self.dst, self.device = engine, np.asarray(cuts, np.int64), dst, device
+        self.torch, self.dist = torch, dist
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        ident = [None]
+        if self.rank == 0:
+            try:
+                ident[0] = comm_unique_id()
+            except Exception as e:                          # e.g. librccl not found: tell everybody instead of leaving them waiting
+                ident[0] = "error: %s" % e
         dist.broadcast_object_list(ident, src=0)
-        engine.comm_init(ident[0], rank, world)
+        if not isinstance(ident[0], (bytes, bytearray)):
+            raise RuntimeError("rank 0 could not make an RCCL id (%s)" % ident[0])
+        ok, why = 1, ""
+        try:
+            engine.comm_init(ident[0], self.rank, self.world)
+        except Exception as e:
+            ok, why = 0, str(e)
+        if not self._all_ok(ok):
+            if ok:
+                engine.comm_destroy()
+            raise RuntimeError("m6a_comm_init failed on a rank%s" % (": " + why if why else ""))
         total = int(self.cuts[-1])
         self.out = [(torch.empty(total, dtype=torch.float32, device=device), torch.empty(total, dtype=torch.float64, device=device))
-                    if rank == dst else None for _ in range(2)]
+                    if self.rank == dst else None for _ in range(2)]
         self.slot = 0
+
+    def _all_ok(self, ok):
+        dev = self.device if self.dist.get_backend() == "nccl" else "cpu"
+        flag = self.torch.tensor([int(ok)], dtype=self.torch.int32, device=dev)
+        self.dist.all_reduce(flag, op=self.dist.ReduceOp.MIN)
+        return bool(flag.item())
+
+    def self_test(self):
+        """One exchange of a known pattern, checked on dst.  Collective; returns None when every rank is happy, else
+        the reason (the same verdict on every rank)."""
+        torch = self.torch
+        a, b = int(self.cuts[self.rank]), int(self.cuts[self.rank + 1])
+        idx = torch.arange(a, b, device=self.device)
+        ok, why = 1, None
+        try:
+            k = self.start((idx % 1000).to(torch.float32) + self.rank * 1000.0, idx.to(torch.float64) * 0.5)
+            site, mod = self.finish(k)
+            if self.rank == self.dst:
+                n = int(self.cuts[-1])
+                want = torch.arange(0, n, device=self.device)
+                owner = torch.bucketize(want, torch.as_tensor(self.cuts[1:], device=self.device), right=True)
+                if not (torch.equal(site, (want % 1000).to(torch.float32) + owner.to(torch.float32) * 1000.0) and
+                        torch.equal(mod, want.to(torch.float64) * 0.5)):
+                    ok, why = 0, "m6a_gather delivered wrong data in its self-test"
+        except Exception as e:
+            ok, why = 0, "m6a_gather failed: %s" % e
+        if self._all_ok(ok):
+            return None
+        return why or "m6a_gather self-test failed on another rank"
 
     def start(self, site, mod):
         k = self.slot

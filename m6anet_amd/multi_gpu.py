@@ -1,0 +1,195 @@
+"""`m6anet_amd inference --gpus N`: the job's sites split over N GPUs of one node.
+
+The reference has no multi-device path; this is north_star's: candidate sites are independent, so the job is cut
+into contiguous, flush-group-aligned shards balanced by read count (`m6a_shard_plan`), every rank -- one process per
+GPU -- runs the whole hot path on its shard with `m6a_set_job_offset(first_site)` (flush groups and RNG restarts are
+those of the whole job, so the CSVs do not depend on N), and ONE exchange at the end brings site_prob + mod_ratio
+(`m6a_gather`) and the per-read probabilities data.indiv_proba.csv needs (`m6a_gather_reads`) to rank 0 over
+RCCL/xGMI -- the library's own communicator, no torch.distributed.  Rank 0 writes the CSVs.
+
+    launcher (the process the user started)
+      |- makes an exchange directory, packs data.json -> one binary site store there unless the input already is one
+      |  (every rank maps the same file: nothing is parsed N times, a rank touches only its shard's pages)
+      |- starts N ranks: the same command line with M6A_RANK / M6A_WORLD / M6A_XDIR / M6A_STORE in the environment
+      '- waits; a rank that dies takes the others down (exact pids) and the launcher exits non-zero
+
+The 128-byte RCCL id travels through the exchange directory (rank 0 writes it, the others wait for it).
+M6A_EXCHANGE=host is a debugging aid like bench.py's M6A_BENCH_BACKEND=gloo: the gather goes through files in the
+exchange directory instead of RCCL and ranks may share a GPU (RCCL refuses two ranks on one device), which is how the
+one-GPU test box checks that N ranks give the CSV bytes of one.
+"""
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+from .constants import DEFAULT_MIN_READS, N_SAMPLES
+from .data_utils import STORE_SUFFIX, open_store, pack_sites
+from .engine import M6ANetEngine, comm_unique_id, device_count, reference_written_sites, shard_plan
+
+
+def _timeout():
+    return float(os.environ.get("M6A_EXCHANGE_TIMEOUT", "900"))
+
+
+def _wait_for(path, what, parent):
+    """Blocks until `path` exists (written atomically by its producer).  Gives up when the launcher has gone away or
+    after M6A_EXCHANGE_TIMEOUT seconds -- a rank must never wait for ever on a peer that died."""
+    t0, nap = time.time(), 0.0005
+    while not os.path.exists(path):
+        if os.getppid() != parent:
+            raise RuntimeError("launcher has gone away while waiting for %s" % what)
+        if time.time() - t0 > _timeout():
+            raise TimeoutError("timed out after %.0f s waiting for %s (%s)" % (_timeout(), what, path))
+        time.sleep(nap)
+        nap = min(nap * 2, 0.05)
+
+
+def _publish(path, data):
+    tmp = "%s.tmp%d" % (path, os.getpid())
+    with open(tmp, "wb") as f:
+        f.write(data)
+    os.rename(tmp, path)
+
+
+def exchange_mode(world):
+    mode = os.environ.get("M6A_EXCHANGE", "rccl")
+    if mode not in ("rccl", "host"):
+        raise ValueError("M6A_EXCHANGE must be 'rccl' or 'host'")
+    if mode == "rccl" and device_count() < world:
+        raise RuntimeError("--gpus %d but only %d HIP device(s) visible (M6A_EXCHANGE=host lets ranks share a GPU for debugging)"
+                           % (world, device_count()))
+    return mode
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# launcher
+# ---------------------------------------------------------------------------------------------------------------
+def rank_argv(args):
+    """The command line of a rank: the launcher's own options (the pretrained-model defaults are resolved again there)."""
+    argv = ["--input_dir"] + [str(d) for d in args.input_dir] + ["--out_dir", str(args.out_dir)]
+    for name in ("pretrained_model", "model_config", "model_state_dict", "norm_path", "batch_size", "save_per_batch", "n_processes",
+                 "num_iterations", "device", "seed", "read_proba_threshold", "gpus"):
+        v = getattr(args, name)
+        if v is not None:
+            argv += ["--" + name, str(v)]
+    if args.drop_unflushed_tail:
+        argv.append("--drop_unflushed_tail")
+    return argv
+
+
+def launch(args):
+    """Starts `args.gpus` ranks of this command line and waits for them.  Returns the exit code."""
+    world = int(args.gpus)
+    argv = rank_argv(args)
+    exchange_mode(world)                                   # fails early, with the reason, in the launcher
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    xdir = tempfile.mkdtemp(prefix="m6a_gpus_", dir=base)
+    procs = []
+    try:
+        given_store = len(args.input_dir) == 1 and str(args.input_dir[0]).endswith(STORE_SUFFIX)
+        store = os.path.abspath(args.input_dir[0]) if given_store else os.path.join(xdir, "job" + STORE_SUFFIX)
+        for r in range(world):
+            env = dict(os.environ, M6A_RANK=str(r), M6A_WORLD=str(world), M6A_XDIR=xdir, M6A_STORE=store)
+            procs.append(subprocess.Popen([sys.executable, "-m", "m6anet_amd", "inference"] + list(argv), env=env))
+        if not given_store:
+            # parse + normalise ONCE, while the ranks bring their HIP runtimes up; they map the result
+            pack_sites(args.input_dir, store, DEFAULT_MIN_READS, args.norm_path, n_threads=args.n_processes)
+        return _wait_all(procs)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        shutil.rmtree(xdir, ignore_errors=True)
+
+
+def _wait_all(procs):
+    """0 when every rank exits 0.  The first rank that fails ends the job: the others are terminated (they would wait
+    for it in the exchange) and its code is returned."""
+    t0 = time.time()
+    limit = float(os.environ.get("M6A_JOB_TIMEOUT", "0"))      # 0: no limit
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [c for c in codes if c not in (None, 0)]
+        if bad or (limit and time.time() - t0 > limit):
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            for p in procs:
+                try:
+                    p.wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            if not bad:
+                print("m6anet_amd: job exceeded M6A_JOB_TIMEOUT=%.0f s" % limit, file=sys.stderr)
+            return bad[0] if bad else 124
+        if all(c == 0 for c in codes):
+            return 0
+        time.sleep(0.01)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# one rank
+# ---------------------------------------------------------------------------------------------------------------
+def run_rank(args, weights):
+    rank, world = int(os.environ["M6A_RANK"]), int(os.environ["M6A_WORLD"])
+    xdir, store = os.environ["M6A_XDIR"], os.environ["M6A_STORE"]
+    parent = os.getppid()
+    mode = exchange_mode(world)
+    device = rank if mode == "rccl" else rank % max(device_count(), 1)
+
+    # the GPU context comes up while the launcher may still be packing the store
+    engine = M6ANetEngine(weights=weights, device=device)
+    _wait_for(store, "the launcher's site store", parent)
+    batch = open_store(store, args.norm_path, DEFAULT_MIN_READS)
+    off = batch.off
+    cuts = shard_plan(off, world, args.batch_size, args.save_per_batch)
+    read_cuts = np.ascontiguousarray(off[cuts])
+    a, b = int(cuts[rank]), int(cuts[rank + 1])
+    r0, r1 = int(off[a]), int(off[b])
+    if r1 - r0 >= (1 << 22):
+        engine.prepare_host_io()                         # pinned ring: the shard's features stream from the mapping
+    engine.set_job_offset(a)
+    read_prob, site_prob, mod_ratio = engine.infer(
+        batch.X[r0:r1], batch.site_kmers[a:b], np.ascontiguousarray(off[a:b + 1] - r0), args.num_iterations, N_SAMPLES,
+        args.read_proba_threshold, args.seed, args.batch_size, args.save_per_batch)
+
+    if mode == "rccl":
+        ident_path = os.path.join(xdir, "rccl_id")
+        if rank == 0:
+            _publish(ident_path, comm_unique_id())
+        _wait_for(ident_path, "rank 0's RCCL id", parent)
+        with open(ident_path, "rb") as f:
+            engine.comm_init(f.read(), rank, world)
+        site_all, mod_all = engine.gather(site_prob, mod_ratio, cuts, dst=0)
+        read_all = engine.gather_reads(read_prob, read_cuts, dst=0)
+        engine.comm_destroy()
+    else:
+        site_all = mod_all = read_all = None
+        if rank != 0:
+            _publish(os.path.join(xdir, "shard%d.bin" % rank),
+                     mod_ratio.tobytes() + site_prob.tobytes() + read_prob.tobytes())
+        else:
+            site_all, mod_all = np.empty(int(cuts[-1]), np.float32), np.empty(int(cuts[-1]), np.float64)
+            read_all = np.empty(int(off[-1]), np.float32)
+            site_all[a:b], mod_all[a:b], read_all[r0:r1] = site_prob, mod_ratio, read_prob
+            for r in range(1, world):
+                p = os.path.join(xdir, "shard%d.bin" % r)
+                _wait_for(p, "rank %d's results" % r, parent)
+                ns, nr = int(cuts[r + 1] - cuts[r]), int(read_cuts[r + 1] - read_cuts[r])
+                raw = np.fromfile(p, np.uint8)
+                if raw.size != 12 * ns + 4 * nr:
+                    raise RuntimeError("rank %d delivered %d bytes, expected %d" % (r, raw.size, 12 * ns + 4 * nr))
+                mod_all[cuts[r]:cuts[r + 1]] = raw[:8 * ns].view(np.float64)
+                site_all[cuts[r]:cuts[r + 1]] = raw[8 * ns:12 * ns].view(np.float32)
+                read_all[read_cuts[r]:read_cuts[r + 1]] = raw[12 * ns:].view(np.float32)
+    engine.close()
+    if rank == 0:
+        n_write = None
+        if getattr(args, "drop_unflushed_tail", False):
+            n_write = reference_written_sites(batch.n_sites, args.batch_size, args.save_per_batch)
+        batch.native.write_csv(args.out_dir, read_all, site_all, mod_all, write_header=True, n_sites=n_write)

@@ -37,6 +37,9 @@ def argparser():
     parser.add_argument("--seed", default=0, type=int, help="random seed for sampling.")
     parser.add_argument("--read_proba_threshold", default=DEFAULT_READ_THRESHOLD, type=float,
                         help="default probability threshold for a read to be considered modified.")
+    parser.add_argument("--gpus", default=1, type=int,
+                        help="GPUs of this node to split the job's sites over: one process per GPU, flush-group-aligned shards, "
+                             "one RCCL gather to the rank that writes the CSVs; the output does not depend on it.")
     parser.add_argument("--drop_unflushed_tail", action="store_true",
                         help="reference-compatible output: omit the batches after the reference's last flush, which "
                              "`m6anet inference` never writes (its flush test is inverted); default: write every site.")
@@ -86,6 +89,20 @@ def main(args):
         weights = load_weights(args.pretrained_model)
         args.read_proba_threshold = PRETRAINED_CONFIGS[args.pretrained_model][1]
         args.norm_path = PRETRAINED_CONFIGS[args.pretrained_model][2]
+
+    if args.gpus < 1:
+        raise ValueError("--gpus must be >= 1")
+    if "M6A_RANK" in os.environ:                         # one rank of a --gpus N job (started by multi_gpu.launch)
+        from .. import multi_gpu
+        multi_gpu.run_rank(args, weights)
+        return
+    if args.gpus > 1:
+        from .. import multi_gpu
+        pathlib.Path(args.out_dir).mkdir(parents=True, exist_ok=True)
+        rc = multi_gpu.launch(args)
+        if rc != 0:
+            raise SystemExit(rc)
+        return
 
     # the GPU context (HIP initialisation, weights) comes up on a thread while the loader parses data.json
     import threading

@@ -124,3 +124,33 @@ def test_reference_written_sites_matches_the_reference_runs(golden):
     assert engine.reference_written_sites(101, 16, 2) == 101
     assert engine.reference_written_sites(0, 16, 2) == 0
     assert engine.reference_written_sites(32, 16, 1) == 0            # save_per_batch 1: the reference never flushes
+
+
+def test_multi_gpu_launcher_stops_the_job_when_a_rank_dies():
+    """`inference --gpus N`: the launcher waits for its ranks; the first one that fails ends the job -- the others
+    (which would wait for it in the exchange) are terminated by pid -- and its exit code is the job's."""
+    import subprocess
+    import sys
+    import time
+    from m6anet_amd import multi_gpu
+    t0 = time.time()
+    procs = [subprocess.Popen([sys.executable, "-c", "import time; time.sleep(120)"]),
+             subprocess.Popen([sys.executable, "-c", "import sys, time; time.sleep(0.3); sys.exit(7)"])]
+    assert multi_gpu._wait_all(procs) == 7
+    assert time.time() - t0 < 30 and all(p.poll() is not None for p in procs)
+    procs = [subprocess.Popen([sys.executable, "-c", "pass"]) for _ in range(3)]
+    assert multi_gpu._wait_all(procs) == 0
+
+
+def test_multi_gpu_rank_command_line_round_trips():
+    """A rank is started with the launcher's own options: parsing the rebuilt command line gives the same namespace."""
+    from argparse import ArgumentParser
+    from m6anet_amd import multi_gpu
+    from m6anet_amd.scripts import inference
+    p = ArgumentParser(parents=[inference.argparser()])
+    argv = ["--input_dir", "a", "b", "--out_dir", "o", "--gpus", "4", "--num_iterations", "77", "--seed", "3", "--batch_size", "8",
+            "--drop_unflushed_tail", "--read_proba_threshold", "0.0125", "--model_config", "m.toml"]
+    a = p.parse_args(argv)
+    assert vars(p.parse_args(multi_gpu.rank_argv(a))) == vars(a)
+    a = p.parse_args(["--input_dir", "x.m6astore", "--out_dir", "o"])
+    assert vars(p.parse_args(multi_gpu.rank_argv(a))) == vars(a)

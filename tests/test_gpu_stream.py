@@ -257,3 +257,149 @@ def test_integration_stub_as_written(golden, weights, monkeypatch):
         assert np.array_equal(site, site_g["T5_bs16_spb2_seed0_site"][g0:g1])
         assert np.array_equal(mod, site_g["T5_bs16_spb2_seed0_mod"][g0:g1])
     ns["_L"].m6a_destroy(model._h)
+
+
+# ------------------------------------------------------------------ --gpus N in the product CLI --------------------
+DATA = os.path.join(REPO, "tests", "golden", "ref_tests_data")
+
+
+def replicate_bundled(n, out_dir):
+    """The bundled 101 sites n times over (transcript ids made unique): a 101*n-site dataprep directory."""
+    info = open(os.path.join(DATA, "data.info")).read().splitlines()[1:]
+    blob = open(os.path.join(DATA, "data.json"), "rb").read()
+    os.makedirs(out_dir, exist_ok=True)
+    with open(os.path.join(out_dir, "data.json"), "wb") as fj, open(os.path.join(out_dir, "data.info"), "w") as fi:
+        fi.write("transcript_id,transcript_position,start,end,n_reads\n")
+        pos = 0
+        for k in range(n):
+            for row in info:
+                tx, p, a, b, nr = row.split(",")
+                new_tx = "%s_c%d" % (tx, k)
+                rec = blob[int(a):int(b)].replace(('"%s"' % tx).encode(), ('"%s"' % new_tx).encode(), 1)
+                fj.write(rec)
+                fi.write("%s,%s,%d,%d,%s\n" % (new_tx, p, pos, pos + len(rec), nr))
+                pos += len(rec)
+
+
+def cli(argv, env=None, expect=0):
+    import subprocess
+    e = dict(os.environ, PYTHONPATH=REPO + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    e.update(env or {})
+    r = subprocess.run([sys.executable, "-m", "m6anet_amd"] + argv, env=e, capture_output=True, text=True, timeout=600, cwd=REPO)
+    assert r.returncode == expect, (r.returncode, r.stderr[-2000:])
+    return r
+
+
+def csv_bytes(out_dir):
+    return [open(os.path.join(out_dir, fn), "rb").read() for fn in ("data.site_proba.csv", "data.indiv_proba.csv")]
+
+
+@pytest.mark.parametrize("extra", [[], ["--batch_size", "8", "--save_per_batch", "3", "--drop_unflushed_tail", "--seed", "5"]])
+def test_cli_gpus_n_writes_the_bytes_of_one_gpu(tmp_path, extra):
+    """`inference --gpus N` (self-launched ranks, flush-group-aligned shards, job offsets, gather to rank 0, rank 0
+    writes) == the one-GPU run, byte for byte, from data.json (the launcher packs it once) and from a 5 050-site
+    store (every rank maps it).  The box has one GPU: M6A_EXCHANGE=host lets the ranks share it and moves the gather
+    through the exchange directory -- everything but the RCCL transport is the code an 8-GPU node runs."""
+    common = ["--num_iterations", "40", "--n_processes", "4"] + extra
+    one = str(tmp_path / "one")
+    cli(["inference", "--input_dir", DATA, "--out_dir", one] + common)
+    want = csv_bytes(one)
+    assert want[0].count(b"\n") > 50
+    for n in (2, 3):
+        out = str(tmp_path / ("n%d" % n))
+        cli(["inference", "--input_dir", DATA, "--out_dir", out, "--gpus", str(n)] + common, env={"M6A_EXCHANGE": "host"})
+        assert csv_bytes(out) == want, n
+    big = str(tmp_path / "big")
+    replicate_bundled(50, big)
+    store = str(tmp_path / "big.m6astore")
+    cli(["pack", "--input_dir", big, "--out", store])
+    one = str(tmp_path / "big_one")
+    cli(["inference", "--input_dir", store, "--out_dir", one] + common)
+    want = csv_bytes(one)
+    assert want[0].count(b"\n") > 2500
+    for n in (2, 5):
+        out = str(tmp_path / ("big_n%d" % n))
+        cli(["inference", "--input_dir", store, "--out_dir", out, "--gpus", str(n)] + common, env={"M6A_EXCHANGE": "host"})
+        assert csv_bytes(out) == want, n
+
+
+def test_cli_rank_over_rccl_on_one_gpu(tmp_path):
+    """The RCCL leg of a rank -- id through the exchange directory, m6a_comm_init, m6a_gather and m6a_gather_reads with
+    HOST arrays -- on the one communicator a one-GPU box allows (world = 1): same CSV bytes as the plain run."""
+    store = str(tmp_path / "b.m6astore")
+    cli(["pack", "--input_dir", DATA, "--out", store])
+    common = ["--num_iterations", "25"]
+    one = str(tmp_path / "one")
+    cli(["inference", "--input_dir", store, "--out_dir", one] + common)
+    xdir = tmp_path / "x"
+    xdir.mkdir()
+    out = str(tmp_path / "rank")
+    os.makedirs(out)
+    cli(["inference", "--input_dir", store, "--out_dir", out, "--gpus", "1"] + common,
+        env={"M6A_RANK": "0", "M6A_WORLD": "1", "M6A_XDIR": str(xdir), "M6A_STORE": store})
+    assert (xdir / "rccl_id").stat().st_size == 128
+    assert csv_bytes(out) == csv_bytes(one)
+
+
+def test_cli_gpus_failures_are_loud(tmp_path):
+    """More ranks than GPUs without the debugging transport is refused by the launcher; a rank that dies takes the
+    job down with its exit code instead of leaving the others waiting."""
+    r = cli(["inference", "--input_dir", DATA, "--out_dir", str(tmp_path / "o"), "--gpus", "64"], expect=1)
+    assert "HIP device(s) visible" in r.stderr
+    r = cli(["inference", "--input_dir", DATA, "--out_dir", str(tmp_path / "o2"), "--gpus", "2", "--num_iterations", "5",
+             "--norm_path", "/nonexistent/norm.npz", "--model_state_dict", os.path.join(REPO, "m6anet_amd", "assets", "weights_hct116.bin")],
+            env={"M6A_EXCHANGE": "host", "M6A_EXCHANGE_TIMEOUT": "20"}, expect=1)
+    assert r.stderr
+
+
+# ------------------------------------------------------------------ bench.py's N-rank legs on one GPU --------------
+def run_bench(argv, env, timeout=900):
+    import json
+    import subprocess
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + argv, capture_output=True, text=True,
+                         env=dict(os.environ, **env), timeout=timeout)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    return out, [json.loads(l) for l in lines]
+
+
+def one_rank_env():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return {"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port),
+            "M6A_BENCH_FORCE_EXCHANGE": "1"}
+
+
+SMALL = ["--sites", "3001", "--iters", "60", "--steps", "2", "--warmup", "1", "--verify", "--no-cpu-baseline", "--no-live-traffic"]
+
+
+def test_bench_native_exchange_is_the_default_and_checks_itself():
+    """The N-GPU run's exchange on the one communicator a one-GPU box allows: process group on backend nccl (= RCCL),
+    NativeGather's collective construction and self-test, one m6a_gather per step on the context's stream, --verify."""
+    out, lines = run_bench(["--gpus", "1"] + SMALL, one_rank_env())
+    assert out.returncode == 0 and len(lines) == 1, out.stderr[-2000:]
+    d = lines[0]
+    assert "m6a_gather" in d["config"]["sharding"] and d["verify"] is True and d["value"] > 0
+    assert d["value_one_shot"] > 0 and d["first_call_ms"] > 0 and "rank0_local" in d
+
+
+def test_bench_falls_back_to_torch_when_the_library_cannot_bind_rccl():
+    out, lines = run_bench(["--gpus", "1"] + SMALL, dict(one_rank_env(), M6A_RCCL_LIB="/nonexistent/librccl.so"))
+    assert out.returncode == 0 and len(lines) == 1, out.stderr[-2000:]
+    d = lines[0]
+    assert "torch.distributed" in d["config"]["sharding"] and "unavailable" in d["config"]["sharding"]
+    assert d["verify"] is True
+
+
+def test_bench_prints_its_line_when_a_rank_dies():
+    """Rank 1 dies before the timed region: torch.distributed.run takes rank 0 down, and rank 0 still prints ONE JSON line
+    -- its own measurements plus the reason -- and the run exits non-zero instead of hanging."""
+    out, lines = run_bench(["--gpus", "2", "--workload", "ragged", "--sites", "700", "--iters", "60", "--steps", "2", "--warmup", "1",
+                            "--no-cpu-baseline"], {"M6A_BENCH_BACKEND": "gloo", "M6A_BENCH_TEST_KILL_RANK": "1", "M6A_BENCH_TIMEOUT": "240"},
+                           timeout=600)
+    assert out.returncode != 0
+    assert len(lines) == 1, (out.stdout[-1000:], out.stderr[-2000:])
+    d = lines[0]
+    assert d["n_gpus"] == 2 and d["value"] is None and "error" in d and d["rank0_local"]["sites_per_s"] > 0
