@@ -53,8 +53,9 @@ def pool_roofline(variant, draws, avg_ms, launches):
     rate = draws / (avg_ms * 1e-3) if avg_ms else None
     if variant == "table-reg":
         bound, peak = "valu", PEAK_VALU_MULS
-        note = ("peak = packed float32 multiply rate (2 per lane per issue slot, 78.6 T/s); on this part v_pk_mul_f32 issues every "
-                "~7 cycles, not 4 (profiles/r02_gpr_variants.txt), which puts the practical ceiling of bags-in-registers at 44.8 T draws/s")
+        note = ("peak = NOMINAL packed float32 multiply rate (2 per lane per 4-cycle issue slot, 78.6 T/s).  The part does not deliver it: "
+                "a v_pk_mul_f32 costs 6.1-7 cycles per wave64 whatever the occupancy and a plain v_mul_f32 3.05 (profiles/r03_gpr_variants.txt: "
+                "the same 21 lane-multiplies per SIMD cycle either way); measured_ceiling, taken live, is that multiply throughput")
     else:
         bound, peak = "l1-lds", PEAK_LDS_GATHERS
         note = ("a draw moves 2 index bytes through the vector L1 (64 B/clk/CU) and one 4-byte LDS gather (32 banks/clk/CU): both pipes "
@@ -276,6 +277,35 @@ def measured_gather_ceiling(bag):
                       "harmonic mean over bag sizes %d..%d)" % (lo, hi)}
 
 
+def measured_multiply_ceiling():
+    """What bags-in-registers can reach on THIS box, measured now: tools/gpr_variants (tools/gpr_variants_gen.py) runs the
+    inner loop of pool_reg_kernel -- one float32 multiply per draw and site, nothing else -- at 2, 4 and 8 resident waves per
+    SIMD, with and without the VGPR index switch.  The best row WITHOUT index switching is the multiply throughput of the
+    part (no kernel that has to select a register per draw can beat it)."""
+    exe = os.path.join(REPO, "tools", "gpr_variants")
+    if not os.path.exists(exe):
+        return None
+    try:
+        out = subprocess.run([exe], capture_output=True, text=True, timeout=120).stdout
+    except (subprocess.SubprocessError, OSError):
+        return None
+    rows = {}
+    for line in out.splitlines():
+        f = line.split()
+        if len(f) > 4 and f[2] == "ms" and f[4] == "T":
+            try:
+                rows[f[0]] = float(f[3]) * 1e12
+            except ValueError:
+                pass
+    noidx = {k: v for k, v in rows.items() if k.endswith("noidx")}
+    if not noidx:
+        return None
+    best = max(noidx, key=noidx.get)
+    return {"rate": noidx[best], "variant": best, "rows": {k: v / 1e12 for k, v in rows.items()},
+            "source": "tools/gpr_variants run by this bench: the kernel's inner loop (one multiply per draw and site) at 2 / 4 / 8 waves "
+                      "per SIMD, with and without the VGPR index switch; ceiling = best row without it (%s)" % best}
+
+
 def smi_snapshot():
     """Clock and power as rocm-smi reports them right now (None if the tool is missing)."""
     try:
@@ -407,6 +437,10 @@ class Bench:
         self.step()
         self.fence()
         first_call_ms = (time.perf_counter() - t0) * 1e3
+        t0 = time.perf_counter()
+        self.step()                                          # the same call again, alone and synchronised: what a cold call could cost at best
+        self.fence()
+        second_call_ms = (time.perf_counter() - t0) * 1e3
         for _ in range(warmup):
             self.step()
         # HIP events around every launch of the dominant kernel (the encoder) inside the timed region -- roofline.achieved
@@ -441,7 +475,7 @@ class Bench:
             t_all, = self.max_over_ranks(t_all)
             sustained = {"seconds": t_all, "steps": n_done, "ms_per_step": t_all / n_done * 1e3, "rocm_smi_under_load": smi}
         dt, first_call_ms = self.max_over_ranks(dt, first_call_ms)
-        return {"dt": dt, "first_call_ms": first_call_ms, "enc_ms": enc_ms, "enc_n": enc_n, "pool_ms": pool_ms, "pool_n": pool_n,
+        return {"dt": dt, "first_call_ms": first_call_ms, "second_call_ms": second_call_ms, "enc_ms": enc_ms, "enc_n": enc_n, "pool_ms": pool_ms, "pool_n": pool_n,
                 "sustained": sustained}
 
     def verify(self):
@@ -486,6 +520,11 @@ class Bench:
         pool_kernel = {"table-reg": "pool_reg_kernel", "table": "pool_table_kernel", "ragged-table": "pool_rtab_kernel"}.get(
             eng.last_pool_variant, "pool_scan_kernels")
         proof = pool_roofline(eng.last_pool_variant, draws, pool_avg_ms, r["pool_n"])
+        if gather_ceiling and eng.last_pool_variant == "table-reg" and self.rank == 0:
+            m = measured_multiply_ceiling()
+            if m is not None and proof["achieved"]:
+                proof["measured_ceiling"] = {"peak": m["rate"] / 1e12, "unit": "T draws/s", "frac": proof["achieved"] * 1e12 / m["rate"],
+                                             "source": m["source"], "T_draws_per_s_by_variant": m["rows"]}
         if gather_ceiling and eng.last_pool_variant == "ragged-table" and self.rank == 0:
             m = measured_gather_ceiling(bag)
             if m is not None and proof["achieved"]:
@@ -496,6 +535,7 @@ class Bench:
             "value": value,
             "ms_per_step": r["dt"] / steps * 1e3,
             "first_call_ms": r["first_call_ms"],
+            "second_call_ms": r["second_call_ms"],           # one call, alone and synchronised, everything cached (steps in the timed region queue back to back)
             # a real job is ONE call on a fresh context: sites / the cold call (what m6a_create did not prepare is inside)
             "value_one_shot": total_sites / (r["first_call_ms"] * 1e-3),
             "roofline": {"kernel": "read encoder (%s)" % eng.last_encoder_variant, "bound": "mfma", "achieved": enc_tflops,
@@ -689,7 +729,7 @@ def run(args, line, rank, world, local_rank, S, bag, T):
     if rank == 0:
         rep = b.report(r, args.steps)
         line.update({"value": rep.pop("value"), "ms_per_step": rep.pop("ms_per_step"), "config": b.config(),
-                     "first_call_ms": rep.pop("first_call_ms"), "value_one_shot": rep.pop("value_one_shot"), "verify": verified})
+                     "first_call_ms": rep.pop("first_call_ms"), "second_call_ms": rep.pop("second_call_ms"), "value_one_shot": rep.pop("value_one_shot"), "verify": verified})
         line.update(rep)
         default_run = (world == 1 and args.workload == "uniform" and S == WORKLOADS["uniform"]["sites"] and T == 1000 and
                        bag == WORKLOADS["uniform"]["bag"])

@@ -214,6 +214,13 @@ int m6a_comm_destroy(m6a_ctx *ctx);
 /* HIP devices visible to this process (0 if none / no runtime): what a launcher sizes `world` against. */
 int m6a_device_count(void);
 
+/* The random stream the site sampling replays, by itself: the first n_words 32-bit outputs of NumPy's legacy generator
+ * after np.random.seed(seed) (m6anet/scripts/inference.py:86) -- MT19937 seeded by init_genrand, the words
+ * RandomState.bytes / randint consume (m6anet/utils/inference_utils.py:85 draws from it through np.random.choice).
+ * Generated on the GPU in up to 32 parallel segments (GF(2) jump-ahead).  words: host or device pointer; a device-pointer
+ * call is stream-ordered (m6a_sync).  Known-answer vectors: tests/golden/mt19937_seed*_first4096.u32. */
+int m6a_random_stream(m6a_ctx *ctx, uint32_t seed, int64_t n_words, uint32_t *words);
+
 /* Per-kernel timing with HIP events on the context's stream (bench.py's live roofline).
  * kind: 0 = read encoder, 1 = site pooling.  on: 0 off, 1 both kinds, 2 the encoder only, 3 the pooling only (two events per
  * timed launch cost ~5 us each on the stream).  m6a_profile_read synchronises the stream. */

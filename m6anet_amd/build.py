@@ -9,7 +9,7 @@ INCLUDE = os.path.join(os.path.dirname(PKG), "include")
 LIB = os.path.join(PKG, "libm6a_hip.so")
 IO_LIB = os.path.join(PKG, "libm6a_io.so")
 SOURCES = ["m6a_kernels.hip", "m6a_pool_reg.hip", "m6a_pool_rtab.hip", "m6a_api.hip"]
-DEPS = SOURCES + ["m6a_kernels.h", os.path.join(INCLUDE, "m6a.h")]
+DEPS = SOURCES + ["m6a_kernels.h", os.path.join(INCLUDE, "m6a.h"), os.path.join(PKG, "assets", "mt19937_jump.bin")]
 
 
 def needs_build():
@@ -25,8 +25,9 @@ def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     # -ffp-contract=off: the pooling arithmetic must round where NumPy rounds (a fused 1 - a*b would
     # not); the encoder's FMAs are explicit fmaf()
+    jump = os.path.join(PKG, "assets", "mt19937_jump.bin")      # embedded into the library (tools/make_mt_jump.py writes it)
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-Wall", "-Wextra", "-fPIC", "-shared",
-           "-I" + INCLUDE, "-I" + CSRC] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+           '-DM6A_MT_JUMP_PATH="%s"' % jump, "-I" + INCLUDE, "-I" + CSRC] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

@@ -109,12 +109,18 @@ __global__ void mean_over_passes_kernel(const float *y, int n_iters, int64_t n_s
 __global__ void bag_minmax_kernel(const int64_t *off, int64_t n_sites, unsigned long long *out, uint32_t *hist);
 __global__ void bag_verify_kernel(const unsigned long long *got, const uint32_t *hist, unsigned long long mn, unsigned long long mx,
                                   unsigned long long reads, unsigned long long hash, int *err);
-__global__ void mt19937_kernel(uint32_t seed, int64_t n_words, uint32_t *raw);
+__global__ void mt19937_kernel(uint32_t seed, int64_t n_words, uint32_t *raw, const uint32_t *hist, int64_t seg_words, uint32_t *xhead, int64_t xhead_n);
+__global__ void mt_jump_kernel(const uint32_t *xhead, const uint64_t *polys, uint32_t *hist);
 __global__ void rtab_count_kernel(RtabBuild a);
 __global__ void rtab_scan_kernel(RtabBuild a);
 __global__ void rtab_fill_kernel(RtabBuild a);
 __global__ void rtab_to_reg_table_kernel(const uint16_t *C, int64_t A, int64_t row_bytes, int jmax, uint8_t *tab);
+__global__ void rtab_to_lds_table_kernel(const uint16_t *C, int64_t A, int K, int rows, int jmax, const int *iter_of, uint32_t *tab);
 __global__ void rtab_prep_kernel(PoolArgs a, RtabUse u, uint32_t *cursor, uint32_t *order, unsigned n_order_blocks);
 template <int KT> __global__ void pool_rtab_kernel(PoolArgs a, RtabUse u);
+
+__global__ void m6a_touch_kernels();
+__global__ void m6a_touch_pool_reg();
+__global__ void m6a_touch_pool_rtab();
 
 #endif

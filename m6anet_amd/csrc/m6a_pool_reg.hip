@@ -346,3 +346,7 @@ __global__ __launch_bounds__(256) void pool_reg_finish_kernel(PoolArgs a)
         }
     }
 }
+
+// An empty kernel per translation unit: HIP maps a code object on the first launch of any kernel in it (0.3-1.2 ms, measured
+// in the first call's timeline, profiles/r03_first_call_timeline.txt); m6a_create's background set-up launches these instead.
+__global__ void m6a_touch_pool_reg() {}

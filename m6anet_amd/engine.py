@@ -214,6 +214,13 @@ class M6ANetEngine:
         self._chk(self._L.m6a_gather_reads(self._h, aP.ptr, cuts.ctypes.data, int(dst), oP.ptr if oP else None))
         return ra
 
+    def random_stream(self, seed, n_words):
+        """First n_words uint32 outputs of NumPy's legacy generator after np.random.seed(seed), generated on the GPU
+        (include/m6a.h: m6a_random_stream): np.frombuffer(np.random.RandomState(seed).bytes(4 * n), np.uint32)."""
+        out = np.empty(int(n_words), np.uint32)
+        self._chk(self._L.m6a_random_stream(self._h, int(seed) & 0xffffffff, int(n_words), out.ctypes.data))
+        return out
+
     def prepare_host_io(self):
         """Pin the staging ring of the host-pointer path now (otherwise the first numpy-array call does it)."""
         self._chk(self._L.m6a_prepare_host_io(self._h))

@@ -403,3 +403,87 @@ def test_bench_prints_its_line_when_a_rank_dies():
     assert len(lines) == 1, (out.stdout[-1000:], out.stderr[-2000:])
     d = lines[0]
     assert d["n_gpus"] == 2 and d["value"] is None and "error" in d and d["rank0_local"]["sites_per_s"] > 0
+
+
+# ------------------------------------------------------------------ the read-probability bar, statistically --------
+def test_read_probability_tail_at_full_size(engines, orc, weights):
+    """BASELINE configs[2] at full size: ALL 20 M read probabilities of both encoder kernels and all four checkpoints
+    against the multi-threaded oracle.  The bar is the reference's (m6anet/tests/test_inference.py:32: rtol 1e-5, atol
+    1e-8); at this scale float32 rounding noise between two summation orders puts a handful of reads in 10^8 just beyond
+    it (even exact float64 arithmetic sits AT the bar against the float32 oracle), so the guard is
+    statistical: at most 1e-6 of the reads beyond the bar, the worst below 1.5x, nothing grossly wrong.  A kernel change
+    that moved the tail from 5e-8 to 1e-4 of the reads -- invisible to the small committed vectors -- fails here."""
+    import json
+    d = synthetic.make_sites(1_000_000, 20, seed=20250328)
+    X, km, off = d["X"], d["site_kmers"], d["off"]
+    threads = os.cpu_count() or 8
+    seen = {}
+    for name, e in engines.items():
+        want = orc.encode_reads(weights[name], X, km, off, n_threads=threads)
+        tol = 1e-8 + 1e-5 * np.abs(want.astype(np.float64))
+        for variant, kernel in ((1, "general16"), (2, "csite12")):
+            e.set_encoder_variant(variant)
+            try:
+                got = e.get_read_probability(X, km, off)
+                assert e.last_encoder_variant == kernel
+            finally:
+                e.set_encoder_variant(0)
+            assert got.shape == want.shape and np.all(np.isfinite(got))
+            use = np.abs(got.astype(np.float64) - want) / tol
+            beyond, worst = int((use > 1.0).sum()), float(use.max())
+            seen["%s/%s" % (name, kernel)] = {"reads": int(use.size), "beyond_bar": beyond, "fraction": beyond / use.size,
+                                             "worst_use_of_bar": worst}
+    print("read-probability guard:", json.dumps(seen))
+    try:                                                     # scratch copy for profiles/ (best effort)
+        os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(REPO, "gpurun_out", "read_prob_guard.json"), "w") as f:
+            json.dump(seen, f, indent=1)
+    except OSError:
+        pass
+    for key, s in seen.items():
+        assert s["fraction"] <= 1e-6, (key, s)
+        assert s["worst_use_of_bar"] < 1.5, (key, s)
+
+
+def test_c_abi_from_plain_c():
+    """tools/feed_probe.c: a C program that dlopens libm6a_hip.so and runs the reference's batch loop through
+    m6a_job_begin / feed / end and the same job as one m6a_infer -- no Python, no torch in the process: exit code 0 means
+    the two agreed bit for bit."""
+    import json
+    import subprocess
+    exe = os.path.join(REPO, "tools", "feed_probe")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(REPO, "tools"), "feed_probe"])
+    r = subprocess.run([exe, "3000", "16", "20", "60", "200"], capture_output=True, text=True, cwd=REPO, timeout=300)
+    assert r.returncode == 0, r.stderr[-1000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["bit_identical_to_m6a_infer"] is True and d["sites"] == 3000 and d["streamed_sites_per_s"] > 0
+
+
+# ------------------------------------------------------------------ the NumPy stream, in parallel segments ---------
+@pytest.mark.parametrize("seed,n", [(0, 1), (0, 4096), (1, 65536 + 22016), (42, 65536 + 22017), (0, 1_328_128), (7, 2 * 65536),
+                                    (0xffffffff, 32 * 65536), (3, 32 * 65536 + 1024), (5, 5_000_011), (9, 33 * (1 << 20) + 77),
+                                    (0, 70_000_000)])
+def test_random_stream_is_numpys(eng, seed, n):
+    """m6a_random_stream == the 32-bit words NumPy's legacy generator hands out after np.random.seed(seed) -- for stream
+    lengths on both sides of every switch of the segmented generator: one chain (< 2^16 + head), 2..32 segments of 2^16 words,
+    the 2^20 and 2^24 regimes, lengths that are not multiples of anything."""
+    want = np.frombuffer(np.random.RandomState(seed).bytes(4 * n), dtype=np.uint32)
+    got = eng.random_stream(seed, n)
+    assert got.dtype == np.uint32 and got.shape == want.shape
+    bad = np.flatnonzero(got != want)
+    assert bad.size == 0, (bad[:5], bad.size)
+
+
+def test_random_stream_known_answers_and_single_chain(eng, golden, monkeypatch):
+    g = golden("rng_known.npz")
+    for seed in (0, 1, 42):
+        key = "mt19937_seed%d" % seed
+        if key in g.files:
+            assert np.array_equal(eng.random_stream(seed, g[key].size), g[key])
+    import torch
+    out = torch.empty(3_000_000, dtype=torch.int32, device="cuda")
+    eng._chk(eng._L.m6a_random_stream(eng._h, 11, out.numel(), out.data_ptr()))      # device pointer: stream-ordered
+    eng.sync()
+    want = np.frombuffer(np.random.RandomState(11).bytes(4 * out.numel()), dtype=np.uint32)
+    assert np.array_equal(out.cpu().numpy().view(np.uint32), want)

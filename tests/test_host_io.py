@@ -222,3 +222,70 @@ def test_fast_16_digit_formatter_equals_printf():
     assert np.isfinite(vals).sum() > 500000
     bad = [(v, fmt(v), "%.16f" % v) for v in vals.tolist() if fmt(v) != "%.16f" % v]
     assert not bad, bad[:5]
+
+
+def test_site_store_is_tied_to_the_content_of_its_norm_factors(tmp_path):
+    """A store holds NORMALISED features: it is accepted only for the factors it was packed with -- compared by content,
+    not by file name -- and a run without --norm_path (the reference then feeds un-normalised features) refuses a
+    normalised store instead of silently using it; a corrupt k-mer id never reaches the GPU's embedding table."""
+    import shutil
+    from m6anet_amd import _io
+    from m6anet_amd.constants import asset_path
+    store = str(tmp_path / "b.m6astore")
+    data_utils.pack_sites([DATA], store, 20, "norm_hct116.npz")
+    data_utils.open_store(store, "norm_hct116.npz", 20).native.close()
+    # the same factors under another name / path: accepted
+    other = tmp_path / "renamed.npz"
+    shutil.copyfile(asset_path("norm_hct116.npz"), other)
+    data_utils.open_store(store, str(other), 20).native.close()
+    # other factors under the SAME base name: refused
+    d = tmp_path / "elsewhere"
+    d.mkdir()
+    z = np.load(asset_path("norm_hct116.npz"))
+    np.savez(d / "norm_hct116.npz", kmers=z["kmers"], mean=z["mean"] + 1e-9, std=z["std"])
+    with pytest.raises(ValueError, match="re-run"):
+        data_utils.open_store(store, str(d / "norm_hct116.npz"), 20)
+    with pytest.raises(ValueError, match="re-run"):
+        data_utils.open_store(store, None, 20)                      # this run expects un-normalised features
+    with pytest.raises(ValueError, match="re-run"):
+        data_utils.open_store(store, "norm_hct116.npz", 30)         # another read-count filter
+    # un-normalised store <-> run without factors
+    raw_store = str(tmp_path / "raw.m6astore")
+    data_utils.pack_sites([DATA], raw_store, 20, None)
+    st = data_utils.open_store(raw_store, None, 20)
+    assert np.array_equal(st.X, data_utils.load_sites([DATA], 20, None).X)
+    st.native.close()
+    with pytest.raises(ValueError, match="re-run"):
+        data_utils.open_store(raw_store, "norm_hct116.npz", 20)
+    # a k-mer id beyond the 66-word vocabulary
+    nat = _io.NativeSites(store=store)
+    pos = nat.site_kmers.ctypes.data - nat.off.ctypes.data            # both are views into the mapping
+    nat.close()
+    raw = bytearray(open(store, "rb").read())
+    at = raw.find(bytes(np.asarray([0], np.int64).tobytes()), 128)      # off[0] = 0 is the first array after the header
+    raw[at + pos + 5] = 200
+    bad = str(tmp_path / "bad.m6astore")
+    open(bad, "wb").write(bytes(raw))
+    with pytest.raises(_io.M6AIOError, match="k-mer id out of range"):
+        data_utils.open_store(bad, "norm_hct116.npz", 20)
+
+
+def test_loader_reads_the_non_finite_literals_python_json_writes(tmp_path):
+    """json.loads -- the reference's parser (data_utils.py:186) -- accepts NaN / Infinity / -Infinity, and json.dumps
+    writes them: a data.json holding one must load, in the native loader as in the Python mirror, not fail the job."""
+    import json
+    info = open(os.path.join(DATA, "data.info")).read().splitlines()
+    tx, pos, a, b, n = info[1].split(",")
+    rec = json.loads(open(os.path.join(DATA, "data.json"), "rb").read()[int(a):int(b)])
+    kmer, rows = next(iter(rec[tx][pos].items()))
+    rows[0][0], rows[1][1], rows[2][2] = float("nan"), float("inf"), float("-inf")
+    text = json.dumps(rec, separators=(",", ":")) + "\n"
+    assert "NaN" in text and "Infinity" in text and "-Infinity" in text
+    with open(tmp_path / "data.json", "w") as f:
+        f.write(text)
+    with open(tmp_path / "data.info", "w") as f:
+        f.write(info[0] + "\n%s,%s,0,%d,%s\n" % (tx, pos, len(text), n))
+    ref = data_utils.load_sites([str(tmp_path)], 20, "norm_hct116.npz")
+    nat = data_utils.load_sites_native([str(tmp_path)], 20, "norm_hct116.npz", n_threads=2)
+    assert np.array_equal(nat.X, ref.X, equal_nan=True)
+    assert np.isnan(nat.X).sum() >= 1 and np.isinf(nat.X).sum() >= 2

@@ -1,5 +1,6 @@
 #!/bin/bash
-# the measurements the round's profiles/ and DESIGN.md quote (run on one MI355X)
+# The measurements profiles/ and DESIGN.md quote, on one MI355X:  tools/gpu_measure.sh <tag>   (outputs: gpurun_out/<tag>_*)
+# One script for every round: earlier rounds kept a copy per GPU session (gpu_r2a..q.sh); their extra steps are flags of bench.py now.
 export TMPDIR=/tmp
 O=gpurun_out
 T=$1

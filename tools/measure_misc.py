@@ -99,6 +99,73 @@ def main():
     out["reference_loop_through_the_stub"] = {"sites": 20_000, "encode_calls_of_16_sites_s": t_enc, "pool_calls_of_32_sites_s": t_pool,
                                               "sites_per_s": 20_000 / (t_enc + t_pool), "us_per_pool_call": t_pool / n_calls * 1e6,
                                               "note": "per-batch / per-flush-group calls with host arrays, as INTEGRATION.md section 2 wires them"}
+    # the same loop STREAMED (m6a_job_begin / feed / end, INTEGRATION.md section 2's recommended wiring): the batches are
+    # fed as a DataLoader would produce them, the GPU works behind the loop, one pooling at the end
+    import ctypes as C
+    X, km = d["X"], d["site_kmers"]
+    batches = [(np.ascontiguousarray(X[off[s0]:off[min(20_000, s0 + 16)]]), np.ascontiguousarray(km[s0:s0 + 16]),
+                np.ascontiguousarray(off[s0:min(20_000, s0 + 16) + 1] - off[s0])) for s0 in range(0, 20_000, 16)]
+    eng.prepare_host_io()
+    want = eng.infer(X, km, off, 1000)
+    streamed = {}
+    for label in ("engine.job_feed (numpy batches)", "raw ctypes calls (pointers prepared)"):
+        best = None
+        for _ in range(4):
+            t0 = time.perf_counter()
+            eng.job_begin(1000)
+            if label.startswith("engine"):
+                for bx, bk, bo in batches:
+                    eng.job_feed(bx, bk, bo)
+            else:
+                L, h = eng._L, eng._h
+                for bx, bk, bo in batches:
+                    L.m6a_job_feed(h, bx.ctypes.data, bk.ctypes.data, bo.ctypes.data, bo.size - 1)
+            t_feed = time.perf_counter() - t0
+            got = eng.job_end()
+            t_all = time.perf_counter() - t0
+            assert all(np.array_equal(a, b) for a, b in zip(got, want))
+            if best is None or t_all < best[1]:
+                best = (t_feed, t_all)
+        streamed[label] = {"feed_loop_s": best[0], "begin_to_end_s": best[1], "sites_per_s": 20_000 / best[1],
+                           "us_per_feed_call": best[0] / len(batches) * 1e6}
+    # ... and through INTEGRATION.md's stub exactly as a reference-side caller would hold the batches (torch tensors,
+    # k-mers per READ as inference_collate builds them)
+    import re
+    text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "INTEGRATION.md")).read()
+    stub = [b for b in re.findall(r"```python\n(.*?)```", text, flags=re.S) if "class HipModel" in b][0]
+    os.environ["M6A_HIP_LIB"] = eng._L._name
+    ns = {}
+    exec(compile(stub, "hip_backend.py", "exec"), ns)
+    from m6anet_amd.engine import load_weights as _lw
+    w = _lw()
+    shapes = [(66, 2), (150, 15), (150,), (150,), (150,), (150,), (150,), (32, 150), (32,), (1, 32), (1,)]
+    sd, at = {}, 0
+    for k, shp in zip(ns["_ORDER"], shapes):
+        n = int(np.prod(shp))
+        sd[k] = torch.from_numpy(w[at:at + n].reshape(shp).copy())
+        at += n
+    model = ns["HipModel"](sd)
+    tb = [(torch.from_numpy(bx), torch.from_numpy(np.repeat(bk.astype(np.int64), np.diff(bo), axis=0)), torch.from_numpy(np.diff(bo)))
+          for bx, bk, bo in batches]
+    best = None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        model.begin(1000, 0.033379376, 0, 16, 2)
+        for f, k, n in tb:
+            model.feed(f, k, n)
+        t_feed = time.perf_counter() - t0
+        got = model.end()
+        t_all = time.perf_counter() - t0
+        assert all(np.array_equal(a, b) for a, b in zip(got, want))
+        if best is None or t_all < best[1]:
+            best = (t_feed, t_all)
+    streamed["INTEGRATION.md stub (torch batches as the reference's collate builds them)"] = {
+        "feed_loop_s": best[0], "begin_to_end_s": best[1], "sites_per_s": 20_000 / best[1], "us_per_feed_call": best[0] / len(tb) * 1e6}
+    t0 = time.perf_counter()
+    eng.infer(X, km, off, 1000)
+    streamed["one m6a_infer over the whole job (host arrays)"] = {"sites_per_s": 20_000 / (time.perf_counter() - t0)}
+    out["reference_loop_streamed"] = dict(streamed, sites=20_000, reads=int(off[-1]), batches=len(batches),
+                                          note="16-site batches, host arrays, T = 1000; results bit-identical to one m6a_infer")
     # validation-style forward: 5 passes over 200 k ragged sites, device tensors
     eng = M6ANetEngine(weights=load_weights("HEK293T_RNA004"))
     d = synthetic.make_sites(200_000, (50, 500), seed=1)
