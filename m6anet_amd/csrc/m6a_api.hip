@@ -1596,7 +1596,8 @@ int job_feed_impl(m6a_ctx *c, const float *X, const uint8_t *km, const int64_t *
             continue;
         }
         const int64_t r0 = off[i], nr = off[i + k] - r0;
-        std::memcpy(pin + j.o_x + (size_t)j.fill_reads * M6A_N_FEATURES * 4, X + r0 * M6A_N_FEATURES, (size_t)nr * M6A_N_FEATURES * 4);
+        // a DataLoader-sized batch is one memcpy on the caller's thread (16 sites ~ 30 KB); megabyte batches use the copy threads
+        c->stg.pool->copy(pin + j.o_x + (size_t)j.fill_reads * M6A_N_FEATURES * 4, X + r0 * M6A_N_FEATURES, (size_t)nr * M6A_N_FEATURES * 4);
         std::memcpy(pin + j.o_km + (size_t)j.fill_sites * 3, km + i * 3, (size_t)k * 3);
         job_append_offsets(c, pin, off, i, k);
         i += k;
@@ -2178,11 +2179,64 @@ struct MtBulk {
     inline uint32_t next() { if (pos == 624) refill(); return out[pos++]; }
 };
 
-// the training-mode sampler of a whole validation run (data_utils.py:213-214 under
-// training_utils.py:235-240, num_workers=0): RandomState.choice(n, K, replace=False) =
-// permutation(n)[:K] = legacy shuffle of arange(n): for i = n-1..1: j = rk_interval(i) (masked rejection over
-// 32-bit words), swap.  One stream, seeded once, pass after pass, site after site -- inherently serial, so it
-// runs here; gidx gets GLOBAL read indices [T][S][K].
+// The training-mode sampler of a whole validation run (data_utils.py:213-214 under training_utils.py:235-240,
+// num_workers=0): RandomState.choice(n, K, replace=False) = permutation(n)[:K] = the legacy shuffle of arange(n): for
+// i = n-1..1: j = rk_interval(i) (masked rejection over 32-bit words), swap.  ONE stream, seeded once, pass after pass,
+// site after site: where an item (pass, site) starts depends on how many words every earlier shuffle rejected, so the walk
+// over the stream is a chain.  It is split in two:
+//   * the WALK (this thread): per item only COUNT -- i steps down on every accepted word, the mask changes when i crosses a
+//     power of two -- no permutation, no memory traffic, ~1 ns per word; it hands out blocks of items together with the
+//     stream words they consume and every item's offset into them;
+//   * the SHUFFLES (worker threads): every item replayed from its offset, independently of all others.
+// Both loops are branch-free per word (the accept/reject branch of the textbook loop mispredicts every third word): inside
+// a phase -- i in [2^b, 2^(b+1)) -- the mask is fixed, acceptance is one compare, the swap is two unconditional stores of
+// selected values.  gidx gets GLOBAL read indices [T][S][K].
+struct ValBlock {
+    int64_t k0 = 0, k1 = 0;                  // items [k0, k1) of the run, item k = (pass k / S, site k % S)
+    std::vector<uint32_t> words;             // the stream words these items consume, in order
+    std::vector<uint32_t> start;             // offset of every item's first word in `words`
+};
+
+// words the shuffle of n entries consumes from w[] (w holds at least `avail` words; returns ~0 if they run out)
+inline size_t shuffle_count(const uint32_t *w, size_t avail, uint32_t n, uint32_t *i_io)
+{
+    uint32_t i = *i_io;
+    size_t q = 0;
+    while (i) {
+        const uint32_t mask = 0xffffffffu >> __builtin_clz(i), lo = (mask >> 1) + 1;      // this phase: i in [lo, mask]
+        for (;;) {
+            if (q == avail) { *i_io = i; return q; }
+            i -= ((w[q++] & mask) <= i);
+            if (i < lo) break;
+        }
+    }
+    (void)n;
+    *i_io = 0;
+    return q;
+}
+
+// the shuffle itself: p holds >= 2 * n + 2 entries (a rejected word indexes up to the mask, its slot is rewritten unchanged)
+inline void shuffle_item(const uint32_t *w, uint32_t n, int32_t *p, int K, int32_t base, int32_t *out)
+{
+    for (uint32_t i = 0; i < n; i++) p[i] = (int32_t)i;
+    uint32_t i = n - 1;
+    int32_t a = p[i];                         // perm[i] rides in a register while i stands still
+    while (i) {
+        const uint32_t mask = 0xffffffffu >> __builtin_clz(i), lo = (mask >> 1) + 1;
+        for (;;) {
+            const uint32_t v = *w++ & mask;
+            const bool acc = v <= i;
+            const int32_t b = p[v];
+            p[i] = acc ? b : a;
+            p[v] = acc ? a : b;
+            i -= acc;
+            a = p[i];
+            if (i < lo) break;
+        }
+    }
+    for (int k = 0; k < K; k++) out[k] = base + p[k];
+}
+
 int validation_indices(m6a_ctx *c, const int64_t *h_off, int64_t S, int T, int K, uint32_t seed, std::vector<int32_t> &gidx)
 {
     int64_t nmax = 0;
@@ -2194,21 +2248,73 @@ int validation_indices(m6a_ctx *c, const int64_t *h_off, int64_t S, int T, int K
     }
     if (h_off[S] > 0x7fffffff) return fail(c, M6A_EUNSUPPORTED, "more than 2^31 reads");
     gidx.resize((size_t)T * S * K);
-    std::vector<int32_t> perm((size_t)nmax);
-    MtBulk gen(seed);
-    int32_t *out = gidx.data();
-    for (int t = 0; t < T; t++)
-        for (int64_t s = 0; s < S; s++) {
-            const int64_t n = h_off[s + 1] - h_off[s];
-            for (int64_t i = 0; i < n; i++) perm[i] = (int32_t)i;
-            for (uint32_t i = (uint32_t)n - 1; i >= 1; i--) {
-                const uint32_t mask = 0xffffffffu >> __builtin_clz(i);       // smallest 2^b - 1 >= i
-                uint32_t v;
-                do { v = gen.next() & mask; } while (v > i);
-                const int32_t x = perm[i]; perm[i] = perm[v]; perm[v] = x;
-            }
-            for (int k = 0; k < K; k++) *out++ = (int32_t)h_off[s] + perm[k];
+    const int64_t n_items = (int64_t)T * S;
+    const int64_t block_items = 2048;
+    const char *env = getenv("M6A_VALIDATE_THREADS");
+    int n_workers = env ? atoi(env) : (int)std::min<unsigned>(32u, std::max(1u, std::thread::hardware_concurrency() / 2));
+    if (n_items < 4 * block_items || n_workers < 1) n_workers = 0;          // small runs: walk and shuffle on this thread
+
+    std::mutex mu;
+    std::condition_variable cv_put, cv_get;
+    std::vector<std::unique_ptr<ValBlock>> queue;
+    bool done = false;
+    auto shuffle_block = [&](const ValBlock &b, std::vector<int32_t> &perm) {
+        for (int64_t k = b.k0; k < b.k1; k++) {
+            const int64_t s = k % S;
+            shuffle_item(b.words.data() + b.start[(size_t)(k - b.k0)], (uint32_t)(h_off[s + 1] - h_off[s]), perm.data(), K, (int32_t)h_off[s],
+                         gidx.data() + (size_t)k * K);
         }
+    };
+    std::vector<std::thread> workers;
+    for (int t = 0; t < n_workers; t++)
+        workers.emplace_back([&] {
+            std::vector<int32_t> perm((size_t)2 * nmax + 2);
+            for (;;) {
+                std::unique_ptr<ValBlock> b;
+                {
+                    std::unique_lock<std::mutex> g(mu);
+                    cv_get.wait(g, [&] { return done || !queue.empty(); });
+                    if (queue.empty()) return;
+                    b = std::move(queue.back());
+                    queue.pop_back();
+                }
+                cv_put.notify_one();
+                shuffle_block(*b, perm);
+            }
+        });
+
+    MtBulk gen(seed);
+    std::vector<int32_t> perm0;
+    if (!n_workers) perm0.resize((size_t)2 * nmax + 2);
+    for (int64_t k0 = 0; k0 < n_items; k0 += block_items) {
+        std::unique_ptr<ValBlock> b(new ValBlock);
+        b->k0 = k0; b->k1 = std::min(n_items, k0 + block_items);
+        b->start.resize((size_t)(b->k1 - b->k0));
+        b->words.reserve((size_t)(b->k1 - b->k0) * (size_t)nmax * 3 / 2 + 2048);
+        b->words.assign(gen.out + gen.pos, gen.out + 624);                  // what is left of the current refill
+        size_t cur = 0;
+        for (int64_t k = b->k0; k < b->k1; k++) {
+            const int64_t s = k % S;
+            const uint32_t n = (uint32_t)(h_off[s + 1] - h_off[s]);
+            b->start[(size_t)(k - b->k0)] = (uint32_t)cur;
+            uint32_t i = n - 1;
+            while (i) {
+                cur += shuffle_count(b->words.data() + cur, b->words.size() - cur, n, &i);
+                if (i) { gen.refill(); b->words.insert(b->words.end(), gen.out, gen.out + 624); }
+            }
+        }
+        gen.pos = 624 - (int)(b->words.size() - cur);                        // the next block starts inside this refill
+        if (!n_workers) { shuffle_block(*b, perm0); continue; }
+        {
+            std::unique_lock<std::mutex> g(mu);
+            cv_put.wait(g, [&] { return queue.size() < 4 * (size_t)n_workers; });
+            queue.push_back(std::move(b));
+        }
+        cv_get.notify_one();
+    }
+    { std::lock_guard<std::mutex> g(mu); done = true; }
+    cv_get.notify_all();
+    for (auto &w : workers) w.join();
     return M6A_OK;
 }
 

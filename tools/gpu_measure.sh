@@ -5,11 +5,15 @@ export TMPDIR=/tmp
 O=gpurun_out
 T=$1
 mkdir -p $O
+# the bench lines: default (configs[2] + the `ragged` key), --workload ragged, and both sustained for >= 10 s
 python bench.py > $O/${T}_bench_uniform.json 2> $O/${T}_bench_uniform.err
 python bench.py --workload ragged > $O/${T}_bench_ragged.json 2> $O/${T}_bench_ragged.err
-CMD="python bench.py --no-cpu-baseline --no-live-traffic"
+python bench.py --min-seconds 10 --no-cpu-baseline --no-live-traffic --no-ragged-extra > $O/${T}_bench_uniform_sustained.json 2> $O/${T}_sustained.err
+python bench.py --workload ragged --min-seconds 10 --no-cpu-baseline --no-live-traffic > $O/${T}_bench_ragged_sustained.json 2>> $O/${T}_sustained.err
+# kernel trace + PMC passes (counters in their own runs, --kernel-trace only)
+CMD="python bench.py --no-cpu-baseline --no-live-traffic --no-ragged-extra"
 rocprofv3 --kernel-trace --stats -d $O/${T}_trace -o bench -- $CMD > $O/${T}_trace.json 2> $O/${T}_trace.err
-SHORT="python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-live-traffic"
+SHORT="python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-live-traffic --no-ragged-extra"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/${T}_pmc_fetch -o pmc -- $SHORT > /dev/null 2> $O/${T}_pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/${T}_pmc_write -o pmc -- $SHORT > /dev/null 2> $O/${T}_pmc_write.err
 rocprofv3 --pmc SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT --kernel-trace -d $O/${T}_pmc_sq -o pmc -- $SHORT > /dev/null 2> $O/${T}_pmc_sq.err
@@ -20,7 +24,17 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/${T}_pmc_fetch_ragged -o pmc -- 
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/${T}_pmc_write_ragged -o pmc -- $RSHORT > /dev/null 2> $O/${T}_pmc_write_ragged.err
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_SALU SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU --kernel-trace -d $O/${T}_pmc_sq_ragged -o pmc -- $RSHORT > /dev/null 2> $O/${T}_pmc_sq_ragged.err
 for f in $(find $O -name "*_results.db" -path "*${T}_*" | sort); do python tools/rocpd_summary.py $f; done > $O/${T}_summary.txt 2>&1
+# the first call, as a timeline (HIP API + kernels) and by phase
+rocprofv3 --hip-trace --kernel-trace --memory-copy-trace --output-format csv -d $O/${T}_tl -o tl -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-live-traffic --no-ragged-extra > /dev/null 2> $O/${T}_tl.err
+python tools/first_call_timeline.py $O/${T}_tl > $O/${T}_first_call_timeline.txt 2>&1
+python tools/first_call_probe.py > $O/${T}_first_call.json 2> $O/${T}_first_call.err
+# microbenchmarks behind the ceilings, the stream generator, the feed API from plain C
+./tools/gpr_variants > $O/${T}_gpr_variants.txt 2>&1
+./tools/rg_probe > $O/${T}_rg_probe.txt 2>&1
+python tools/stream_probe.py > $O/${T}_stream.json 2> $O/${T}_stream.err
+{ ./tools/feed_probe 20000 16; ./tools/feed_probe 20000 1024; ./tools/feed_probe 1000000 16 20 20; ./tools/feed_probe 1000000 4096 20 20; } > $O/${T}_feed_probe.json 2>&1
 python tools/measure_misc.py > $O/${T}_misc.json 2> $O/${T}_misc.err
 python tools/measure_cli.py > $O/${T}_cli.json 2> $O/${T}_cli.err
 find $O -name "*.db" -path "*${T}_*" -size +20M -delete
+find $O -path "*${T}_tl*" -size +10M -delete
 echo done
