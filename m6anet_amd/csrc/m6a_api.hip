@@ -1668,8 +1668,9 @@ inline void settle(m6a_ctx *c) { if (c && c->warm.joinable()) c->warm.join(); }
 // Background half of m6a_create: everything a first call with the reference's DEFAULT job parameters would otherwise
 // build inside the call -- seed 0 (scripts/inference.py:60), num_iterations 1000 (:56), 20 samples
 // (inference_utils.py:54), batch_size 16 x save_per_batch 2 (:46-50) -> flush groups of <= 32 sites: the pairwise-sum
-// plan, the MT19937 stream, the index-table arena (sized for M6A_WARM_SLOTS bag sizes, default 512: 1.4 GB of a 288 GB
-// part) and the tables of the smallest legal bag (min_reads = 20, constants.py:14).  Runs on the side stream from its
+// plan, the MT19937 stream, the index tables of bag sizes 2 .. M6A_WARM_SLOTS - 1 (default 512: 1.4 GB of a 288 GB part,
+// one 1.2 ms pass of an idle GPU) and the register kernel's table of the smallest legal bag (min_reads = 20,
+// constants.py:14).  Runs on the side stream from its
 // own thread, so neither m6a_create nor the caller's loader waits for it; a first call with other parameters simply
 // rebuilds what differs, exactly as before.  M6A_WARMUP=0 turns it off.
 void warm_default(m6a_ctx *c)
@@ -1691,6 +1692,14 @@ void warm_default(m6a_ctx *c)
         const char *e = getenv("M6A_WARM_SLOTS");
         c->rt_presize = e && atoi(e) > 0 ? std::min(atoi(e), M6A_RTAB_MAX_N + 1) : 512;
         rc = ensure_table_reg(c, seed, n, T, K, (int)gmax);
+        if (!rc) {
+            // ... and the index table of every bag size the arena was sized for: one pass over the stream for all of them
+            // (1.2 ms of an idle GPU); a first call then only builds tables for bags beyond that
+            std::vector<uint32_t> hist(M6A_HIST_BINS, 0u);
+            for (int m = 2; m < c->rt_presize && m <= M6A_RTAB_MAX_N; m++) hist[m] = 1;
+            bool usable = false;
+            rc = ensure_rtab(c, seed, T, K, gmax, hist.data(), &usable);
+        }
         c->rt_presize = 0;
     }
     (void)hipStreamSynchronize(c->s_prep);

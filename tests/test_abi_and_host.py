@@ -154,3 +154,37 @@ def test_multi_gpu_rank_command_line_round_trips():
     assert vars(p.parse_args(multi_gpu.rank_argv(a))) == vars(a)
     a = p.parse_args(["--input_dir", "x.m6astore", "--out_dir", "o"])
     assert vars(p.parse_args(multi_gpu.rank_argv(a))) == vars(a)
+
+
+def test_mt19937_jump_polynomials_against_numpy():
+    """assets/mt19937_jump.bin (tools/make_mt_jump.py; embedded in libm6a_hip.so for the segmented stream generator):
+    r = t^(i*G - 512) mod phi means  out[k + i*G - 512] = XOR over the set coefficients t of r of out[k + t]  for NumPy's
+    legacy stream (tempering is linear, so the relation holds for the outputs).  Checked here for the first polynomials of
+    the 2^16 and 2^20 regimes and the header for all three."""
+    import struct
+    from m6anet_amd.constants import asset_path
+    blob = open(asset_path("mt19937_jump.bin"), "rb").read()
+    assert blob[:8] == b"M6AMTJP1"
+    n_reg, n_per, words, back = struct.unpack("<IIII", blob[8:24])
+    assert (n_reg, n_per, words, back) == (3, 31, 312, 512) and len(blob) == 24 + n_reg * (8 + n_per * words * 8)
+    per = 8 + n_per * words * 8
+    out = np.frombuffer(np.random.RandomState(2024).bytes(4 * (3 * (1 << 20) + 22000)), dtype=np.uint32)
+    Gs = []
+    for r in range(n_reg):
+        base = 24 + r * per
+        G, = struct.unpack("<Q", blob[base:base + 8])
+        Gs.append(G)
+        for i in (1, 2, 3) if r < 2 else ():
+            poly = np.frombuffer(blob, dtype=np.uint64, count=words, offset=base + 8 + (i - 1) * words * 8)
+            bits = np.unpackbits(poly.view(np.uint8), bitorder="little")
+            taps = np.flatnonzero(bits)
+            assert taps.max() < 19937 and 1000 < taps.size < 11000
+            D = i * G - back
+            if D + 400 + 19937 > out.size:
+                continue
+            ks = np.arange(0, 300)
+            acc = np.zeros(ks.size, np.uint32)
+            for t in taps:
+                acc ^= out[ks + t]
+            assert np.array_equal(acc, out[ks + D]), (G, i)
+    assert Gs == [1 << 16, 1 << 20, 1 << 24]

@@ -506,3 +506,17 @@ def test_validation_sampler_walk_and_parallel_shuffles(eng, orc, monkeypatch):
             monkeypatch.setenv("M6A_VALIDATE_THREADS", threads)
         y, avg = eng.validate_pool(rp, off, 3, seed=9)
         assert np.array_equal(y, want_y) and np.array_equal(avg, want_avg), threads
+
+
+def test_configs1_at_full_size(eng, orc, weights):
+    """BASELINE.json configs[1] at its full size -- 100 000 synthetic DRACH sites x 20 reads, HCT116 weights,
+    num_iterations = 100 -- every read and every site against the oracle: read probabilities within rtol 1e-5, site
+    probabilities and mod_ratio of ALL sites bit-identical given the same read probabilities."""
+    d = synthetic.make_sites(100_000, 20, seed=20250328)
+    rp, site, mod = eng.infer(d["X"], d["site_kmers"], d["off"], 100, 20, THR, 0, 16, 2)
+    assert eng.last_pool_variant == "table-reg" and eng.last_encoder_variant == "csite12"
+    threads = os.cpu_count() or 8
+    want_rp = orc.encode_reads(weights["hct116"], d["X"], d["site_kmers"], d["off"], n_threads=threads)
+    assert np.allclose(rp, want_rp, rtol=1e-5, atol=1e-8)
+    want_site, want_mod = orc.site_pool(rp, d["off"], 100, THR, n_threads=threads)
+    assert np.array_equal(site, want_site) and np.array_equal(mod, want_mod)
