@@ -470,9 +470,9 @@ class Bench:
                     t_leg = time.perf_counter() - t0
                 else:
                     t_leg = self.timed(steps)
+                t_leg, = self.max_over_ranks(t_leg)           # every rank adds the same number: they leave the loop together
                 t_all += t_leg
                 n_done += steps
-            t_all, = self.max_over_ranks(t_all)
             sustained = {"seconds": t_all, "steps": n_done, "ms_per_step": t_all / n_done * 1e3, "rocm_smi_under_load": smi}
         dt, first_call_ms = self.max_over_ranks(dt, first_call_ms)
         return {"dt": dt, "first_call_ms": first_call_ms, "second_call_ms": second_call_ms, "enc_ms": enc_ms, "enc_n": enc_n, "pool_ms": pool_ms, "pool_n": pool_n,

@@ -520,3 +520,13 @@ def test_configs1_at_full_size(eng, orc, weights):
     assert np.allclose(rp, want_rp, rtol=1e-5, atol=1e-8)
     want_site, want_mod = orc.site_pool(rp, d["off"], 100, THR, n_threads=threads)
     assert np.array_equal(site, want_site) and np.array_equal(mod, want_mod)
+
+
+def test_bench_sustained_leg_with_two_ranks():
+    """--min-seconds keeps stepping after the timed region; with several ranks the loop's exit is a collective decision
+    (every rank adds the slowest rank's time), so nobody is left waiting at a barrier."""
+    out, lines = run_bench(["--gpus", "2", "--sites", "3001", "--iters", "60", "--steps", "3", "--warmup", "1", "--min-seconds", "1.0",
+                            "--no-cpu-baseline"], {"M6A_BENCH_BACKEND": "gloo", "M6A_BENCH_TIMEOUT": "300"}, timeout=600)
+    assert out.returncode == 0 and len(lines) == 1, out.stderr[-2000:]
+    d = lines[0]
+    assert d["value_sustained"] > 0 and d["sustained"]["seconds"] >= 1.0 and d["sustained"]["steps"] % 3 == 0
