@@ -135,8 +135,18 @@ class NativeGather:
                 engine.comm_destroy()
             raise RuntimeError("m6a_comm_init failed on a rank%s" % (": " + why if why else ""))
         total = int(self.cuts[-1])
+        n = int(self.cuts[self.rank + 1] - self.cuts[self.rank])
         self.out = [(torch.empty(total, dtype=torch.float32, device=device), torch.empty(total, dtype=torch.float64, device=device))
                     if self.rank == dst else None for _ in range(2)]
+        # The exchange runs on a side stream so that it is not a link in the compute stream's chain (pooling of step i ->
+        # exchange -> encoder of step i+1): the shard's results are copied into one of two send buffers on the compute
+        # stream, the side stream waits for that copy and carries the RCCL group, and a buffer is reused only after the
+        # exchange that read it has finished.
+        self.send = [(torch.empty(n, dtype=torch.float32, device=device), torch.empty(n, dtype=torch.float64, device=device)) for _ in range(2)]
+        self.side = torch.cuda.Stream(device=device)
+        self.copied = [torch.cuda.Event() for _ in range(2)]
+        self.sent = [torch.cuda.Event() for _ in range(2)]
+        self.in_flight = [False, False]
         self.slot = 0
 
     def _all_ok(self, ok):
@@ -169,15 +179,31 @@ class NativeGather:
         return why or "m6a_gather self-test failed on another rank"
 
     def start(self, site, mod):
+        torch = self.torch
         k = self.slot
-        self.engine.gather(site, mod, self.cuts, self.dst, out=self.out[k])      # stream-ordered behind the pooling kernel
+        cur = torch.cuda.current_stream(self.device)
+        if self.in_flight[k]:
+            cur.wait_event(self.sent[k])                      # the exchange two steps ago has read this send buffer
+        self.send[k][0].copy_(site)
+        self.send[k][1].copy_(mod)
+        self.copied[k].record(cur)
+        self.side.wait_event(self.copied[k])
+        self.engine.set_stream(self.side.cuda_stream)         # m6a_gather is enqueued on the context's stream
+        try:
+            self.engine.gather(self.send[k][0], self.send[k][1], self.cuts, self.dst, out=self.out[k])
+        finally:
+            self.engine.use_torch_stream()
+        self.sent[k].record(self.side)
+        self.in_flight[k] = True
         self.slot ^= 1
         return k
 
     def finish(self, k=None):
+        self.side.synchronize()
         self.engine.sync()
         o = self.out[self.slot ^ 1 if k is None else k]
         return o if o is not None else (None, None)
 
     def drain(self):
+        self.side.synchronize()
         self.engine.sync()
