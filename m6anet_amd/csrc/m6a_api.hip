@@ -429,9 +429,9 @@ struct JumpRegime { int64_t G; const uint64_t *polys; };   // polys: host pointe
 const JumpRegime *jump_regimes(int *n_out)
 {
     static JumpRegime reg[8];
-    static int n = -1;
-    if (n < 0) {
-        n = 0;
+    static int n = 0;
+    static std::once_flag once;                            // contexts may be created (and warmed) from several threads at once
+    std::call_once(once, [] {
         const unsigned char *b = m6a_mt_jump_blob;
         const size_t len = (size_t)(m6a_mt_jump_blob_end - m6a_mt_jump_blob);
         uint32_t hdr[4];
@@ -447,7 +447,7 @@ const JumpRegime *jump_regimes(int *n_out)
                     reg[n++] = {G, (const uint64_t *)(q + 8)};
                 }
         }
-    }
+    });
     *n_out = n;
     return reg;
 }

@@ -90,6 +90,16 @@ def launch(args):
     base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
     xdir = tempfile.mkdtemp(prefix="m6a_gpus_", dir=base)
     procs = []
+    # a terminated launcher still takes its ranks down and removes the exchange directory (a packed store can be hundreds of MB
+    # of /dev/shm): SIGTERM becomes an exception, so the `finally` below runs
+    import signal
+
+    def on_term(signum, frame):
+        raise SystemExit(128 + signum)
+    try:
+        signal.signal(signal.SIGTERM, on_term)
+    except ValueError:                                       # not the main thread (the CLI called from a library): keep the default
+        pass
     try:
         given_store = len(args.input_dir) == 1 and str(args.input_dir[0]).endswith(STORE_SUFFIX)
         store = os.path.abspath(args.input_dir[0]) if given_store else os.path.join(xdir, "job" + STORE_SUFFIX)
