@@ -251,6 +251,7 @@ struct m6a_ctx {
     struct Job {
         bool open = false;
         int failed = 0;                       // first error of a feed: the job is void, m6a_job_end reports it
+        std::string failed_msg;               // ... with the text it had (other calls may have overwritten the context's since)
         int T = 0, K = 0; float thr = 0.f; uint32_t seed = 0; int64_t bs = 1, spb = 1;
         std::vector<int64_t> off;             // the job's CSR offsets so far, host [S+1]
         int64_t S = 0, R = 0;                 // sites / reads fed so far (R == off[S])
@@ -2030,7 +2031,7 @@ int m6a_job_begin(m6a_ctx *c, int T, int K, float thr, uint32_t seed, int rng_mo
     } catch (const std::bad_alloc &) {
         return fail(c, M6A_ENOMEM, "out of host memory");
     }
-    j.S = j.R = 0; j.item = 0; j.chunks = 0; j.failed = 0;
+    j.S = j.R = 0; j.item = 0; j.chunks = 0; j.failed = 0; j.failed_msg.clear();
     j.fill_sites = j.fill_reads = 0; j.fill_min = INT64_MAX; j.cur_ready = false;
     std::fill(j.used.begin(), j.used.end(), 0);
     // the ring may still carry DMAs of an earlier host-pointer call or job on other streams: start from idle
@@ -2047,7 +2048,7 @@ int m6a_job_feed(m6a_ctx *c, const float *X, const uint8_t *km, const int64_t *o
     if (!c) return M6A_EINVAL;
     auto &j = c->job;
     if (!j.open) return fail(c, M6A_EINVAL, "no streaming job is open (m6a_job_begin)");
-    if (j.failed) return j.failed;                                   // message of the first failure is still in place
+    if (j.failed) { c->err = j.failed_msg; return j.failed; }        // the first failure, with its own text
     if (n_sites < 0) return fail(c, M6A_EINVAL, "n_sites < 0");
     if (n_sites == 0) return M6A_OK;
     if (!km || !off) return fail(c, M6A_EINVAL, "null pointer argument");
@@ -2062,7 +2063,7 @@ int m6a_job_feed(m6a_ctx *c, const float *X, const uint8_t *km, const int64_t *o
     } catch (const std::bad_alloc &) {                       // the job's host copy of off[] grows with every batch
         rc = fail(c, M6A_ENOMEM, "out of host memory");
     }
-    if (rc) j.failed = rc;
+    if (rc) { j.failed = rc; j.failed_msg = c->err; }
     return rc;
 }
 
@@ -2095,7 +2096,12 @@ int m6a_job_end(m6a_ctx *c, float *rp, float *site, double *mod)
     HintScope hint_scope(c);
     HIPCHK(c, hipSetDevice(c->device));
     struct Closer { m6a_ctx *c; ~Closer() { (void)m6a_job_abort(c); } } closer{c};     // whatever happens, the job ends here
-    if (j.failed) return j.failed;
+    if (j.failed) {
+        const int rc_failed = j.failed;
+        (void)m6a_job_abort(c);                                      // (may touch the error text)
+        c->err = j.failed_msg;
+        return rc_failed;
+    }
     int rc = job_flush(c);
     if (rc) return rc;
     const int64_t S = j.S, R = j.R;

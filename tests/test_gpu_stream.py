@@ -157,10 +157,12 @@ def test_job_stream_errors(eng):
     with pytest.raises(_lib.M6AError) as e1:
         eng._chk(eng._L.m6a_job_feed(eng._h, d["X"].ctypes.data, d["site_kmers"].ctypes.data, bad.ctypes.data, 40))
     assert e1.value.code == -1
-    with pytest.raises(_lib.M6AError) as e2:                      # the job is void: feeds and the end report the first failure
+    with pytest.raises(_lib.M6AError, match="streaming job is open"):      # (overwrites the context's error text)
+        eng.infer(d["X"], d["site_kmers"], d["off"], 10)
+    with pytest.raises(_lib.M6AError, match=r"off\[0\] must be 0") as e2:   # the job is void: feeds and the end report the FIRST failure
         eng.job_feed(d["X"], d["site_kmers"], d["off"])
     assert e2.value.code == -1
-    with pytest.raises(_lib.M6AError):
+    with pytest.raises(_lib.M6AError, match=r"off\[0\] must be 0"):
         eng.job_end()
     got = feed_in_batches(eng, d, 16, n_iters=10)                 # and the context is usable again
     want = eng.infer(d["X"], d["site_kmers"], d["off"], 10)
