@@ -107,7 +107,7 @@ def live_traffic(workload, kernel_name, timeout_s=240):
         d = tempfile.mkdtemp(prefix="m6a_pmc_")
         try:
             cmd = ["rocprofv3", "--pmc", ctr, "--kernel-trace", "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
-                   "--workload", workload, "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-live-traffic", "--no-ragged-extra"]
+                   "--workload", workload, "--steps", "3", "--warmup", "1", "--min-seconds", "0", "--no-cpu-baseline", "--no-live-traffic", "--no-ragged-extra"]
             subprocess.run(cmd, capture_output=True, timeout=timeout_s, env=dict(os.environ, TMPDIR=os.environ.get("TMPDIR", "/tmp")))
             dbs = glob.glob(os.path.join(d, "**", "*_results.db"), recursive=True)
             if not dbs:
@@ -582,9 +582,10 @@ def main():
     ap.add_argument("--sites", type=int, default=None, help="sites per GPU (default: the workload's)")
     ap.add_argument("--reads", type=int, default=None, help="uniform workload: reads per site (default 20)")
     ap.add_argument("--iters", type=int, default=1000, help="num_iterations")
-    ap.add_argument("--min-seconds", type=float, default=0.0,
-                    help="after the timed region keep stepping for at least this long and report value_sustained plus rocm-smi's "
-                         "clock / power under load (the K-step region is tens of milliseconds: inside one DVFS window)")
+    ap.add_argument("--min-seconds", type=float, default=3.0,
+                    help="after the timed region (which alone defines `value`) keep stepping for at least this long and report "
+                         "value_sustained plus rocm-smi's clock / power under load -- the K-step region is tens of milliseconds, inside "
+                         "one DVFS window; 0 skips the leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ragged-extra", action="store_true",
                     help="default run only: skip the extra `ragged` key (configs[4]'s per-GPU shape, ~10 steps after the headline)")

@@ -663,7 +663,7 @@ def test_bench_self_launch_two_ranks_equal_the_whole_job(workload, sites):
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, M6A_BENCH_BACKEND="gloo")
     out = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--workload", workload, "--sites", str(sites),
-                          "--iters", "60", "--steps", "2", "--warmup", "1", "--verify", "--no-cpu-baseline"],
+                          "--iters", "60", "--steps", "2", "--warmup", "1", "--min-seconds", "0", "--verify", "--no-cpu-baseline"],
                          capture_output=True, text=True, env=env, timeout=900)
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert out.returncode == 0 and len(lines) == 1, out.stderr[-2000:]

@@ -385,7 +385,7 @@ def one_rank_env():
             "M6A_BENCH_FORCE_EXCHANGE": "1"}
 
 
-SMALL = ["--sites", "3001", "--iters", "60", "--steps", "2", "--warmup", "1", "--verify", "--no-cpu-baseline", "--no-live-traffic"]
+SMALL = ["--sites", "3001", "--iters", "60", "--steps", "2", "--warmup", "1", "--min-seconds", "0", "--verify", "--no-cpu-baseline", "--no-live-traffic"]
 
 
 def test_bench_native_exchange_is_the_default_and_checks_itself():
@@ -410,7 +410,7 @@ def test_bench_prints_its_line_when_a_rank_dies():
     """Rank 1 dies before the timed region: torch.distributed.run takes rank 0 down, and rank 0 still prints ONE JSON line
     -- its own measurements plus the reason -- and the run exits non-zero instead of hanging."""
     out, lines = run_bench(["--gpus", "2", "--workload", "ragged", "--sites", "700", "--iters", "60", "--steps", "2", "--warmup", "1",
-                            "--no-cpu-baseline"], {"M6A_BENCH_BACKEND": "gloo", "M6A_BENCH_TEST_KILL_RANK": "1", "M6A_BENCH_TIMEOUT": "240"},
+                            "--min-seconds", "0", "--no-cpu-baseline"], {"M6A_BENCH_BACKEND": "gloo", "M6A_BENCH_TEST_KILL_RANK": "1", "M6A_BENCH_TIMEOUT": "240"},
                            timeout=600)
     assert out.returncode != 0
     assert len(lines) == 1, (out.stdout[-1000:], out.stderr[-2000:])
