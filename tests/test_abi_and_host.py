@@ -188,3 +188,27 @@ def test_mt19937_jump_polynomials_against_numpy():
                 acc ^= out[ks + t]
             assert np.array_equal(acc, out[ks + D]), (G, i)
     assert Gs == [1 << 16, 1 << 20, 1 << 24]
+
+
+def test_multi_gpu_exchange_plumbing(tmp_path, monkeypatch):
+    """The pieces of `inference --gpus N` that need no GPU: more ranks than visible devices is refused (there are none
+    here), an unknown transport is an error, a rank never waits for ever on a peer, results are published atomically."""
+    import os
+    from m6anet_amd import multi_gpu
+    monkeypatch.delenv("M6A_EXCHANGE", raising=False)
+    with pytest.raises(RuntimeError, match="HIP device"):
+        multi_gpu.exchange_mode(2)
+    monkeypatch.setenv("M6A_EXCHANGE", "carrier-pigeon")
+    with pytest.raises(ValueError):
+        multi_gpu.exchange_mode(2)
+    monkeypatch.setenv("M6A_EXCHANGE", "host")
+    assert multi_gpu.exchange_mode(64) == "host"
+    monkeypatch.setenv("M6A_EXCHANGE_TIMEOUT", "0.2")
+    with pytest.raises(TimeoutError, match="rank 3"):
+        multi_gpu._wait_for(str(tmp_path / "never"), "rank 3's results", os.getppid())
+    with pytest.raises(RuntimeError, match="launcher has gone away"):
+        multi_gpu._wait_for(str(tmp_path / "never"), "anything", os.getppid() + 12345)
+    p = str(tmp_path / "shard1.bin")
+    multi_gpu._publish(p, b"abc" * 1000)
+    assert open(p, "rb").read() == b"abc" * 1000 and os.listdir(tmp_path) == ["shard1.bin"]
+    multi_gpu._wait_for(p, "present", os.getppid())
