@@ -520,16 +520,23 @@ class Bench:
         pool_kernel = {"table-reg": "pool_reg_kernel", "table": "pool_table_kernel", "ragged-table": "pool_rtab_kernel"}.get(
             eng.last_pool_variant, "pool_scan_kernels")
         proof = pool_roofline(eng.last_pool_variant, draws, pool_avg_ms, r["pool_n"])
-        if gather_ceiling and eng.last_pool_variant == "table-reg" and self.rank == 0:
-            m = measured_multiply_ceiling()
-            if m is not None and proof["achieved"]:
-                proof["measured_ceiling"] = {"peak": m["rate"] / 1e12, "unit": "T draws/s", "frac": proof["achieved"] * 1e12 / m["rate"],
-                                             "source": m["source"], "T_draws_per_s_by_variant": m["rows"]}
-        if gather_ceiling and eng.last_pool_variant == "ragged-table" and self.rank == 0:
-            m = measured_gather_ceiling(bag)
-            if m is not None and proof["achieved"]:
-                proof["measured_ceiling"] = {"peak": m["rate"] / 1e12, "unit": "T draws/s", "frac": proof["achieved"] * 1e12 / m["rate"],
-                                             "source": m["source"], "T_gathers_per_s_by_bag_size": m["points"]}
+        # the pooling kernels are priced against what the part DELIVERS for their instruction mix, measured by this run with the
+        # microbenchmark of their inner loop: `peak` / `frac` are that; the nominal figure stays beside it
+        m, detail = None, {}
+        if gather_ceiling and self.rank == 0 and proof["achieved"]:
+            if eng.last_pool_variant == "table-reg":
+                m = measured_multiply_ceiling()
+                detail = {"T_draws_per_s_by_variant": m["rows"]} if m else {}
+            elif eng.last_pool_variant == "ragged-table":
+                m = measured_gather_ceiling(bag)
+                detail = {"T_gathers_per_s_by_bag_size": m["points"]} if m else {}
+        if m is not None:
+            proof["nominal_peak"], proof["nominal_frac"] = proof["peak"], proof["frac"]
+            proof["peak"], proof["frac"] = m["rate"] / 1e12, proof["achieved"] * 1e12 / m["rate"]
+            proof["peak_source"] = m["source"]
+            proof["measured_ceiling"] = dict({"peak": m["rate"] / 1e12, "unit": "T draws/s", "frac": proof["frac"], "source": m["source"]}, **detail)
+        else:
+            proof["peak_source"] = "nominal (the microbenchmark binary under tools/ is not built: __graft_entry__.build())"
         value = total_sites * steps / r["dt"]
         out = {
             "value": value,
