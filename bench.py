@@ -749,7 +749,7 @@ def run(args, line, rank, world, local_rank, S, bag, T):
             rs = WORKLOADS["ragged"]
             rb = Bench(args, "ragged", rs["sites"], rs["bag"], 1000, 0, 1, local_rank, dev, backend)
             rr = rb.run(10, 3, args.min_seconds)
-            rg = rb.report(rr, 10, traffic=False)
+            rg = rb.report(rr, 10)                        # incl. its own live PMC passes for roofline.traffic
             rg["config"] = rb.config()
             rg["steps"], rg["warmup"] = 10, 3
             line["ragged"] = rg
