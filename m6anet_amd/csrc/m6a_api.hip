@@ -1128,10 +1128,13 @@ int launch_pool(m6a_ctx *c, const float *rp, const int64_t *off, int64_t S, int 
 }
 
 // ---- host-pointer path: pinned staging ring, H2D of chunk k+1 under the encoder of chunk k ---------------------
+void release_staging(m6a_ctx *c);
+
 int ensure_staging(m6a_ctx *c)
 {
     Staging &g = c->stg;
     if (g.ready) return M6A_OK;
+    release_staging(c);                                       // whatever a failed earlier attempt left behind
     const char *env = getenv("M6A_STAGE_MB");
     const size_t slot_mb = env && atoi(env) > 0 ? (size_t)atoi(env) : 24;
     g.chunk_reads = (int64_t)(slot_mb << 20) / (M6A_N_FEATURES * 4);
@@ -1460,6 +1463,10 @@ int job_setup_ring(m6a_ctx *c)
     int rc = ensure_staging(c);
     if (rc) return rc;
     if (j.n_sub) return M6A_OK;
+    // (a previous attempt may have failed half way: start from nothing)
+    for (auto e : j.ev_h2d) (void)hipEventDestroy(e);
+    for (auto e : j.ev_enc) (void)hipEventDestroy(e);
+    j.ev_h2d.clear(); j.ev_enc.clear(); j.pin.clear();
     Staging &g = c->stg;
     const size_t slot_bytes = (size_t)g.chunk_reads * M6A_N_FEATURES * 4;
     const int per_slot = slot_bytes >= ((size_t)20 << 20) ? 5 : slot_bytes >= ((size_t)8 << 20) ? 2 : 1;
