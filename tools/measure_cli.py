@@ -51,12 +51,29 @@ def main():
         t0 = time.perf_counter()
         cli(["inference", "--input_dir", store, "--out_dir", out, "--num_iterations", "1000", "--n_processes", "0"])
         wall_store = time.perf_counter() - t0
+        # the N-GPU split of the same job, as far as one GPU can show it: two ranks sharing the GPU, results through the
+        # exchange directory (M6A_EXCHANGE=host) -- what the launcher, the rank start-up and the gather to rank 0 cost
+        import subprocess
+        t0 = time.perf_counter()
+        subprocess.run([sys.executable, "-m", "m6anet_amd", "inference", "--input_dir", store, "--out_dir", os.path.join(d, "out2"),
+                        "--num_iterations", "1000", "--n_processes", "0", "--gpus", "2"], check=True,
+                       env=dict(os.environ, M6A_EXCHANGE="host"), cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        wall_gpus2 = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        subprocess.run([sys.executable, "-m", "m6anet_amd", "inference", "--input_dir", store, "--out_dir", os.path.join(d, "out1"),
+                        "--num_iterations", "1000", "--n_processes", "0"], check=True,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        wall_gpus1_process = time.perf_counter() - t0
+        same = all(open(os.path.join(d, "out1", f), "rb").read() == open(os.path.join(d, "out2", f), "rb").read()
+                   for f in ("data.site_proba.csv", "data.indiv_proba.csv"))
         sites, reads = batch.n_sites, int(batch.off[-1])
         print(json.dumps({"copies": n, "json_MB": size / 1e6, "sites": sites, "reads": reads,
                           "cli_wall_s": wall, "sites_per_s_end_to_end": sites / wall,
                           "load_s": t_load, "gpu_infer_host_pointers_s": t_gpu, "gpu_infer_host_pointers_warm_s": t_gpu_warm, "csv_s": t_csv,
                           "store_pack_s": t_pack, "store_bytes": os.path.getsize(store), "store_open_s": t_open,
                           "gpu_infer_from_mapped_store_s": t_gpu_store, "cli_wall_from_store_s": wall_store,
+                          "cli_process_from_store_s": wall_gpus1_process, "cli_process_from_store_gpus2_host_exchange_s": wall_gpus2,
+                          "gpus2_csv_bytes_equal_gpus1": same,
                           "pool_kernel": eng.last_pool_variant,
                           "site_csv_bytes": os.path.getsize(os.path.join(out, "data.site_proba.csv")),
                           "indiv_csv_bytes": os.path.getsize(os.path.join(out, "data.indiv_proba.csv")),
