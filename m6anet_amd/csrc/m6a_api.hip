@@ -1700,6 +1700,13 @@ void warm_default(m6a_ctx *c)
     if (!rc) {
         const char *e = getenv("M6A_WARM_SLOTS");
         c->rt_presize = e && atoi(e) > 0 ? std::min(atoi(e), M6A_RTAB_MAX_N + 1) : 512;
+        // speculative memory stays a small share of what is free (a shared or nearly full GPU gets the 32-slot arena a first
+        // call would make anyway); an explicit M6A_WARM_SLOTS is taken at its word
+        size_t free_b = 0, total_b = 0;
+        if (!e && hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            const size_t slot_bytes = (size_t)(c->raw_len) * 2 + (size_t)(c->raw_len / 64 + 1) * 4;
+            if ((size_t)c->rt_presize * slot_bytes > free_b / 20) c->rt_presize = 32;
+        }
         rc = ensure_table_reg(c, seed, n, T, K, (int)gmax);
         if (!rc) {
             // ... and the index table of every bag size the arena was sized for: one pass over the stream for all of them
