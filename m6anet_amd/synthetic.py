@@ -20,9 +20,13 @@ def bag_sizes(n_sites, bag=20, seed=20250328):
     return np.full(n_sites, int(bag), np.int64)
 
 
-def make_sites(n_sites, bag=20, seed=20250328, chunk_reads=1 << 22, n_reads=None):
+def make_sites(n_sites, bag=20, seed=20250328, chunk_reads=1 << 22, n_reads=None, prefix_sites=None):
     """Returns dict(X f32 [R,9], site_kmers u8 [S,3], off i64 [S+1]).  `n_reads` (int64 [n_sites])
-    fixes the bag sizes explicitly -- a rank's slice of a job-wide bag_sizes() array."""
+    fixes the bag sizes explicitly -- a rank's slice of a job-wide bag_sizes() array.
+    `prefix_sites` = P returns sites [0, P) of the n_sites-job, bit for bit, without generating the
+    features of the rest (the feature stream is drawn last and in read order, so a prefix of the job is a
+    prefix of the stream): how tests/golden/reference_at_scale.npz addresses "the first P sites of
+    BASELINE.json configs[2] / configs[4]" cheaply."""
     g = np.random.Generator(np.random.PCG64(seed))
     site_kmers = _IDS_288[g.integers(0, len(ALL_7MERS), size=n_sites)]
     if n_reads is not None:
@@ -34,6 +38,10 @@ def make_sites(n_sites, bag=20, seed=20250328, chunk_reads=1 << 22, n_reads=None
         n_reads = np.full(n_sites, int(bag), np.int64)
     off = np.zeros(n_sites + 1, np.int64)
     np.cumsum(n_reads, out=off[1:])
+    if prefix_sites is not None:
+        P = int(prefix_sites)
+        assert 0 <= P <= n_sites
+        off, site_kmers = off[:P + 1].copy(), site_kmers[:P]
     R = int(off[-1])
     X = np.empty((R, 9), np.float32)
     for a in range(0, R, chunk_reads):

@@ -1,0 +1,127 @@
+"""The HIP encoder (both kernels), the end-to-end site probabilities and the oracle, each compared DIRECTLY with
+what the reference computed on this repo's synthetic jobs at scale: tests/golden/reference_at_scale.npz, captured by
+tests/golden/make_golden.py --only-scale (the reference's encoder per 16-site DataLoader batch,
+m6anet/utils/inference_utils.py:33-37; its sampling at n_processes = 1, :53,74-104):
+
+  * read probabilities of sites [0, 50 000) of BASELINE.json configs[2] (1 000 000 reads) and sites [0, 4 000) of
+    configs[4] (1 106 308 reads), all four checkpoints -- bar: rtol 1e-5, atol 1e-8, the reference's own
+    (m6anet/tests/test_inference.py:32), for EVERY read, no statistical allowance;
+  * site probabilities (T = 1000) and mod_ratio of sites [0, 10 000) of each -- bar: 1e-5 absolute on
+    probability_modified (north_star); mod_ratio may differ only where a read probability sits within rtol 1e-5 of
+    the threshold.
+
+Inputs are regenerated (synthetic.make_sites(..., prefix_sites=P) = the prefix of the full job, bit for bit) and
+checked against the checksum stored with the capture.  No oracle in the GPU tests: this is HIP <-> reference."""
+import numpy as np
+import pytest
+
+from m6anet_amd import synthetic
+from m6anet_amd.constants import DEFAULT_READ_THRESHOLD
+
+THR = np.float32(DEFAULT_READ_THRESHOLD)
+SHAPES = {"uniform": (1_000_000, 20, 50_000, 10_000), "ragged": (1_000_000, (50, 500), 4_000, 10_000)}
+MODELS = ("hct116", "arabidopsis", "hek293t_glori", "hek293t_m6ace")
+
+
+def bar_use(got, want):
+    """|got - want| as a fraction of np.allclose's allowance atol + rtol*|want| (1 = at the bar)."""
+    want = want.astype(np.float64)
+    return np.abs(got.astype(np.float64) - want) / (1e-8 + 1e-5 * np.abs(want))
+
+
+_jobs = {}
+
+
+def job(golden, tag):
+    if tag not in _jobs:
+        n, bag, keep_reads, keep_sites = SHAPES[tag]
+        d = synthetic.make_sites(n, bag, seed=20250328, prefix_sites=max(keep_reads, keep_sites))
+        G = golden("reference_at_scale.npz")
+        chk = G[f"{tag}_check"]
+        assert np.array_equal(d["off"], G[f"{tag}_off"])
+        assert float(d["X"].astype(np.float64).sum()) == chk[0] and float(d["site_kmers"].astype(np.int64).sum()) == chk[1], \
+            "the synthetic generator no longer reproduces the inputs the reference was run on"
+        _jobs[tag] = (d, G, keep_reads, keep_sites)
+    return _jobs[tag]
+
+
+# ------------------------------------------------------------------ CPU: oracle <-> reference ---------------
+@pytest.mark.parametrize("tag", list(SHAPES))
+def test_oracle_read_probabilities_vs_reference_at_scale(golden, weights, tag):
+    from oracle import m6a_oracle as orc
+    d, G, keep_reads, _ = job(golden, tag)
+    R = int(d["off"][keep_reads])
+    for name in MODELS:
+        got = orc.encode_reads(weights[name], d["X"][:R], d["site_kmers"][:keep_reads], d["off"][:keep_reads + 1], n_threads=4)
+        u = bar_use(got, G[f"{tag}_{name}_readprob"])
+        assert u.max() <= 1.0, (tag, name, float(u.max()), int((u > 1).sum()))
+
+
+@pytest.mark.parametrize("tag", list(SHAPES))
+def test_oracle_site_probabilities_vs_reference_at_scale(golden, weights, tag):
+    """From the REFERENCE's read probabilities the oracle's sampling must be the reference's, bit for bit (2 000 sites:
+    the oracle is the slow side here); from its OWN read probabilities within 1e-5 (north_star's bar)."""
+    from oracle import m6a_oracle as orc
+    d, G, keep_reads, _ = job(golden, tag)
+    S = min(2_000, keep_reads)
+    off = d["off"][:S + 1]
+    for name in ("hct116", "hek293t_glori"):
+        p_ref = G[f"{tag}_{name}_readprob"][:int(off[-1])]
+        site, mod = orc.site_pool(p_ref, off, 1000, THR)
+        assert np.array_equal(site, G[f"{tag}_{name}_site_T1000"][:S]), (tag, name)
+        assert np.array_equal(mod, G[f"{tag}_{name}_mod"][:S]), (tag, name)
+        p_own = orc.encode_reads(weights[name], d["X"][:int(off[-1])], d["site_kmers"][:S], off, n_threads=4)
+        site2, _ = orc.site_pool(p_own, off, 1000, THR)
+        assert np.abs(site2.astype(np.float64) - G[f"{tag}_{name}_site_T1000"][:S]).max() <= 1e-5, (tag, name)
+
+
+# ------------------------------------------------------------------ GPU: HIP <-> reference -----------------
+@pytest.fixture(scope="module")
+def engines(weights):
+    from m6anet_amd.engine import M6ANetEngine
+    return {name: M6ANetEngine(weights=w) for name, w in weights.items()}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", [(1, "general16"), (2, "csite12")])
+@pytest.mark.parametrize("tag", list(SHAPES))
+def test_hip_read_probabilities_vs_reference_at_scale(golden, engines, tag, variant):
+    """Every one of the 2.1 M reads x 4 checkpoints x 2 kernels inside rtol 1e-5 / atol 1e-8 of the reference's value."""
+    d, G, keep_reads, _ = job(golden, tag)
+    R = int(d["off"][keep_reads])
+    mode, label = variant
+    for name in MODELS:
+        e = engines[name]
+        e.set_encoder_variant(mode)
+        try:
+            got = e.get_read_probability(d["X"][:R], d["site_kmers"][:keep_reads], d["off"][:keep_reads + 1])
+            assert e.last_encoder_variant == label
+        finally:
+            e.set_encoder_variant(0)
+        u = bar_use(got, G[f"{tag}_{name}_readprob"])
+        assert u.max() <= 1.0, (tag, name, label, float(u.max()), int((u > 1).sum()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", list(SHAPES))
+def test_hip_site_probabilities_vs_reference_at_scale(golden, engines, tag):
+    """m6a_infer end to end (HIP encoder -> HIP sampling) against the reference's site probabilities at T = 1000:
+    <= 1e-5 on probability_modified; and the sampling alone, fed the REFERENCE's read probabilities, bit for bit."""
+    d, G, keep_reads, keep_sites = job(golden, tag)
+    off = d["off"][:keep_sites + 1]
+    R = int(off[-1])
+    for name in MODELS:
+        e = engines[name]
+        rp, site, mod = e.infer(d["X"][:R], d["site_kmers"][:keep_sites], off, 1000)
+        want = G[f"{tag}_{name}_site_T1000"]
+        assert np.abs(site.astype(np.float64) - want).max() <= 1e-5, (tag, name, float(np.abs(site.astype(np.float64) - want).max()))
+        # mod_ratio = mean(p >= thr): differs from the reference's only through reads whose probability is within the
+        # read-probability bar of the threshold (one read of an n-read bag moves it by 1/n)
+        dm = np.abs(mod - G[f"{tag}_{name}_mod"]) * np.diff(off)
+        near = np.add.reduceat((np.abs(rp.astype(np.float64) - float(THR)) <= 1e-8 + 1e-5 * float(THR)).astype(np.int64), off[:-1])
+        assert np.all(dm <= near + 1e-9), (tag, name)
+        Sk = min(keep_reads, keep_sites)
+        p_ref = G[f"{tag}_{name}_readprob"][:int(d["off"][Sk])]
+        site2, mod2 = e.calculate_site_proba(p_ref, d["off"][:Sk + 1], 1000)
+        assert np.array_equal(site2, want[:Sk]), (tag, name)
+        assert np.array_equal(mod2, G[f"{tag}_{name}_mod"][:Sk]), (tag, name)
