@@ -395,6 +395,13 @@ class Bench:
         t0 = time.perf_counter()
         for _ in range(n):
             self.step()
+        if self.dist is not None:
+            # this rank's OWN time: its compute and its exchanges done, before it waits for anybody at the barrier
+            # (rank 0's includes the arrival of every shard: it is the receiving end of the gather)
+            if self.gather is not None:
+                self.gather.drain()
+            self.torch.cuda.synchronize(self.dev)
+            self.own_dt = time.perf_counter() - t0
         self.fence()
         return time.perf_counter() - t0
 
@@ -453,7 +460,15 @@ class Bench:
         # costs the stream ~10 us per step, and the headline pays only for the pair it needs)
         self.fence()
         eng.profile("encoder")
+        timing_gather = hasattr(self.gather, "timed_pairs")
+        if timing_gather:
+            self.gather.timing = True
         dt = self.timed(steps)
+        own_dt = getattr(self, "own_dt", dt)
+        gather_ms = None
+        if timing_gather:
+            gather_ms, _ = self.gather.exchange_ms()
+            self.gather.timing = False
         enc_ms, enc_n = eng.profile_read(0)
         eng.profile("pooling")
         self.timed(min(steps, 10))
@@ -481,7 +496,48 @@ class Bench:
             sustained = {"seconds": t_all, "steps": n_done, "ms_per_step": t_all / n_done * 1e3, "rocm_smi_under_load": smi}
         dt, first_call_ms = self.max_over_ranks(dt, first_call_ms)
         return {"dt": dt, "first_call_ms": first_call_ms, "second_call_ms": second_call_ms, "enc_ms": enc_ms, "enc_n": enc_n, "pool_ms": pool_ms, "pool_n": pool_n,
-                "sustained": sustained}
+                "sustained": sustained, "own_ms_per_step": own_dt / steps * 1e3, "gather_ms_per_step": gather_ms}
+
+    def certify(self, r, local_ms):
+        """What makes an N-rank line checkable from the line alone (collective; returns the keys on rank 0): the communicator's
+        own rank count / device / RCCL version on every rank, how rank 0's device reaches the others, every rank's own step
+        time (in the timed region, before the barrier), its compute-only step time (before the process group existed), and the
+        exchange's own duration from HIP events on the stream that carries it."""
+        info = None
+        if hasattr(self.gather, "timed_pairs"):
+            try:
+                info = self.eng.comm_info()
+            except Exception as e:                          # noqa: BLE001
+                info = {"error": str(e)[:200]}
+        mine = {"rank": self.rank, "device": self.dev.index, "sites": self.Sr, "reads": self.R, "own_ms_per_step": r["own_ms_per_step"],
+                "local_ms_per_step": local_ms, "gather_ms_per_step": r["gather_ms_per_step"], "comm": info}
+        rows = [None] * self.world
+        self.dist.all_gather_object(rows, mine)
+        if self.rank != 0:
+            return None
+        links = None
+        try:
+            from m6anet_amd.engine import device_link
+            links = [dict(device_link(rows[0]["device"], x["device"]), to_rank=x["rank"]) for x in rows[1:]]
+        except Exception as e:                              # noqa: BLE001 -- e.g. each rank sees only its own device
+            links = "unavailable: %s" % str(e)[:120]
+        comms = [x["comm"] for x in rows]
+        native = all(isinstance(c, dict) and "ranks_seen" in c for c in comms)
+        return {
+            "rccl": {"ranks_seen": [c["ranks_seen"] for c in comms] if native else None,
+                     "ranks_seen_all_equal_world": bool(native and all(c["ranks_seen"] == self.world for c in comms)),
+                     "version": comms[0].get("rccl_version") if native else None,
+                     "comm_devices": [c["device"] for c in comms] if native else None,
+                     "communicator": "m6a_comm_init (the library's own)" if native else "torch.distributed's (%s)" % self.backend,
+                     "links_from_rank0": links},
+            "per_rank": {"sites": [x["sites"] for x in rows], "reads": [x["reads"] for x in rows],
+                         "ms_per_step": [x["own_ms_per_step"] for x in rows],
+                         "local_ms_per_step": [x["local_ms_per_step"] for x in rows],
+                         "gather_ms_per_step": [x["gather_ms_per_step"] for x in rows],
+                         "note": "ms_per_step: the rank's own wall time per step inside the timed region, exchange included, before the "
+                                 "closing barrier; local_ms_per_step: its compute-only step before the process group was formed; "
+                                 "gather_ms_per_step: HIP events around m6a_gather on the side stream that carries it (it overlaps the next step)"},
+        }
 
     def verify(self):
         """rank 0 recomputes the WHOLE job unsharded on its GPU and compares the gathered arrays bit for bit"""
@@ -739,15 +795,22 @@ def run(args, line, rank, world, local_rank, S, bag, T):
     if os.environ.get("M6A_BENCH_TEST_KILL_RANK") == str(rank):   # test hook: this rank dies before the timed region
         os._exit(9)
     r = b.run(args.steps, args.warmup, args.min_seconds)
+    cert = None
     if multi:
         # every rank made its cold call alone above; what run() timed first was only the first call WITH the exchange
         r["first_call_ms"], = b.max_over_ranks(cold)
+        cert = b.certify(r, local_ms)
     verified = b.verify() if args.verify else None
     if rank == 0:
         rep = b.report(r, args.steps)
         line.update({"value": rep.pop("value"), "ms_per_step": rep.pop("ms_per_step"), "config": b.config(),
                      "first_call_ms": rep.pop("first_call_ms"), "second_call_ms": rep.pop("second_call_ms"), "value_one_shot": rep.pop("value_one_shot"), "verify": verified})
         line.update(rep)
+        if cert:
+            line.update(cert)
+            # the driver computes scaling efficiency itself from the per-N values; this is the same quantity from ONE line:
+            # whole-job rate over N x what rank 0 does alone on its shard (weak scaling: 1.0 = the exchange and the barrier are free)
+            line["efficiency"] = line["value"] / (world * line["rank0_local"]["sites_per_s"])
         default_run = (world == 1 and args.workload == "uniform" and S == WORKLOADS["uniform"]["sites"] and T == 1000 and
                        bag == WORKLOADS["uniform"]["bag"])
         if default_run and not args.no_ragged_extra:

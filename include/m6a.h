@@ -211,6 +211,16 @@ int m6a_gather(m6a_ctx *ctx, const float *site_prob, const double *mod_ratio, co
                int dst, float *site_all, double *mod_all);
 int m6a_gather_reads(m6a_ctx *ctx, const float *read_prob, const int64_t *shard_read_off, int dst, float *read_all);
 int m6a_comm_destroy(m6a_ctx *ctx);
+/* What the communicator ITSELF reports, for a launcher or a benchmark line that has to certify an N-rank run instead of
+ * trusting its own arguments: m6a_comm_count = ncclCommCount (the ranks RCCL formed the communicator with);
+ * m6a_comm_info = ncclCommUserRank, ncclCommCuDevice (the HIP device the communicator is bound to) and ncclGetVersion
+ * (e.g. 22707); any of the three pointers may be NULL.  m6a_device_link = how two visible HIP devices are connected:
+ * link_type as hipExtGetLinkTypeAndHopCount reports it (hsa_amd_link_info_type_t: 2 = PCIe, 4 = xGMI), hop count,
+ * and whether dev_a can map dev_b's memory (hipDeviceCanAccessPeer) -- what decides whether the gather's direct
+ * send/recv writes travel over xGMI.  No reference counterpart (it has no multi-device path). */
+int m6a_comm_count(m6a_ctx *ctx, int *ranks_seen);
+int m6a_comm_info(m6a_ctx *ctx, int *rank, int *device, int *rccl_version);
+int m6a_device_link(int dev_a, int dev_b, int *link_type, int *hops, int *peer_access);
 /* HIP devices visible to this process (0 if none / no runtime): what a launcher sizes `world` against. */
 int m6a_device_count(void);
 

@@ -1333,6 +1333,10 @@ struct Rccl {
     int (*Send)(const void *, size_t, int, int, void *, hipStream_t) = nullptr;
     int (*Recv)(void *, size_t, int, int, void *, hipStream_t) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
+    int (*CommCount)(void *, int *) = nullptr;          // the four below are optional: a copy without them still gathers
+    int (*CommUserRank)(void *, int *) = nullptr;
+    int (*CommCuDevice)(void *, int *) = nullptr;
+    int (*GetVersion)(int *) = nullptr;
     std::string err;
 };
 
@@ -1364,6 +1368,10 @@ Rccl *rccl()
         r.Send = (int (*)(const void *, size_t, int, int, void *, hipStream_t))sym("ncclSend");
         r.Recv = (int (*)(void *, size_t, int, int, void *, hipStream_t))sym("ncclRecv");
         r.GetErrorString = (const char *(*)(int))sym("ncclGetErrorString");
+        r.CommCount = (int (*)(void *, int *))dlsym(r.h, "ncclCommCount");
+        r.CommUserRank = (int (*)(void *, int *))dlsym(r.h, "ncclCommUserRank");
+        r.CommCuDevice = (int (*)(void *, int *))dlsym(r.h, "ncclCommCuDevice");
+        r.GetVersion = (int (*)(int *))dlsym(r.h, "ncclGetVersion");
     });
     return &r;
 }
@@ -2615,6 +2623,51 @@ int m6a_comm_destroy(m6a_ctx *c)
     void *comm = c->comm;
     c->comm = nullptr; c->comm_world = 0;                  // whatever CommDestroy says: m6a_destroy must not destroy it again
     RCCLCHK(c, R, R->CommDestroy(comm));
+    return M6A_OK;
+}
+
+// What the communicator itself says (not what the launcher asked for): how a bench line or a launcher certifies that RCCL
+// really formed an N-rank communicator on the devices it meant.
+int m6a_comm_count(m6a_ctx *c, int *ranks_seen)
+{
+    settle(c);
+    if (!c) return M6A_EINVAL;
+    if (!ranks_seen) return fail(c, M6A_EINVAL, "null pointer argument");
+    if (!c->comm) return fail(c, M6A_EINVAL, "m6a_comm_init has not run on this context");
+    Rccl *R = rccl();
+    if (!R->CommCount) return fail(c, M6A_EUNSUPPORTED, "librccl lacks ncclCommCount");
+    RCCLCHK(c, R, R->CommCount(c->comm, ranks_seen));
+    return M6A_OK;
+}
+
+int m6a_comm_info(m6a_ctx *c, int *rank, int *device, int *rccl_version)
+{
+    settle(c);
+    if (!c) return M6A_EINVAL;
+    if (!c->comm) return fail(c, M6A_EINVAL, "m6a_comm_init has not run on this context");
+    Rccl *R = rccl();
+    if (rank) { *rank = -1; if (R->CommUserRank) RCCLCHK(c, R, R->CommUserRank(c->comm, rank)); }
+    if (device) { *device = -1; if (R->CommCuDevice) RCCLCHK(c, R, R->CommCuDevice(c->comm, device)); }
+    if (rccl_version) { *rccl_version = 0; if (R->GetVersion) RCCLCHK(c, R, R->GetVersion(rccl_version)); }
+    return M6A_OK;
+}
+
+int m6a_device_link(int dev_a, int dev_b, int *link_type, int *hops, int *peer_access)
+{
+    if (link_type) *link_type = -1;
+    if (hops) *hops = -1;
+    if (peer_access) *peer_access = 0;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return M6A_ENODEV; }
+    if (dev_a < 0 || dev_b < 0 || dev_a >= n || dev_b >= n) return M6A_EINVAL;
+    if (dev_a == dev_b) { if (hops) *hops = 0; if (peer_access) *peer_access = 1; return M6A_OK; }
+    uint32_t lt = 0, hc = 0;
+    if (hipExtGetLinkTypeAndHopCount(dev_a, dev_b, &lt, &hc) != hipSuccess) { (void)hipGetLastError(); return M6A_EHIP; }
+    if (link_type) *link_type = (int)lt;
+    if (hops) *hops = (int)hc;
+    int pa = 0;
+    if (hipDeviceCanAccessPeer(&pa, dev_a, dev_b) != hipSuccess) { (void)hipGetLastError(); pa = 0; }
+    if (peer_access) *peer_access = pa;
     return M6A_OK;
 }
 

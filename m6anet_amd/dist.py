@@ -148,6 +148,15 @@ class NativeGather:
         self.sent = [torch.cuda.Event() for _ in range(2)]
         self.in_flight = [False, False]
         self.slot = 0
+        self.timing = False          # bench.py: HIP events around every exchange on the side stream
+        self.timed_pairs = []
+
+    def exchange_ms(self):
+        """(average ms per exchange, exchanges) over the exchanges issued while `timing` was on; drains first."""
+        self.drain()
+        ms = [a.elapsed_time(b) for a, b in self.timed_pairs]
+        self.timed_pairs = []
+        return (sum(ms) / len(ms) if ms else None), len(ms)
 
     def _all_ok(self, ok):
         dev = self.device if self.dist.get_backend() == "nccl" else "cpu"
@@ -189,10 +198,16 @@ class NativeGather:
         self.copied[k].record(cur)
         self.side.wait_event(self.copied[k])
         self.engine.set_stream(self.side.cuda_stream)         # m6a_gather is enqueued on the context's stream
+        if self.timing:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(self.side)
         try:
             self.engine.gather(self.send[k][0], self.send[k][1], self.cuts, self.dst, out=self.out[k])
         finally:
             self.engine.use_torch_stream()
+        if self.timing:
+            e1.record(self.side)
+            self.timed_pairs.append((e0, e1))
         self.sent[k].record(self.side)
         self.in_flight[k] = True
         self.slot ^= 1

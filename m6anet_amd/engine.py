@@ -178,6 +178,13 @@ class M6ANetEngine:
         self._chk(self._L.m6a_comm_init(self._h, buf, int(rank), int(world_size)))
         self._comm = (int(rank), int(world_size))
 
+    def comm_info(self):
+        """What the communicator itself reports: {'ranks_seen': ncclCommCount, 'rank', 'device', 'rccl_version'}."""
+        n, r, d, v = C.c_int(0), C.c_int(-1), C.c_int(-1), C.c_int(0)
+        self._chk(self._L.m6a_comm_count(self._h, C.byref(n)))
+        self._chk(self._L.m6a_comm_info(self._h, C.byref(r), C.byref(d), C.byref(v)))
+        return {"ranks_seen": n.value, "rank": r.value, "device": d.value, "rccl_version": v.value}
+
     def comm_destroy(self):
         self._chk(self._L.m6a_comm_destroy(self._h))
 
@@ -387,6 +394,19 @@ def comm_unique_id():
     if rc != 0:
         raise _lib.M6AError(rc, L.m6a_last_error(None).decode())
     return bytes(buf.raw)
+
+
+LINK_TYPES = {0: "hypertransport", 1: "qpi", 2: "pcie", 3: "infiniband", 4: "xgmi"}
+
+
+def device_link(dev_a, dev_b):
+    """{'link': 'xgmi' | 'pcie' | ..., 'hops', 'peer_access'} between two visible HIP devices (m6a_device_link)."""
+    L = _lib.load()
+    lt, hc, pa = C.c_int(-1), C.c_int(-1), C.c_int(0)
+    rc = L.m6a_device_link(int(dev_a), int(dev_b), C.byref(lt), C.byref(hc), C.byref(pa))
+    if rc != 0:
+        raise _lib.M6AError(rc, "m6a_device_link(%d, %d)" % (dev_a, dev_b))
+    return {"link": "self" if dev_a == dev_b else LINK_TYPES.get(lt.value, "type %d" % lt.value), "hops": hc.value, "peer_access": bool(pa.value)}
 
 
 def device_count():

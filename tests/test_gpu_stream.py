@@ -400,6 +400,25 @@ def test_bench_native_exchange_is_the_default_and_checks_itself():
     d = lines[0]
     assert "m6a_gather" in d["config"]["sharding"] and d["verify"] is True and d["value"] > 0
     assert d["value_one_shot"] > 0 and d["first_call_ms"] > 0 and "rank0_local" in d
+    # the line certifies the run: what the communicator itself saw (ncclCommCount, its device, RCCL's version), each
+    # rank's own step time, the exchange's duration from events on its stream, efficiency against rank 0 alone
+    r = d["rccl"]
+    assert r["ranks_seen"] == [1] and r["ranks_seen_all_equal_world"] is True and r["version"] > 20000 and r["comm_devices"] == [0]
+    assert r["communicator"].startswith("m6a_comm_init") and r["links_from_rank0"] == []
+    pr = d["per_rank"]
+    assert len(pr["ms_per_step"]) == 1 and pr["ms_per_step"][0] > 0 and pr["local_ms_per_step"][0] > 0 and pr["sites"] == [3001]
+    assert pr["gather_ms_per_step"][0] is not None and 0 < pr["gather_ms_per_step"][0] < 50
+    assert 0.05 < d["efficiency"] <= 1.5
+
+
+def test_device_link_and_comm_info_errors(engines):
+    from m6anet_amd import _lib
+    from m6anet_amd.engine import device_link
+    assert device_link(0, 0) == {"link": "self", "hops": 0, "peer_access": True}
+    with pytest.raises(_lib.M6AError):
+        device_link(0, 99)
+    with pytest.raises(_lib.M6AError):
+        engines["hct116"].comm_info()          # no communicator on this context
 
 
 def test_bench_falls_back_to_torch_when_the_library_cannot_bind_rccl():
@@ -408,6 +427,8 @@ def test_bench_falls_back_to_torch_when_the_library_cannot_bind_rccl():
     d = lines[0]
     assert "torch.distributed" in d["config"]["sharding"] and "unavailable" in d["config"]["sharding"]
     assert d["verify"] is True
+    assert d["rccl"]["ranks_seen"] is None and d["rccl"]["communicator"].startswith("torch.distributed")
+    assert d["per_rank"]["gather_ms_per_step"] == [None] and d["per_rank"]["ms_per_step"][0] > 0
 
 
 def test_bench_prints_its_line_when_a_rank_dies():
@@ -547,3 +568,6 @@ def test_bench_sustained_leg_with_two_ranks():
     assert out.returncode == 0 and len(lines) == 1, out.stderr[-2000:]
     d = lines[0]
     assert d["value_sustained"] > 0 and d["sustained"]["seconds"] >= 1.0 and d["sustained"]["steps"] % 3 == 0
+    pr = d["per_rank"]
+    assert len(pr["ms_per_step"]) == 2 and all(x > 0 for x in pr["ms_per_step"] + pr["local_ms_per_step"]) and sum(pr["sites"]) == 2 * 3001
+    assert d["rccl"]["ranks_seen"] is None and "gloo" in d["rccl"]["communicator"] and d["efficiency"] > 0
