@@ -142,6 +142,63 @@ def _pool_site_worker(job):
     return float(site[0])
 
 
+def host_cpu_facts():
+    """What this process may actually use of the host: logical CPUs, the scheduler affinity mask, the cgroup CPU quota
+    (v2 cpu.max, v1 cfs_quota_us / cfs_period_us), physical cores, and how busy the host already is."""
+    logical = os.cpu_count() or 1
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        affinity = logical
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    model, phys, cur = "unknown", set(), [None, None]
+    try:
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "model name" and model == "unknown":
+                model = v
+            elif k == "physical id":
+                cur[0] = v
+            elif k == "core id":
+                cur[1] = v
+                phys.add(tuple(cur))
+    except OSError:
+        pass
+    try:
+        load = [float(x) for x in open("/proc/loadavg").read().split()[:3]]
+    except (OSError, ValueError):
+        load = None
+    eff = affinity if quota is None else max(1, min(affinity, int(quota + 0.5)))
+    return {"cpu_model": model, "logical_cpus": logical, "physical_cores": len(phys) or None, "affinity_cpus": affinity,
+            "cgroup_cpu_quota": quota, "effective_cores": eff, "loadavg_1_5_15_before": load}
+
+
+def cpu_calibration():
+    """tools/calibrate_cpu_baseline.py (build container, imports the reference): oracle vs the reference's own NumPy / torch
+    code on the same inputs, one thread.  BASELINE.md section 3: the port stands for the reference within +-10 % or this factor."""
+    path = os.path.join(REPO, "profiles", "r04_cpu_calibration.json")
+    try:
+        with open(path) as f:
+            c = json.load(f)
+        return {"file": "profiles/r04_cpu_calibration.json", "oracle_over_reference": c["oracle_over_reference"],
+                "measured_on": c.get("host"), "note": c.get("note")}
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def cpu_baseline_main(workload, T, budget_s):
     """The oracle (a port of the reference's algorithm, oracle/m6a_oracle.c) on this host's cores, on a
     bounded sample of the bench workload.  Three figures, as BASELINE.md section 3 asks:
@@ -150,7 +207,10 @@ def cpu_baseline_main(workload, T, budget_s):
                         (inference_utils.py:33-54,102-104), at n = 1, 25 (the reference's default) and all cores;
       best_case         the same arithmetic with one persistent set of threads over all sites (what the
                         reference could do at best) -- `value`, the figure most favourable to the CPU;
-      single_thread     one thread in-process."""
+      single_thread     one thread in-process.
+    `cores` = the threads the best case ran on = the CPUs this process may really use (affinity mask and cgroup
+    quota, not os.cpu_count()); `scaling` = the same job at 1, 2, 4, ... threads with the efficiency of each point, so a
+    host that is shared or throttled shows up in the line instead of in the ratio."""
     import multiprocessing as mp
     from m6anet_amd import synthetic
     from m6anet_amd.constants import DEFAULT_READ_THRESHOLD
@@ -158,7 +218,8 @@ def cpu_baseline_main(workload, T, budget_s):
     from oracle import m6a_oracle as orc
     orc.build()
     spec = WORKLOADS[workload]
-    cores = os.cpu_count() or 1
+    facts = host_cpu_facts()
+    cores = facts["effective_cores"]
     thr = np.float32(DEFAULT_READ_THRESHOLD)
     weights = load_weights(spec["model"])
     n_sample = 600_000 if workload == "uniform" else 60_000
@@ -173,13 +234,25 @@ def cpu_baseline_main(workload, T, budget_s):
         return time.perf_counter() - t0
 
     # (iii) one thread in-process
-    n1 = 256 if workload == "uniform" else 64
+    n1 = 512 if workload == "uniform" else 64
+    run(32, 1)
     t1 = run(n1, 1)
     single = n1 / t1
-    # (ii) persistent threads over all sites
-    probe = min(S, 64 * cores)
-    t = run(probe, cores)
-    n = int(min(S, max(probe, probe * (budget_s * 0.5) / max(t, 1e-6))))
+    # the scaling curve: every thread count gets the same sites PER THREAD (whole flush groups), ~0.5 s each
+    per_thread = max(32, int(single * 0.5) // 32 * 32)
+    curve, th = [], 1
+    counts = []
+    while th < cores:
+        counts.append(th)
+        th *= 2
+    counts.append(cores)
+    for th in counts:
+        n = min(S - S % 32, per_thread * th)
+        t = run(n, th)
+        curve.append({"threads": th, "sites": n, "sites_per_s": n / t, "efficiency": n / t / (th * single)})
+    # (ii) persistent threads over all sites, the bounded sample sized from the curve's last point
+    rate = curve[-1]["sites_per_s"]
+    n = int(min(S, max(32 * cores, rate * budget_s * 0.5)))
     n -= n % 32
     n = max(n, min(S, 32))
     t = run(n, cores)
@@ -205,24 +278,29 @@ def cpu_baseline_main(workload, T, budget_s):
         return done / (time.perf_counter() - t0)
 
     shaped = {}
-    for n_proc, groups in ((1, 12), (25, 8), (cores, 3)):
-        if n_proc > cores:
+    for n_proc, groups in ((1, 12), (25, 8), (facts["logical_cpus"], 3)):
+        if n_proc > facts["logical_cpus"]:
             continue
         shaped["n_processes=%d" % n_proc] = ref_shaped(n_proc, groups)
-    model = "unknown"
     try:
-        for line in open("/proc/cpuinfo"):
-            if line.startswith("model name"):
-                model = line.split(":", 1)[1].strip()
-                break
-    except OSError:
+        facts["loadavg_1_5_15_after"] = [float(x) for x in open("/proc/loadavg").read().split()[:3]]
+    except (OSError, ValueError):
         pass
-    return {"value": best, "unit": "sites/s", "cores": cores, "kind": "port", "cpu_model": model,
-            "per_core_value": best / cores, "single_thread_value": single,
-            "reference_shaped_value": shaped,
-            "sample": "first %d sites of the same workload (encoder + T=%d sampling) on %d host threads, %.1f s; "
-                      "single thread: %d sites; reference-shaped (fresh Pool per 32-site flush): 3-12 flush groups "
-                      "per setting" % (n, T, cores, t, n1)}
+    out = {"value": best, "unit": "sites/s", "cores": cores, "kind": "port", "cpu_model": facts["cpu_model"],
+           "effective_cores": cores, "host": facts,
+           "per_core_value": best / cores, "single_thread_value": single,
+           "scaling_efficiency": best / (cores * single), "scaling": curve,
+           "reference_shaped_value": shaped,
+           "sample": "first %d sites of the same workload (encoder + T=%d sampling) on %d host threads, %.1f s; "
+                     "single thread: %d sites; scaling curve: %d sites per thread at %s threads; reference-shaped "
+                     "(fresh Pool per 32-site flush): 3-12 flush groups per setting"
+                     % (n, T, cores, t, n1, per_thread, "/".join(str(c) for c in counts))}
+    cal = cpu_calibration()
+    if cal:
+        out["calibration"] = cal
+        # what the REFERENCE's own code would do on this host, by the calibration factor (oracle speed / reference speed)
+        out["reference_equivalent_value"] = best / cal["oracle_over_reference"]["whole_path"]
+    return out
 
 
 def run_cpu_baseline_subprocess(workload, T):

@@ -15,6 +15,7 @@
 
 #include <math.h>
 #include <pthread.h>
+#include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -262,35 +263,32 @@ int64_t m6a_or_flush_groups(int64_t n_sites, int64_t batch_size, int64_t save_pe
     return m6a_or_flush_groups_at(n_sites, batch_size, save_per_batch, 0, group_off);
 }
 
+/* Threads: flush groups are independent (each reseeds), so every thread owns ONE contiguous range of groups, cut once by
+ * site count (a site costs n_iters * n_samples accepted draws whatever its bag size) -- no shared cursor, no lock; the
+ * scratch of all threads is one block the caller allocated; each thread also counts its own sites' mod_ratio. */
 typedef struct {
-    const float *p; const int64_t *off; const int64_t *goff; int64_t n_groups;
-    int n_iters, n_samples; uint32_t seed; float *site; int64_t *next; pthread_mutex_t *mu;
-    int64_t chunk;
+    const float *p; const int64_t *off; const int64_t *goff; int64_t g0, g1;
+    int n_iters, n_samples; uint32_t seed; float thr; float *site; double *mod;
+    int32_t *idx; float *vals;
 } pool_job;
 
 static void *pool_worker(void *arg)
 {
     pool_job *j = (pool_job *)arg;
-    int32_t *idx = (int32_t *)malloc((size_t)j->n_iters * j->n_samples * sizeof(int32_t));
-    float *vals = (float *)malloc((size_t)j->n_iters * sizeof(float));
-    for (;;) {
-        pthread_mutex_lock(j->mu);
-        int64_t g0 = *j->next;
-        *j->next = g0 + j->chunk;
-        pthread_mutex_unlock(j->mu);
-        if (g0 >= j->n_groups) break;
-        int64_t g1 = g0 + j->chunk < j->n_groups ? g0 + j->chunk : j->n_groups;
-        for (int64_t g = g0; g < g1; g++) {
-            /* every flush group's Pool worker starts from the parent's never-advanced state
-             * (inference_utils.py:102-104 forks after inference.py:86 seeded): reseed. */
-            m6a_or_mt st;
-            m6a_or_mt_seed(&st, j->seed);
-            for (int64_t s = j->goff[g]; s < j->goff[g + 1]; s++)
-                j->site[s] = m6a_or_site_proba(&st, j->p + j->off[s], j->off[s + 1] - j->off[s],
-                                               j->n_iters, j->n_samples, idx, vals);
+    for (int64_t g = j->g0; g < j->g1; g++) {
+        /* every flush group's Pool worker starts from the parent's never-advanced state
+         * (inference_utils.py:102-104 forks after inference.py:86 seeded): reseed. */
+        m6a_or_mt st;
+        m6a_or_mt_seed(&st, j->seed);
+        for (int64_t s = j->goff[g]; s < j->goff[g + 1]; s++) {
+            const int64_t n = j->off[s + 1] - j->off[s];
+            j->site[s] = m6a_or_site_proba(&st, j->p + j->off[s], n, j->n_iters, j->n_samples, j->idx, j->vals);
+            /* inference_utils.py:53: np.mean(x >= thr): float32 compare, float64 mean */
+            int64_t c = 0;
+            for (int64_t r = j->off[s]; r < j->off[s + 1]; r++) c += j->p[r] >= j->thr;
+            j->mod[s] = n ? (double)c / (double)n : NAN;
         }
     }
-    free(idx); free(vals);
     return NULL;
 }
 
@@ -311,28 +309,36 @@ int m6a_or_site_pool_at(const float *read_prob, const int64_t *off, int64_t n_si
     int64_t n_batches = (n_sites + batch_size - 1) / batch_size;
     int64_t *goff = (int64_t *)malloc((size_t)(n_batches + 2) * sizeof(int64_t));
     if (!goff) return -1;
-    int64_t G = m6a_or_flush_groups_at(n_sites, batch_size, save_per_batch, first_site, goff);
-    int64_t next = 0;
-    pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER;
-    int64_t chunk = G / ((int64_t)(n_threads > 0 ? n_threads : 1) * 16);
-    if (chunk < 1) chunk = 1;
-    if (chunk > 64) chunk = 64;
-    pool_job job = { read_prob, off, goff, G, n_iters, n_samples, seed, site_prob, &next, &mu, chunk };
-    if (n_threads <= 1) {
-        pool_worker(&job);
+    const int64_t G = m6a_or_flush_groups_at(n_sites, batch_size, save_per_batch, first_site, goff);
+    int W = n_threads > 1 ? n_threads : 1;
+    if ((int64_t)W > G) W = (int)G;
+    const size_t n_idx = (size_t)n_iters * (size_t)n_samples, n_val = (size_t)n_iters;
+    /* per-thread scratch, 64-byte strides so two threads never share a line */
+    const size_t stride = ((n_idx * sizeof(int32_t) + n_val * sizeof(float) + 63) / 64 + 1) * 64;
+    char *scratch = (char *)malloc(stride * (size_t)W + 64);
+    pool_job *jobs = (pool_job *)malloc((size_t)W * sizeof(pool_job));
+    pthread_t *th = (pthread_t *)malloc((size_t)W * sizeof(pthread_t));
+    if (!scratch || !jobs || !th) { free(goff); free(scratch); free(jobs); free(th); return -1; }
+    char *base = (char *)(((uintptr_t)scratch + 63) & ~(uintptr_t)63);
+    int64_t g = 0;
+    for (int i = 0; i < W; i++) {
+        /* groups [g, e): up to the group whose last site reaches this thread's share of the sites */
+        const int64_t target = n_sites * (i + 1) / W;
+        int64_t e = g;
+        while (e < G && goff[e + 1] <= target) e++;
+        if (i == W - 1) e = G;
+        char *b = base + stride * (size_t)i;
+        jobs[i] = (pool_job){ read_prob, off, goff, g, e, n_iters, n_samples, seed, thr, site_prob, mod_ratio,
+                              (int32_t *)b, (float *)(b + n_idx * sizeof(int32_t)) };
+        g = e;
+    }
+    if (W == 1) {
+        pool_worker(&jobs[0]);
     } else {
-        pthread_t *th = (pthread_t *)malloc((size_t)n_threads * sizeof(pthread_t));
-        for (int i = 0; i < n_threads; i++) pthread_create(&th[i], NULL, pool_worker, &job);
-        for (int i = 0; i < n_threads; i++) pthread_join(th[i], NULL);
-        free(th);
+        for (int i = 0; i < W; i++) pthread_create(&th[i], NULL, pool_worker, &jobs[i]);
+        for (int i = 0; i < W; i++) pthread_join(th[i], NULL);
     }
-    /* inference_utils.py:53: np.mean(x >= thr): float32 compare, float64 mean */
-    for (int64_t s = 0; s < n_sites; s++) {
-        int64_t n = off[s + 1] - off[s], c = 0;
-        for (int64_t r = off[s]; r < off[s + 1]; r++) c += read_prob[r] >= thr;
-        mod_ratio[s] = n ? (double)c / (double)n : NAN;
-    }
-    free(goff);
+    free(th); free(jobs); free(scratch); free(goff);
     return 0;
 }
 
