@@ -9,7 +9,7 @@ INCLUDE = os.path.join(os.path.dirname(PKG), "include")
 LIB = os.path.join(PKG, "libm6a_hip.so")
 IO_LIB = os.path.join(PKG, "libm6a_io.so")
 SOURCES = ["m6a_kernels.hip", "m6a_pool_reg.hip", "m6a_pool_rtab.hip", "m6a_api.hip"]
-DEPS = SOURCES + ["m6a_kernels.h", os.path.join(INCLUDE, "m6a.h"), os.path.join(PKG, "assets", "mt19937_jump.bin")]
+DEPS = SOURCES + ["m6a_kernels.h", "m6a_host_cpus.h", os.path.join(INCLUDE, "m6a.h"), os.path.join(PKG, "assets", "mt19937_jump.bin")]
 
 
 def needs_build():
@@ -38,10 +38,11 @@ def build_io(force=False, verbose=False):
     """libm6a_io.so: host-only C++ (loader + CSV writers, include/m6a_io.h)."""
     src = os.path.join(CSRC, "m6a_io.cpp")
     hdr = os.path.join(INCLUDE, "m6a_io.h")
-    if not force and os.path.exists(IO_LIB) and os.path.getmtime(IO_LIB) >= max(os.path.getmtime(src), os.path.getmtime(hdr)):
+    deps = [src, hdr, os.path.join(CSRC, "m6a_host_cpus.h")]
+    if not force and os.path.exists(IO_LIB) and os.path.getmtime(IO_LIB) >= max(os.path.getmtime(d) for d in deps):
         return IO_LIB
     cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Wall", "-Wextra",
-           "-I" + INCLUDE, src, "-o", IO_LIB]
+           "-I" + INCLUDE, "-I" + CSRC, src, "-o", IO_LIB]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

@@ -22,6 +22,7 @@
 
 #include "m6a.h"
 #include "m6a_kernels.h"
+#include "m6a_host_cpus.h"
 
 // assets/mt19937_jump.bin inside the library (host pass only): the drop-in is ONE shared object, no file look-ups at run time
 #if !defined(__HIP_DEVICE_COMPILE__)
@@ -1148,7 +1149,7 @@ int ensure_staging(m6a_ctx *c)
         HIPCHK(c, hipEventCreateWithFlags(&g.ev_d2h[i], hipEventDisableTiming));
     }
     const char *et = getenv("M6A_COPY_THREADS");
-    int nt = et && atoi(et) > 0 ? atoi(et) : (int)std::min<unsigned>(16u, std::max(2u, std::thread::hardware_concurrency() / 2));
+    int nt = et && atoi(et) > 0 ? atoi(et) : std::min(16, std::max(2, m6a_usable_cpus()));
     g.pool.reset(new (std::nothrow) CopyPool(nt - 1));
     if (!g.pool) return fail(c, M6A_ENOMEM, "out of host memory");
     g.ready = true;
@@ -2341,7 +2342,7 @@ int validation_indices(m6a_ctx *c, const int64_t *h_off, int64_t S, int T, int K
     const int64_t n_items = (int64_t)T * S;
     const int64_t block_items = 2048;
     const char *env = getenv("M6A_VALIDATE_THREADS");
-    int n_workers = env ? atoi(env) : (int)std::min<unsigned>(32u, std::max(1u, std::thread::hardware_concurrency() / 2));
+    int n_workers = env ? atoi(env) : std::min(32, std::max(1, m6a_usable_cpus() - 2));
     if (n_items < 4 * block_items || n_workers < 1) n_workers = 0;          // small runs: walk and shuffle on this thread
 
     std::mutex mu;

@@ -1,6 +1,7 @@
 // m6a_io.cpp -- native loader for dataprep output and CSV writers (include/m6a_io.h).
 // Host-only C++17; parsing and formatting are spread over std::threads by site range.
 #include "m6a_io.h"
+#include "m6a_host_cpus.h"
 
 #include <fcntl.h>
 #include <sys/mman.h>
@@ -409,7 +410,7 @@ struct PhaseTrace {
 
 int n_workers(int n_threads, int64_t items)
 {
-    int n = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
+    int n = n_threads > 0 ? n_threads : m6a_usable_cpus();
     n = std::max(1, std::min<int>(n, 64));
     return (int)std::max<int64_t>(1, std::min<int64_t>(n, items));
 }
