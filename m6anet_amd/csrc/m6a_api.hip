@@ -755,7 +755,7 @@ int ensure_table_reg(m6a_ctx *c, uint32_t seed, int n, int T, int K, int jmax)
     if (k.valid && k.seed == seed && k.n == n && k.T == T && k.K == K && k.jmax >= jmax) return M6A_OK;
     k.valid = false;                                       // the table is rewritten below: a failure must not leave the old key standing
     const size_t per_j = (size_t)(T + 8) * K;              // K = 20: a multiple of 4 bytes
-    const size_t bytes = (size_t)jmax * per_j + 256;
+    const size_t bytes = (size_t)jmax * per_j + 4096;      // the kernel's look-ahead touches up to 2 KB past the last row
     HIPCHK(c, c->tab_reg.ensure(bytes));
     HIPCHK(c, hipMemsetAsync(c->tab_reg.p, 0, bytes, c->stream));
     const uint16_t *C = nullptr;

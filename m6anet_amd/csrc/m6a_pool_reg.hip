@@ -131,13 +131,85 @@ __global__ __launch_bounds__(64) void pool_reg_kernel(PoolArgs a)
     float o0, o1, o2, o3;
     int c0, c1, c2, c3;
     asm volatile(
-        // ---- bags: 32 entries x 4 sites straight into their registers; the per-lane byte offset stops
-        // advancing at the bag's last read, so entries >= n (never indexed) repeat it and nothing is
-        // read out of bounds
+        // ---- bags.  A lane's four bags are 4 x n floats at four unrelated addresses, and the lanes of a wave own bags 32
+        // sites apart: every load instruction touches 64 different cache lines whatever its width, so the instruction
+        // count is what the L1's tag pipe sees.  n % 4 == 0 (the reference's 20-read bags): n/4 global_load_dwordx4 per
+        // site into linear temporaries -- 20 instructions per wave instead of 128; with every resident wave in its
+        // prologue at once this phase was 0.10 of the kernel's 0.45 ms (tools/pool_reg_rounds.py) -- then the 1-p pass
+        // moves them to their interleaved places.  Other n: one dword per entry straight into place, the per-lane byte
+        // offset stops advancing at the bag's last read so nothing is read out of bounds.
         "v_mov_b32 v32, %[b0]\n"
         "v_mov_b32 v33, %[b1]\n"
         "v_mov_b32 v34, %[b2]\n"
         "v_mov_b32 v35, %[b3]\n"
+        // first iteration's indices, cursors, counters
+        "s_mov_b64 s[80:81], %[tab]\n"
+        "s_mov_b64 s[82:83], %[ctl]\n"
+        "s_load_dwordx16 s[36:51], s[80:81], 0\n"
+        "s_load_dwordx4 s[52:55], s[80:81], 64\n"
+        "s_mov_b32 s77, %[nr]\n"
+        "s_mov_b32 s78, 0\n"
+        // mod_ratio numerators: reads with p >= thr among the bag's n entries (v40..v43, one per site)
+        "v_mov_b32 v40, 0\n"
+        "v_mov_b32 v41, 0\n"
+        "v_mov_b32 v42, 0\n"
+        "v_mov_b32 v43, 0\n"
+        "s_and_b32 s79, %[n], 3\n"
+        "s_cmp_eq_u32 s79, 0\n"
+        "s_cbranch_scc0 80f\n"
+        // -- n % 4 == 0: site q -> v[64+32q .. 95+32q] (sites 2, 3 borrow the places of sites 0, 1)
+        "s_lshr_b32 s79, %[n], 2\n"
+        ".set m6a_e, 0\n"
+        ".rept 8\n"
+        "s_cmp_lt_u32 m6a_e, s79\n"
+        "s_cbranch_scc0 81f\n"
+        "global_load_dwordx4 v[64+4*m6a_e:67+4*m6a_e], v32, %[rp] offset:16*m6a_e\n"
+        "global_load_dwordx4 v[96+4*m6a_e:99+4*m6a_e], v33, %[rp] offset:16*m6a_e\n"
+        "global_load_dwordx4 v[128+4*m6a_e:131+4*m6a_e], v34, %[rp] offset:16*m6a_e\n"
+        "global_load_dwordx4 v[160+4*m6a_e:163+4*m6a_e], v35, %[rp] offset:16*m6a_e\n"
+        ".set m6a_e, m6a_e+1\n"
+        ".endr\n"
+        "81:\n"
+        "s_waitcnt vmcnt(0)\n"
+        ".set m6a_e, 0\n"
+        ".rept 32\n"
+        "s_cmp_lt_u32 m6a_e, %[n]\n"
+        "s_cselect_b64 s[84:85], exec, 0\n"
+        "v_cmp_le_f32 vcc, %[thr], v[64+m6a_e]\n"
+        "s_and_b64 vcc, vcc, s[84:85]\n"
+        "v_addc_co_u32 v40, vcc, 0, v40, vcc\n"
+        "v_cmp_le_f32 vcc, %[thr], v[96+m6a_e]\n"
+        "s_and_b64 vcc, vcc, s[84:85]\n"
+        "v_addc_co_u32 v41, vcc, 0, v41, vcc\n"
+        "v_cmp_le_f32 vcc, %[thr], v[128+m6a_e]\n"
+        "s_and_b64 vcc, vcc, s[84:85]\n"
+        "v_addc_co_u32 v42, vcc, 0, v42, vcc\n"
+        "v_cmp_le_f32 vcc, %[thr], v[160+m6a_e]\n"
+        "s_and_b64 vcc, vcc, s[84:85]\n"
+        "v_addc_co_u32 v43, vcc, 0, v43, vcc\n"
+        ".set m6a_e, m6a_e+1\n"
+        ".endr\n"
+        // 1-p into the interleaved places: sites 2, 3 first (their temporaries sit where sites 0, 1 go)
+        ".set m6a_e, 0\n"
+        ".rept 32\n"
+        "v_sub_f32 v[192+2*m6a_e], 1.0, v[128+m6a_e]\n"
+        "v_sub_f32 v[193+2*m6a_e], 1.0, v[160+m6a_e]\n"
+        ".set m6a_e, m6a_e+1\n"
+        ".endr\n"
+        ".set m6a_e, 0\n"
+        ".rept 32\n"
+        "v_sub_f32 v[128+2*m6a_e], 1.0, v[64+m6a_e]\n"
+        "v_sub_f32 v[129+2*m6a_e], 1.0, v[96+m6a_e]\n"
+        ".set m6a_e, m6a_e+1\n"
+        ".endr\n"
+        ".set m6a_i, 0\n"
+        ".rept 64\n"
+        "v_mov_b32 v[64+m6a_i], 0\n"
+        ".set m6a_i, m6a_i+1\n"
+        ".endr\n"
+        "s_branch 82f\n"
+        // -- any n: 32 entries x 4 sites straight into their registers
+        "80:\n"
         "s_sub_u32 s79, %[n], 1\n"
         // site-major: the 32 loads of one site hit the same one or two cache lines back to back (entry-major
         // order cycled through 256 lines per wavefront and thrashed the 32 KB L1: 4x the HBM traffic)
@@ -173,24 +245,12 @@ __global__ __launch_bounds__(64) void pool_reg_kernel(PoolArgs a)
         "v_add_u32 v35, s76, v35\n"
         ".set m6a_e, m6a_e+1\n"
         ".endr\n"
-        // first iteration's indices, cursors, counters
-        "s_mov_b64 s[80:81], %[tab]\n"
-        "s_mov_b64 s[82:83], %[ctl]\n"
-        "s_load_dwordx16 s[36:51], s[80:81], 0\n"
-        "s_load_dwordx4 s[52:55], s[80:81], 64\n"
-        "s_mov_b32 s77, %[nr]\n"
-        "s_mov_b32 s78, 0\n"
         ".set m6a_i, 0\n"
         ".rept 64\n"
         "v_mov_b32 v[64+m6a_i], 0\n"
         ".set m6a_i, m6a_i+1\n"
         ".endr\n"
         "s_waitcnt vmcnt(0)\n"
-        // mod_ratio numerators: reads with p >= thr among the bag's n entries (v40..v43, one per site)
-        "v_mov_b32 v40, 0\n"
-        "v_mov_b32 v41, 0\n"
-        "v_mov_b32 v42, 0\n"
-        "v_mov_b32 v43, 0\n"
         ".set m6a_e, 0\n"
         ".rept 32\n"
         "s_cmp_lt_u32 m6a_e, %[n]\n"
@@ -209,15 +269,16 @@ __global__ __launch_bounds__(64) void pool_reg_kernel(PoolArgs a)
         "v_addc_co_u32 v43, vcc, 0, v43, vcc\n"
         ".set m6a_e, m6a_e+1\n"
         ".endr\n"
-        "v_mov_b32 %[c0], v40\n"
-        "v_mov_b32 %[c1], v41\n"
-        "v_mov_b32 %[c2], v42\n"
-        "v_mov_b32 %[c3], v43\n"
         ".set m6a_i, 0\n"
         ".rept 128\n"
         "v_sub_f32 v[128+m6a_i], 1.0, v[128+m6a_i]\n"
         ".set m6a_i, m6a_i+1\n"
         ".endr\n"
+        "82:\n"
+        "v_mov_b32 %[c0], v40\n"
+        "v_mov_b32 %[c1], v41\n"
+        "v_mov_b32 %[c2], v42\n"
+        "v_mov_b32 %[c3], v43\n"
         "s_waitcnt lgkmcnt(0)\n"
         "s_cmp_eq_u32 s77, 0\n"
         "s_cbranch_scc1 3f\n"

@@ -1,0 +1,144 @@
+#!/usr/bin/env python3
+"""Knock-out builds of pool_reg_kernel (RESULTS WRONG, timing only): what do the per-draw SALU instructions, the scalar
+index loads and the index mode itself cost next to the two v_pk_mul_f32 a draw of four sites needs?  (VERDICT r3 item 4:
+tools/valu_rate_bench shows the part delivers a v_pk_mul_f32 per 4.6 SIMD cycles at two waves per SIMD, i.e. 9.2 cycles
+per draw; the kernel takes 14.0.)
+
+    python tools/pool_reg_knockouts.py --build      # build container: cross-compiles tools/ko/libm6a_<variant>.so
+    python tools/pool_reg_knockouts.py              # GPU box: times the pooling of 1 M sites x 20 reads, T = 1000, per variant
+"""
+import json
+import os
+import re
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+CSRC = os.path.join(REPO, "m6anet_amd", "csrc")
+KO = os.path.join(HERE, "ko")
+
+
+def sub(pattern, repl, s, count=1, flags=0):
+    out, n = re.subn(pattern, repl, s, count=count, flags=flags)
+    assert n >= 1, pattern
+    return out
+
+
+def no_loop_loads(s):
+    a = s.index('"1:\\n"')
+    b = s.index('"3:\\n"')
+    body = s[a:b]
+    body = re.sub(r'\s*"s_load_dwordx16 s\[\d+:\d+\], s\[80:81\], \d+\\n"', "", body)
+    body = re.sub(r'\s*"s_load_dwordx4 s\[\d+:\d+\], s\[80:81\], \d+\\n"', "", body)
+    return s[:a] + body + s[b:]
+
+
+def vprefetch(look):
+    """Three dummy VECTOR loads per round, `look` bytes ahead of the round's indices: they pull the lines of the index row
+    into L2 long before the scalar loads ask for them (a scalar load cannot be waited for selectively: lgkmcnt(0) waits for
+    all, so the look-ahead itself cannot be a scalar load; vmcnt is never waited for inside the loop)."""
+    def f(s):
+        s = s.replace('"s_mov_b32 s78, 0\\n"', '"s_mov_b32 s78, 0\\n"\n        "v_mov_b32 v36, 0\\n"', 1)
+        s = s.replace('"1:\\n"', '"1:\\n"\n        "global_load_dword v37, v36, s[80:81] offset:%d\\n"\n        "global_load_dword v37, v36, s[80:81] offset:%d\\n"\n'
+                                  '        "global_load_dword v37, v36, s[80:81] offset:%d\\n"' % (look, look + 64, look + 128), 1)
+        s = s.replace('"v_mov_b32 %[o0], v60\\n"', '"s_waitcnt vmcnt(0)\\n"\n        "v_mov_b32 %[o0], v60\\n"', 1)
+        s = s.replace('"v32", "v33", "v34", "v35", "v40"', '"v32", "v33", "v34", "v35", "v36", "v37", "v40"', 1)
+        assert "global_load_dword v37" in s and '"v36", "v37"' in s and "v_mov_b32 v36, 0" in s
+        return s
+    return f
+
+
+VARIANTS = {
+    "asis": lambda s: s,
+    # 3 instructions per draw: no in-place shift of the index dword (every draw of a dword uses its low byte)
+    "noshr": lambda s: sub(r'#define SHR\(r\) .*', '#define SHR(r) ""', s),
+    # 2 instructions per draw: no index switch either (index mode stays on with the first draw's index)
+    "noidx": lambda s: sub(r'#define IDX\(r\) .*', '#define IDX(r) ""', sub(r'#define SHR\(r\) .*', '#define SHR(r) ""', s)),
+    # the scalar index loads of the round loop removed (stale registers)
+    "noload": no_loop_loads,
+    "pkonly": lambda s: no_loop_loads(VARIANTS["noidx"](s)),
+    # the shift moved between the two multiplies of the PREVIOUS draw (same instruction count, SALU never back to back)
+    "vpre640": vprefetch(640),
+    "vpre1600": vprefetch(1600),
+    "vpre3200": vprefetch(3200),
+    "spread": lambda s: sub(r'#define DRAW4\(r\) .*',
+                            '#define MULA "v_pk_mul_f32 v[56:57], v[128:129], v[56:57]\\\\n"\n#define MULB "v_pk_mul_f32 v[58:59], v[192:193], v[58:59]\\\\n"\n'
+                            '#define DRAW4(r) IDX(r) MULA SHR(r) MULB IDX(r) MULA SHR(r) MULB IDX(r) MULA SHR(r) MULB IDX(r) MULA MULB', s),
+}
+
+
+def build():
+    os.makedirs(KO, exist_ok=True)
+    src = open(os.path.join(CSRC, "m6a_pool_reg.hip")).read()
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-w",
+             '-DM6A_MT_JUMP_PATH="%s"' % os.path.join(REPO, "m6anet_amd", "assets", "mt19937_jump.bin"),
+             "-I" + os.path.join(REPO, "include"), "-I" + CSRC]
+    objs = []
+    for f in ("m6a_kernels.hip", "m6a_pool_rtab.hip", "m6a_api.hip"):
+        o = os.path.join(KO, f.replace(".hip", ".o"))
+        if not os.path.exists(o) or os.path.getmtime(o) < os.path.getmtime(os.path.join(CSRC, f)):
+            subprocess.check_call([hipcc] + flags + ["-c", os.path.join(CSRC, f), "-o", o])
+        objs.append(o)
+    for name, fn in VARIANTS.items():
+        p = os.path.join(KO, "pool_reg_%s.hip" % name)
+        open(p, "w").write(fn(src))
+        o = p.replace(".hip", ".o")
+        subprocess.check_call([hipcc] + flags + ["-c", p, "-o", o])
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + [o, "-o", os.path.join(KO, "libm6a_%s.so" % name)])
+        print("built", name)
+
+
+def time_one():
+    import numpy as np
+    import torch
+    sys.path.insert(0, REPO)
+    from m6anet_amd.engine import M6ANetEngine, load_weights
+    T = 1000
+    eng = M6ANetEngine(weights=load_weights("HCT116_RNA002"))
+    out = {}
+    for S in (1_000_000, 524_288, 2_097_152):
+        g = torch.Generator(device="cuda").manual_seed(1)
+        p = torch.rand(S * 20, device="cuda", generator=g) ** 4
+        off = torch.arange(0, S * 20 + 1, 20, device="cuda", dtype=torch.int64)
+        scratch = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
+        for _ in range(3):
+            eng.calculate_site_proba(p, off, T)
+        eng.sync()
+        eng.profile("pooling")
+        for _ in range(20):
+            scratch.zero_()                               # what the encoder does to the caches between two poolings
+            eng.calculate_site_proba(p, off, T)
+        ms, n = eng.profile_read(1)
+        eng.profile(False)
+        out["pool_ms_%d" % S] = ms / n
+        if S == 1_000_000:
+            out.update({"pool_ms": ms / n, "launches": n, "variant": eng.last_pool_variant,
+                        "cycles_per_draw_of_4_at_2.4GHz": ms / n * 1e-3 * 2.4e9 * 1024 / (S * T * 20 / 4 / 64)})
+        del p, off, scratch
+    print(json.dumps(out))
+
+
+def main():
+    if "--build" in sys.argv:
+        build()
+        return
+    if "--one" in sys.argv:
+        time_one()
+        return
+    rows = {}
+    for name in VARIANTS:
+        lib = os.path.join(KO, "libm6a_%s.so" % name)
+        if not os.path.exists(lib):
+            continue
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--one"], env=dict(os.environ, M6A_HIP_LIB=lib),
+                             capture_output=True, text=True, timeout=600)
+        line = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        rows[name] = json.loads(line[-1]) if line else {"error": out.stderr[-300:]}
+        print(name, rows[name], file=sys.stderr)
+    print(json.dumps(rows, indent=1))
+
+
+if __name__ == "__main__":
+    main()
