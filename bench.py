@@ -53,9 +53,10 @@ def pool_roofline(variant, draws, avg_ms, launches):
     rate = draws / (avg_ms * 1e-3) if avg_ms else None
     if variant == "table-reg":
         bound, peak = "valu", PEAK_VALU_MULS
-        note = ("peak = NOMINAL packed float32 multiply rate (2 per lane per 4-cycle issue slot, 78.6 T/s).  The part does not deliver it: "
-                "a v_pk_mul_f32 costs 6.1-7 cycles per wave64 whatever the occupancy and a plain v_mul_f32 3.05 (profiles/r03_gpr_variants.txt: "
-                "the same 21 lane-multiplies per SIMD cycle either way); measured_ceiling, taken live, is that multiply throughput")
+        note = ("peak = nominal float32 multiply rate, 32 lanes per SIMD cycle at 2.4 GHz = 78.6 T/s (a wave64 v_mul_f32 in 2 cycles, a "
+                "v_pk_mul_f32 in 4: packing buys nothing).  Chain-free streams reach 0.85-0.94 of it (tools/valu_rate_bench, "
+                "profiles/r04_valu_rate.json: 2.2-2.4 / 4.2-4.7 cycles; dependent chains and register banks make no difference, random "
+                "mantissas cost 3-12 % through the clock).  measured_ceiling, taken live, is the kernel's own draw with nothing around it")
     else:
         bound, peak = "l1-lds", PEAK_LDS_GATHERS
         note = ("a draw moves 2 index bytes through the vector L1 (64 B/clk/CU) and one 4-byte LDS gather (32 banks/clk/CU): both pipes "
@@ -356,32 +357,26 @@ def measured_gather_ceiling(bag):
 
 
 def measured_multiply_ceiling():
-    """What bags-in-registers can reach on THIS box, measured now: tools/gpr_variants (tools/gpr_variants_gen.py) runs the
-    inner loop of pool_reg_kernel -- one float32 multiply per draw and site, nothing else -- at 2, 4 and 8 resident waves per
-    SIMD, with and without the VGPR index switch.  The best row WITHOUT index switching is the multiply throughput of the
-    part (no kernel that has to select a register per draw can beat it)."""
-    exe = os.path.join(REPO, "tools", "gpr_variants")
+    """What float32 multiplies cost on THIS box, measured now by tools/valu_rate_bench --ceiling (chain-free streams with
+    random mantissas, events over ~1 ms kernels): the plain and the packed multiply at 2 and 8 waves per SIMD, and
+    pool_reg_kernel's own draw -- two indexed v_pk_mul_f32 behind a shift and an index switch, 256-register single-wave
+    workgroups, 2 waves per SIMD -- with nothing else around it.  `rate` = the last one: what the kernel's instruction
+    stream can reach; the chain-free rows say what the datapath delivers (profiles/r04_valu_rate.json has every variant)."""
+    exe = os.path.join(REPO, "tools", "valu_rate_bench")
     if not os.path.exists(exe):
         return None
     try:
-        out = subprocess.run([exe], capture_output=True, text=True, timeout=120).stdout
-    except (subprocess.SubprocessError, OSError):
+        out = subprocess.run([exe, "--ceiling"], capture_output=True, text=True, timeout=120).stdout
+        rows = json.loads(out)["rows"]
+    except (subprocess.SubprocessError, OSError, ValueError, KeyError):
         return None
-    rows = {}
-    for line in out.splitlines():
-        f = line.split()
-        if len(f) > 4 and f[2] == "ms" and f[4] == "T":
-            try:
-                rows[f[0]] = float(f[3]) * 1e12
-            except ValueError:
-                pass
-    noidx = {k: v for k, v in rows.items() if k.endswith("noidx")}
-    if not noidx:
+    table = {"%s @ %d waves/SIMD" % (" ".join(r["variant"].split()), r["waves_per_simd"]): r["T_lane_ops_per_s"] for r in rows}
+    like = [r for r in rows if "2 SALU" in r["variant"]]
+    if not like:
         return None
-    best = max(noidx, key=noidx.get)
-    return {"rate": noidx[best], "variant": best, "rows": {k: v / 1e12 for k, v in rows.items()},
-            "source": "tools/gpr_variants run by this bench: the kernel's inner loop (one multiply per draw and site) at 2 / 4 / 8 waves "
-                      "per SIMD, with and without the VGPR index switch; ceiling = best row without it (%s)" % best}
+    return {"rate": like[0]["T_lane_ops_per_s"] * 1e12, "variant": like[0]["variant"], "rows": table,
+            "source": "tools/valu_rate_bench --ceiling run by this bench: pool_reg_kernel's draw (shift + index switch + two indexed "
+                      "v_pk_mul_f32, random mantissas, 2 waves per SIMD) with nothing else around it"}
 
 
 def smi_snapshot():
@@ -665,17 +660,18 @@ class Bench:
         if gather_ceiling and self.rank == 0 and proof["achieved"]:
             if eng.last_pool_variant == "table-reg":
                 m = measured_multiply_ceiling()
-                detail = {"T_draws_per_s_by_variant": m["rows"]} if m else {}
+                detail = {"T_lane_multiplies_per_s": m["rows"]} if m else {}
             elif eng.last_pool_variant == "ragged-table":
                 m = measured_gather_ceiling(bag)
                 detail = {"T_gathers_per_s_by_bag_size": m["points"]} if m else {}
+        # `peak` / `frac` are ALWAYS the nominal figure (comparable across rounds); what the part delivers for the kernel's
+        # instruction mix, measured by this run, sits beside them
+        proof["peak_source"] = "nominal"
         if m is not None:
-            proof["nominal_peak"], proof["nominal_frac"] = proof["peak"], proof["frac"]
-            proof["peak"], proof["frac"] = m["rate"] / 1e12, proof["achieved"] * 1e12 / m["rate"]
-            proof["peak_source"] = m["source"]
-            proof["measured_ceiling"] = dict({"peak": m["rate"] / 1e12, "unit": "T draws/s", "frac": proof["frac"], "source": m["source"]}, **detail)
+            proof["measured_ceiling"] = dict({"peak": m["rate"] / 1e12, "unit": "T draws/s", "frac": proof["achieved"] * 1e12 / m["rate"],
+                                              "source": m["source"]}, **detail)
         else:
-            proof["peak_source"] = "nominal (the microbenchmark binary under tools/ is not built: __graft_entry__.build())"
+            proof["measured_ceiling"] = None
         value = total_sites * steps / r["dt"]
         out = {
             "value": value,

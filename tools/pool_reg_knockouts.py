@@ -49,8 +49,25 @@ def vprefetch(look):
     return f
 
 
+def stamps(s):
+    """s_memtime at wave start, after the prologue and at the end, delivered through the four site results of lane 0..63:
+    q0 = prologue cycles, q1 = loop cycles, q2 = start (low 24 bits, in 256-cycle units), q3 = end (same units)."""
+    s = s.replace('"v_mov_b32 v32, %[b0]\\n"', '"s_memtime s[86:87]\\n"\n        "v_mov_b32 v32, %[b0]\\n"', 1)
+    s = s.replace('"82:\\n"', '"82:\\n"\n        "s_waitcnt lgkmcnt(0)\\n"\n        "s_memtime s[88:89]\\n"', 1)
+    s = s.replace('"v_mov_b32 %[o0], v60\\n"\n        "v_mov_b32 %[o1], v61\\n"\n        "v_mov_b32 %[o2], v62\\n"\n        "v_mov_b32 %[o3], v63\\n"',
+                  '"s_memtime s[90:91]\\n"\n        "s_waitcnt lgkmcnt(0)\\n"\n'
+                  '        "s_sub_u32 s92, s88, s86\\n"\n        "s_sub_u32 s93, s90, s88\\n"\n'
+                  '        "s_lshr_b64 s[86:87], s[86:87], 8\\n"\n        "s_and_b32 s86, s86, 0xffffff\\n"\n'
+                  '        "s_lshr_b64 s[90:91], s[90:91], 8\\n"\n        "s_and_b32 s90, s90, 0xffffff\\n"\n'
+                  '        "v_cvt_f32_u32 %[o0], s92\\n"\n        "v_cvt_f32_u32 %[o1], s93\\n"\n        "v_cvt_f32_u32 %[o2], s86\\n"\n        "v_cvt_f32_u32 %[o3], s90\\n"', 1)
+    s = s.replace('"s84", "s85",', '"s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93",', 1)
+    assert "s_memtime s[90:91]" in s and "s_memtime s[88:89]" in s and "s_memtime s[86:87]" in s and '"s93",' in s
+    return s
+
+
 VARIANTS = {
     "asis": lambda s: s,
+    "stamps": stamps,
     # 3 instructions per draw: no in-place shift of the index dword (every draw of a dword uses its low byte)
     "noshr": lambda s: sub(r'#define SHR\(r\) .*', '#define SHR(r) ""', s),
     # 2 instructions per draw: no index switch either (index mode stays on with the first draw's index)
@@ -120,7 +137,43 @@ def time_one():
     print(json.dumps(out))
 
 
+def read_stamps():
+    """Run the `stamps` build: per wave prologue / loop cycles and start / end times, for one round and for the bench shape."""
+    import numpy as np
+    import torch
+    sys.path.insert(0, REPO)
+    from m6anet_amd.engine import M6ANetEngine, load_weights
+    T = 1000
+    eng = M6ANetEngine(weights=load_weights("HCT116_RNA002"))
+    out = {}
+    for S in (262_144, 524_288, 1_000_000, 2_097_152):
+        g = torch.Generator(device="cuda").manual_seed(1)
+        p = torch.rand(S * 20, device="cuda", generator=g) ** 4
+        off = torch.arange(0, S * 20 + 1, 20, device="cuda", dtype=torch.int64)
+        for _ in range(3):
+            site, _ = eng.calculate_site_proba(p, off, T)
+        eng.sync()
+        v = site.cpu().numpy().astype(np.float64) * T                 # the kernel divides by T
+        G = S // 32
+        v = v[:G * 32].reshape(G, 32)                                  # [group][position j]
+        # lane = group (g0 + q*64 + lane): q = (group % 256) // 64
+        q = (np.arange(G) % 256) // 64
+        pro, loop = v[q == 0].ravel(), v[q == 1].ravel()
+        start, end = v[q == 2].ravel() * 256.0, v[q == 3].ravel() * 256.0
+        t0 = start.min()
+        out[S] = {"waves": 32 * ((G + 255) // 256),
+                  "prologue_cycles": {"median": float(np.median(pro)), "p95": float(np.quantile(pro, 0.95)), "max": float(pro.max())},
+                  "loop_cycles": {"median": float(np.median(loop)), "p5": float(np.quantile(loop, 0.05)), "p95": float(np.quantile(loop, 0.95))},
+                  "wave_start_cycles_after_first": {"median": float(np.median(start - t0)), "p95": float(np.quantile(start - t0, 0.95)), "max": float((start - t0).max())},
+                  "kernel_span_cycles": float(end.max() - t0)}
+        print(S, out[S], file=sys.stderr)
+    print(json.dumps(out, indent=1))
+
+
 def main():
+    if "--stamps" in sys.argv:
+        read_stamps()
+        return
     if "--build" in sys.argv:
         build()
         return

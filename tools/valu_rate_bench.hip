@@ -158,7 +158,8 @@ struct Variant { const char *name; kern_t fn; int lane_ops; const char *what; };
 
 int main(int argc, char **argv)
 {
-    const int iters = argc > 1 ? atoi(argv[1]) : 16000;
+    const bool quick = argc > 1 && std::string(argv[1]) == "--ceiling";     // bench.py: the rows pool_roofline quotes, ~0.1 s
+    const int iters = quick ? 4000 : argc > 1 ? atoi(argv[1]) : 16000;
     hipDeviceProp_t prop;
     CHECK(hipGetDeviceProperties(&prop, 0));
     const int cus = prop.multiProcessorCount;
@@ -190,7 +191,9 @@ int main(int argc, char **argv)
     printf("{\"device\": \"%s\", \"cus\": %d, \"iters\": %d, \"instr_per_wave\": %d, \"rows\": [\n", prop.gcnArchName, cus, iters, iters * INSTR_PER_ITER);
     bool first = true;
     for (const Variant &v : vs) {
+        if (quick && v.fn != (kern_t)k_mul_rand && v.fn != (kern_t)k_pkmul_rand) continue;
         for (int W : {1, 2, 4, 8}) {
+            if (quick && W != 2 && W != 8) continue;
             // exactly W workgroups of 4 waves (one per SIMD) fit a CU: each takes 1/W of the 160 KB of LDS
             const size_t lds = (size_t)(160 * 1024 / W) - (W == 1 ? 0 : 512);
             CHECK(hipFuncSetAttribute((const void *)v.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -252,6 +255,7 @@ int main(int argc, char **argv)
     // scale with N when one wave takes ~0.2 ms?  (tools/pool_reg_rounds.py: the kernel itself is 0.36 ms at 2 048 waves but
     // only +0.17 ms per further 2 048)
     for (int waves : {512, 1024, 2048, 3936, 4096, 6144, 8192, 16384}) {
+        if (quick) break;
         const int it = 700;
         hipLaunchKernelGGL(k_klike64_sw2, dim3(waves), dim3(64), 0, 0, it, 1.0000001f, out, cyc);
         CHECK(hipDeviceSynchronize());
