@@ -334,6 +334,11 @@ void build_fragments(const float *w, std::vector<float> &frag, std::vector<float
         for (int k = 0; k < 150; k++) w2[o * 160 + k] = w[O_W2 + 150 * o + k];
         w2[o * 160 + 150] = w[O_B2 + o];
     }
+    // the kernels' ReLU is x + |x| = 2 * relu(x) (one full-rate v_add_f32; max is half rate, m6a_kernels.hip): the 0.5 rides in
+    // the weights that consume the activations -- exact for every normal float (a weight below 2^-125 would lose its last bit:
+    // a contribution under 1e-37 per unit of activation)
+    for (float &v : w2) v *= 0.5f;
+    const float w3_scale = 0.5f;
     frag.assign(M6A_WFRAG_FLOATS, 0.f);
     for (int lane = 0; lane < 64; lane++) {
         const int col = lane & 31, half = lane >> 5;
@@ -346,7 +351,7 @@ void build_fragments(const float *w, std::vector<float> &frag, std::vector<float
             }
         }
         for (int q = 0; q < 16; q++)
-            frag[(120 + q) * 64 + lane] = w[O_W3 + (q & 3) + 8 * (q >> 2) + 4 * half];
+            frag[(120 + q) * 64 + lane] = w3_scale * w[O_W3 + (q & 3) + 8 * (q >> 2) + 4 * half];
     }
     // 12-slot kernel: x-slot fragments W1'[u][2st+half] (st<4), W1'[u][8]; and the per-unit rows the
     // per-site c vectors are folded from: W1'[u][9..14], b1'[u]  (w1 column 15 is the folded bias)

@@ -51,15 +51,17 @@ __device__ __forceinline__ int wave_sum_i32(int v)
 // 80 layer-2 MFMAs per tile, same bits).
 #define L2_REGS(m) ((m) == 4 ? 12 : 16)
 
-// ReLU as one integer max: negative floats (and -0.0) have the sign bit set, i.e. are negative
-// as int32, so max(bits, 0) zeroes them and leaves positive values untouched.  fmaxf() costs two
-// VALU ops here (a canonicalising v_max first), and the encoder issues 96 of them per tile.
-__device__ __forceinline__ float relu_bits(float x)
+// ReLU, doubled: x + |x| is exactly 2*max(x, 0) (2x for x > 0 -- doubling is exact --, x + (-x) = +0 otherwise, -0 + 0 = +0),
+// and the 0.5 rides in the next layer's weights (W2aug, W3: halving a normal float is exact too), so every product the
+// MFMAs and the epilogue's fmaf chain form is the one they formed before, bit for bit (checked on 2.1 M reads x 4
+// checkpoints x both kernels, tools/compare_encoder_builds.py).  Why: max is a HALF-rate VALU operation on gfx950 --
+// v_max_i32, v_max_f32 and v_med3_f32 all take 4.2-4.9 cycles per wave64 where v_add_f32 / v_mul_f32 take 2.2-2.4
+// (tools/valu_rate_bench, profiles/r04_valu_rate.json) -- the encoder issues 92 of them per tile on the datapath its f32
+// MFMAs use, and |x| is a free source modifier of v_add_f32: encoder 2.093 -> 2.065 ms.  (Rounds 1-3 used one v_max_i32 on
+// the float's bits; fmaxf() costs two VALU ops, a canonicalising v_max first; v_max_f32 through inline asm pins the schedule.)
+__device__ __forceinline__ float relu2(float x)
 {
-    // (a bare `v_max_f32 y, 0, x` through inline asm -- one instruction as well, f32 rate -- measured 1 % SLOWER on the
-    // bench workload, 2.118 vs 2.094 ms: the asm statements pin the schedule around the MFMAs)
-    const int b = __builtin_bit_cast(int, x);
-    return __builtin_bit_cast(float, b > 0 ? b : 0);
+    return x + __builtin_fabsf(x);
 }
 
 // A value the program knows to be wave-uniform, made provably so: addresses built from it use
@@ -205,7 +207,7 @@ __global__ __launch_bounds__(256, 2) void enc_kernel(EncArgs a)
         link0(s_base, o);
 
         // Layer 1 of unit-tile m+1 is issued ahead of layer 2 of unit-tile m (ping-pong
-        // accumulators).  ReLU is applied to a finished tile as one batch of 16 v_max_i32 and
+        // accumulators).  ReLU is applied to a finished tile as one batch of 16 v_add_f32 (x + |x|, see relu2) and
         // the 16 layer-2 MFMAs that consume it then issue back to back: a VALU op wedged between
         // two MFMAs on the same accumulator costs ~6% of the matrix pipe (tools/mfma_chain_bench).
         f32x16 acc2, h1a, h1b;
@@ -229,7 +231,7 @@ __global__ __launch_bounds__(256, 2) void enc_kernel(EncArgs a)
             if (m == 0) link1(tn, s_base, o, sn, km, fn);
             if (m == 2) link2(km, fn);
 #pragma unroll
-            for (int q = 0; q < L2_REGS(m); q++) cur[q] = relu_bits(cur[q]);
+            for (int q = 0; q < L2_REGS(m); q++) cur[q] = relu2(cur[q]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int q = 0; q < L2_REGS(m); q++)
@@ -238,7 +240,7 @@ __global__ __launch_bounds__(256, 2) void enc_kernel(EncArgs a)
         }
         float z = 0.0f;
 #pragma unroll
-        for (int q = 0; q < 16; q++) z = fmaf(relu_bits(acc2[q]), w3[q], z);
+        for (int q = 0; q < 16; q++) z = fmaf(relu2(acc2[q]), w3[q], z);
         z += __shfl_xor(z, 32, 64);
         z += a.b3;
         const float p = 1.0f / (1.0f + expf(-z));
@@ -443,7 +445,7 @@ __global__ __launch_bounds__(256, 2) void enc_csite_kernel(EncArgs a)
             if (m == 1) link2(kidn, evn);
             if (m == 3) link3(evn, reln, fn[4], f, a4, a5);             // layer1(4) has issued: in place
 #pragma unroll
-            for (int q = 0; q < L2_REGS(m); q++) cur[q] = relu_bits(cur[q]);
+            for (int q = 0; q < L2_REGS(m); q++) cur[q] = relu2(cur[q]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int q = 0; q < L2_REGS(m); q++)
@@ -452,7 +454,7 @@ __global__ __launch_bounds__(256, 2) void enc_csite_kernel(EncArgs a)
         }
         float z = 0.0f;
 #pragma unroll
-        for (int q = 0; q < 16; q++) z = fmaf(relu_bits(acc2[q]), s_w3[half * 16 + q], z);
+        for (int q = 0; q < 16; q++) z = fmaf(relu2(acc2[q]), s_w3[half * 16 + q], z);
         z += __shfl_xor(z, 32, 64);
         z += a.b3;
         const float p = 1.0f / (1.0f + expf(-z));

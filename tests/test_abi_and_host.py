@@ -212,3 +212,15 @@ def test_multi_gpu_exchange_plumbing(tmp_path, monkeypatch):
     multi_gpu._publish(p, b"abc" * 1000)
     assert open(p, "rb").read() == b"abc" * 1000 and os.listdir(tmp_path) == ["shard1.bin"]
     multi_gpu._wait_for(p, "present", os.getppid())
+
+
+def test_bundled_weights_halve_exactly(weights):
+    """The kernels' ReLU is x + |x| = 2 relu(x); the 0.5 rides in W2 / b2 / W3 (m6a_api.hip::build_fragments).  That is
+    bit-neutral iff halving those weights is exact, i.e. none of them is sub-normal after halving: true for all four
+    bundled checkpoints (and for any float with |w| >= 2^-125)."""
+    for name, w in weights.items():
+        tail = w[3132:7996]                      # W2 [32,150], b2 [32], W3 [32]  (blob layout: include/m6a.h)
+        half = (tail * np.float32(0.5)).astype(np.float32)
+        assert np.array_equal(half * np.float32(2.0), tail), name
+        nz = np.abs(tail[tail != 0])
+        assert nz.min() > 2.0 ** -100, (name, float(nz.min()))

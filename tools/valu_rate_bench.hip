@@ -69,6 +69,8 @@ constexpr int INSTR_PER_ITER = 64;
 #define BODY_PKMUL_IDXSW "  s_mov_b32 s37, 0\n  s_set_gpr_idx_on s37, gpr_idx(SRC0)\n  .rept 32\n  s_set_gpr_idx_idx s37\n  v_pk_mul_f32 v[16:17], v[10:11], v[16:17]\n  v_pk_mul_f32 v[18:19], v[8:9], v[18:19]\n  .endr\n  s_set_gpr_idx_off\n"
 // integer and move for scale: is it the f32 datapath or VALU issue in general?
 #define BODY_ADDU    "  .rept 4\n  .set i, 0\n  .rept 16\n  v_add_u32 v[16+i], v[8+((i+1)&3)], v[16+i]\n  .set i, i+1\n  .endr\n  .endr\n"
+#define BODY_MAXF    "  .rept 4\n  .set i, 0\n  .rept 16\n  v_max_f32 v[16+i], v[8+((i+1)&3)], v[16+i]\n  .set i, i+1\n  .endr\n  .endr\n"
+#define BODY_MED3    "  .rept 4\n  .set i, 0\n  .rept 16\n  v_med3_f32 v[16+i], v[8+((i+1)&3)], v[16+i], v[12+((i+2)&3)]\n  .set i, i+1\n  .endr\n  .endr\n"
 #define BODY_MAXI    "  .rept 4\n  .set i, 0\n  .rept 16\n  v_max_i32 v[16+i], v[8+((i+1)&3)], v[16+i]\n  .set i, i+1\n  .endr\n  .endr\n"
 
 #define KERNEL(name, BODY)                                                                                          \
@@ -152,6 +154,8 @@ KERNEL(k_pkmul_dep2, BODY_PKMUL_DEP2)
 KERNEL(k_pkfma, BODY_PKFMA)
 KERNEL(k_addu, BODY_ADDU)
 KERNEL(k_maxi, BODY_MAXI)
+KERNEL(k_maxf, BODY_MAXF)
+KERNEL(k_med3, BODY_MED3)
 
 typedef void (*kern_t)(int, float, float *, unsigned long long *);
 struct Variant { const char *name; kern_t fn; int lane_ops; const char *what; };
@@ -182,6 +186,8 @@ int main(int argc, char **argv)
         {"v_pk_mul_f32   2 chains, index switched per pair, random", k_pkmul_idxsw_rand, 2, ""},
         {"v_add_u32      16 indep", k_addu, 1, ""},
         {"v_max_i32      16 indep", k_maxi, 1, ""},
+        {"v_max_f32      16 indep", k_maxf, 1, ""},
+        {"v_med3_f32     16 indep", k_med3, 1, ""},
     };
     float *out; unsigned long long *cyc;
     CHECK(hipMalloc(&out, (size_t)16384 * 256 * 4));
