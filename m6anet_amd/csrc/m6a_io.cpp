@@ -19,6 +19,8 @@
 #include <cstdio>
 #include <cstring>
 #include <array>
+#include <atomic>
+#include <condition_variable>
 #include <map>
 #include <mutex>
 #include <set>
@@ -49,7 +51,10 @@ struct Mapped {
     const char *p = nullptr;
     size_t n = 0;
     int fd = -1;
-    int open(const std::string &path)
+    // populate_max: files up to this size are mapped with MAP_POPULATE (one pass over the page tables instead of a fault
+    // per page per thread); larger ones -- an eventalign.txt is tens to hundreds of GB -- are mapped lazily and read ahead
+    // sequentially, so neither the address space nor the page cache has to hold the file at once
+    int open(const std::string &path, size_t populate_max = ~(size_t)0)
     {
         fd = ::open(path.c_str(), O_RDONLY);
         if (fd < 0) return fail(M6A_IO_EIO, "cannot open %s", path.c_str());
@@ -57,9 +62,11 @@ struct Mapped {
         if (fstat(fd, &st) != 0) return fail(M6A_IO_EIO, "cannot stat %s", path.c_str());
         n = (size_t)st.st_size;
         if (n) {
-            void *m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);   // one pass over the page tables, not a fault per page per thread
+            const bool populate = n <= populate_max;
+            void *m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE | (populate ? MAP_POPULATE : 0), fd, 0);
             if (m == MAP_FAILED) return fail(M6A_IO_EIO, "cannot mmap %s", path.c_str());
             p = (const char *)m;
+            if (!populate) (void)madvise(m, n, MADV_SEQUENTIAL);
         }
         return 0;
     }
@@ -959,15 +966,160 @@ bool combine_read(const char *p, const char *e, std::vector<Pos> &out)
     return true;
 }
 
-struct SiteRow { long long pos; std::string kmer7; double f[9]; long long read; };
+struct IdxRun { uint32_t tx; long long read; int64_t start, end; };      // tx = id in order of first appearance
+
+struct SiteRow { long long pos; std::string kmer; long long read; size_t f; };   // f = offset of its 3 (2w+1) features
 
 struct TxOut {
     std::string json;                                  // all records of the transcript
     std::vector<std::array<long long, 4>> recs;        // pos, offset in json, length, n_reads
-    bool done = false;
+    bool wanted = false, logged = false;
     int rc = 0;
     std::string err;
 };
+
+// One transcript: combine -> runs of consecutive positions -> +-w window -> DRACH centre -> group by position
+// (parallel_preprocess_tx :328-396 + preprocess_tx :399-488 + filter_events :51-168)
+void preprocess_transcript(const char *base, size_t file_size, const std::string &tx, const std::vector<IdxRun> &idx,
+                           const std::vector<uint32_t> &rows, int readcount_min, int readcount_max, int min_segment_count,
+                           int w, int compress, TxOut &o)
+{
+    // data_dict: read_index -> combined events, insertion order of first appearance (a repeated
+    // read_index overwrites its entry but keeps its place, like a Python dict)
+    std::vector<long long> read_order;
+    std::unordered_map<long long, std::vector<Pos>> by_read;
+    int readcount = 0;
+    for (uint32_t ri : rows) {
+        const IdxRun &r = idx[ri];
+        if (r.start < 0 || r.end > (int64_t)file_size || r.start > r.end) { o.rc = M6A_IO_EFORMAT; o.err = "index row outside eventalign.txt"; return; }
+        std::vector<Pos> ps;
+        if (!combine_read(base + r.start, base + r.end, ps)) { o.rc = M6A_IO_EFORMAT; o.err = "malformed eventalign line for " + tx; return; }
+        if (ps.size() > 1) {                          // `if data.size > 1`
+            if (!by_read.count(r.read)) read_order.push_back(r.read);
+            by_read[r.read] = std::move(ps);
+        }
+        if (++readcount > readcount_max) break;      // (sic) up to readcount_max + 1 reads
+    }
+    if (readcount < readcount_min) return;
+    o.wanted = true;
+    const size_t W = (size_t)w, NF = 3 * (2 * W + 1);
+    std::vector<SiteRow> sites;
+    std::vector<double> feat;
+    for (long long rd : read_order) {
+        const std::vector<Pos> &ps = by_read[rd];     // sorted by position already
+        size_t a = 0;
+        while (a < ps.size()) {                       // runs of consecutive positions (partition_into_continuous_positions)
+            size_t b = a + 1;
+            while (b < ps.size() && ps[b].position == ps[b - 1].position + 1) ++b;
+            if (b - a >= 2 * W + 1) {
+                for (size_t i = a + W; i + W < b; i++) {
+                    if (!drach18().count(ps[i].kmer)) continue;
+                    SiteRow sr;
+                    sr.pos = ps[i].position + 2;      // centre of the 5-mer
+                    sr.kmer = ps[i - W].kmer;         // combine_sequence: first 5-mer + the last base of every later one
+                    for (size_t k = i - W + 1; k <= i + W; k++) sr.kmer += ps[k].kmer.back();
+                    sr.f = feat.size();
+                    for (size_t k = i - W; k <= i + W; k++) {      // roll(): previous ..., centre, next ...; [dwell, sd, mean] each
+                        feat.push_back(ps[k].dwell); feat.push_back(ps[k].sd); feat.push_back(ps[k].mean);
+                    }
+                    sr.read = rd;
+                    sites.push_back(std::move(sr));
+                }
+            }
+            a = b;
+        }
+    }
+    if (sites.empty()) return;                        // preprocess_tx returns before its log line (dataprep_utils.py:415,431)
+    o.logged = true;
+    // reference: np.argsort(positions) (unstable, machine-dependent order inside a position);
+    // here: stable, i.e. reads stay in index order inside a position
+    std::stable_sort(sites.begin(), sites.end(), [](const SiteRow &x, const SiteRow &y) { return x.pos < y.pos; });
+    size_t i = 0;
+    while (i < sites.size()) {
+        size_t j = i;
+        while (j < sites.size() && sites[j].pos == sites[i].pos) {
+            if (sites[j].kmer != sites[i].kmer) { o.rc = M6A_IO_EFORMAT; o.err = "reads disagree on the sequence at " + tx + ":" + std::to_string(sites[i].pos); return; }
+            ++j;
+        }
+        if ((int)(j - i) >= min_segment_count) {
+            const size_t start = o.json.size();
+            o.json += "{\"" + tx + "\":{\"" + std::to_string(sites[i].pos) + "\":{\"" + sites[i].kmer + "\":[";
+            for (size_t k = i; k < j; k++) {
+                o.json += k == i ? "[" : ",[";
+                for (size_t c = 0; c < NF; c++) {
+                    const double v = feat[sites[k].f + c];
+                    py_repr(compress ? np_round(v, 1000.0) : v, o.json);
+                    o.json += ',';
+                }
+                py_repr((double)sites[k].read, o.json);
+                o.json += ']';
+            }
+            o.json += "]}}}\n";
+            o.recs.push_back({sites[i].pos, (long long)start, (long long)(o.json.size() - start), (long long)(j - i)});
+        }
+        i = j;
+    }
+}
+
+// One byte range of eventalign.txt (whole lines): its contiguous (contig, read_index) runs; contig names are interned per
+// range first (views into the mapping), merged into the file-wide table afterwards
+struct LocalRun { uint32_t tx; long long read; int64_t start, end; };
+struct IndexChunk {
+    std::vector<LocalRun> runs;
+    std::vector<std::string_view> names;            // local id -> name, in order of first appearance in the range
+    std::vector<uint32_t> global;                   // local id -> file-wide id (filled by the sequential merge)
+    size_t out = 0;                                 // where this range's rows start in the file-wide index
+    bool drop_first = false;                        // its first run continues the previous range's last run
+    std::string text;                               // its rows of eventalign.index
+    int rc = 0;
+    int64_t bad_at = -1;
+};
+
+void index_range(const char *base, const char *p, const char *end, IndexChunk &out)
+{
+    std::unordered_map<std::string_view, uint32_t> ids;
+    while (p < end) {
+        const char *le = (const char *)memchr(p, '\n', (size_t)(end - p));
+        const char *next = le ? le + 1 : end;
+        const char *t1 = (const char *)memchr(p, '\t', (size_t)(next - p));
+        if (!t1) { p = next; continue; }
+        const char *q = t1;
+        for (int k = 0; k < 2 && q; k++) q = (const char *)memchr(q + 1, '\t', (size_t)(next - q - 1));
+        if (!q) { out.rc = M6A_IO_EFORMAT; out.bad_at = (int64_t)(p - base); return; }
+        const long long read = atoll(q + 1);
+        const std::string_view name(p, (size_t)(t1 - p));
+        if (out.runs.empty() || out.runs.back().read != read || out.names[out.runs.back().tx] != name) {
+            uint32_t id;
+            if (!out.runs.empty() && out.names[out.runs.back().tx] == name) id = out.runs.back().tx;
+            else {
+                auto it = ids.find(name);
+                if (it == ids.end()) { id = (uint32_t)out.names.size(); ids.emplace(name, id); out.names.push_back(name); }
+                else id = it->second;
+            }
+            out.runs.push_back(LocalRun{id, read, (int64_t)(p - base), (int64_t)(p - base)});
+        }
+        out.runs.back().end = (int64_t)(next - base);
+        p = next;
+    }
+}
+
+inline void append_ll(std::string &s, long long v)
+{
+    char b[24];
+    auto r = std::to_chars(b, b + sizeof b, v);
+    s.append(b, (size_t)(r.ptr - b));
+}
+
+template <class F>
+void on_threads(int nw, int n_items, F &&f)
+{
+    std::atomic<int> next{0};
+    auto worker = [&]() { for (int k; (k = next.fetch_add(1)) < n_items;) f(k); };
+    std::vector<std::thread> th;
+    for (int t = 1; t < std::min(nw, n_items); t++) th.emplace_back(worker);
+    worker();
+    for (auto &t : th) t.join();
+}
 
 }  // namespace
 
@@ -976,15 +1128,31 @@ extern "C" int m6a_io_dataprep(const char *eventalign_path, const char *out_dir,
                                int compress, int skip_index)
 {
     if (!eventalign_path || !out_dir) return fail(M6A_IO_EINVAL, "null argument");
-    if (n_neighbors != 1) return fail(M6A_IO_EINVAL, "only n_neighbors = 1 is supported (the shipped models use 1)");
+    if (n_neighbors < 1 || n_neighbors > 16) return fail(M6A_IO_EINVAL, "n_neighbors must be 1..16");
+    PhaseTrace trace;
     Mapped ev;
-    int rc = ev.open(eventalign_path);
+    const char *pm = getenv("M6A_IO_POPULATE_MAX_MB");
+    int rc = ev.open(eventalign_path, (size_t)(pm ? atoll(pm) : 2048) << 20);
     if (rc) return rc;
     const char *base = ev.p, *end = ev.p + ev.n;
     const std::string dir(out_dir);
+    trace.mark("dataprep: map");
 
-    // ---- index (parallel_index, dataprep_utils.py:187-266): one row per contiguous (contig, read_index) run
-    std::vector<IdxRow> idx;
+    // ---- index (parallel_index, dataprep_utils.py:187-266): one row per contiguous (contig, read_index) run.
+    // Byte ranges of whole lines on all threads; the runs that meet at a range boundary are stitched afterwards.
+    std::vector<IdxRun> idx;
+    std::vector<std::string> tx_names;                 // id -> name, ids in order of first appearance
+    std::unordered_map<std::string, uint32_t> tx_ids;
+    auto intern = [&](const char *p, size_t n) -> uint32_t {
+        if (!idx.empty() && tx_names[idx.back().tx].size() == n && memcmp(tx_names[idx.back().tx].data(), p, n) == 0) return idx.back().tx;
+        std::string key(p, n);
+        auto it = tx_ids.find(key);
+        if (it != tx_ids.end()) return it->second;
+        const uint32_t id = (uint32_t)tx_names.size();
+        tx_ids.emplace(key, id);
+        tx_names.push_back(std::move(key));
+        return id;
+    };
     const std::string idx_path = dir + "/eventalign.index";
     if (skip_index) {
         FILE *f = fopen(idx_path.c_str(), "r");
@@ -995,168 +1163,186 @@ extern "C" int m6a_io_dataprep(const char *eventalign_path, const char *out_dir,
             if (first) { first = false; continue; }
             char *c = strrchr(line, ',');
             if (!c) continue;
-            IdxRow r;
+            IdxRun r;
             r.end = atoll(c + 1); *c = 0;
-            c = strrchr(line, ','); r.start = atoll(c + 1); *c = 0;
-            c = strrchr(line, ','); r.read = atoll(c + 1); *c = 0;
-            r.tx = line;
-            idx.push_back(std::move(r));
+            c = strrchr(line, ','); if (!c) continue; r.start = atoll(c + 1); *c = 0;
+            c = strrchr(line, ','); if (!c) continue; r.read = atoll(c + 1); *c = 0;
+            r.tx = intern(line, strlen(line));
+            idx.push_back(r);
         }
         fclose(f);
     } else {
-        const char *p = (const char *)memchr(base, '\n', ev.n);
-        if (!p) return fail(M6A_IO_EFORMAT, "%s: no header line", eventalign_path);
-        ++p;
-        while (p < end) {
-            const char *le = (const char *)memchr(p, '\n', (size_t)(end - p));
-            const char *next = le ? le + 1 : end;
-            const char *t1 = (const char *)memchr(p, '\t', (size_t)(next - p));
-            if (!t1) { p = next; continue; }
-            const char *q = t1;
-            for (int k = 0; k < 2 && q; k++) q = (const char *)memchr(q + 1, '\t', (size_t)(next - q - 1));
-            if (!q) return fail(M6A_IO_EFORMAT, "%s: short line at byte %lld", eventalign_path, (long long)(p - base));
-            const long long read = atoll(q + 1);
-            if (idx.empty() || idx.back().read != read || idx.back().tx.size() != (size_t)(t1 - p) ||
-                memcmp(idx.back().tx.data(), p, (size_t)(t1 - p)) != 0)
-                idx.push_back(IdxRow{std::string(p, t1), read, (int64_t)(p - base), (int64_t)(p - base)});
-            idx.back().end = (int64_t)(next - base);
-            p = next;
+        const char *body = (const char *)memchr(base, '\n', ev.n);
+        if (!body) return fail(M6A_IO_EFORMAT, "%s: no header line", eventalign_path);
+        ++body;
+        const size_t n_body = (size_t)(end - body);
+        const char *rk = getenv("M6A_IO_INDEX_RANGE_KB");                                      // tests: small ranges on small files
+        const size_t min_range = std::max<size_t>(1, (size_t)(rk ? atoll(rk) : 8192)) << 10;  // a range is at least 8 MB
+        const int nw = n_workers(n_threads, (int64_t)std::max<size_t>(1, n_body / min_range));
+        const int NC = (int)std::max<size_t>(1, std::min<size_t>((size_t)nw * 4, n_body / min_range + 1));
+        std::vector<const char *> cut((size_t)NC + 1, end);
+        cut[0] = body;
+        for (int k = 1; k < NC; k++) {
+            const char *p = body + n_body / (size_t)NC * (size_t)k;
+            if (p < cut[(size_t)k - 1]) p = cut[(size_t)k - 1];
+            const char *nl = p < end ? (const char *)memchr(p, '\n', (size_t)(end - p)) : nullptr;
+            cut[(size_t)k] = nl ? nl + 1 : end;
         }
+        std::vector<IndexChunk> chunks((size_t)NC);
+        on_threads(nw, NC, [&](int k) { index_range(base, cut[(size_t)k], cut[(size_t)k + 1], chunks[(size_t)k]); });
+        trace.mark("dataprep: index ranges");
+        for (const auto &c : chunks)
+            if (c.rc) return fail(c.rc, "%s: short line at byte %lld", eventalign_path, (long long)c.bad_at);
+        // sequential, per RANGE (not per run): contig names into the file-wide table in order of first appearance; a first
+        // run that continues the previous range's last one (same contig, same read, adjacent bytes) is folded into it
+        size_t total = 0;
+        IndexChunk *open_c = nullptr;                                  // the range holding the file's last run so far
+        for (auto &c : chunks) {
+            c.global.resize(c.names.size());
+            for (size_t i = 0; i < c.names.size(); i++) {
+                auto it = tx_ids.find(std::string(c.names[i]));
+                if (it == tx_ids.end()) {
+                    const uint32_t id = (uint32_t)tx_names.size();
+                    tx_names.emplace_back(c.names[i]);
+                    tx_ids.emplace(tx_names.back(), id);
+                    c.global[i] = id;
+                } else c.global[i] = it->second;
+            }
+            if (!c.runs.empty() && open_c) {
+                LocalRun &last = open_c->runs.back();
+                const LocalRun &first = c.runs.front();
+                if (last.end == first.start && last.read == first.read && open_c->global[last.tx] == c.global[first.tx]) {
+                    last.end = first.end;
+                    c.drop_first = true;
+                }
+            }
+            c.out = total;
+            total += c.runs.size() - (c.drop_first ? 1 : 0);
+            if (c.runs.size() > (c.drop_first ? 1u : 0u)) open_c = &c;
+        }
+        if (total > 0xffffffffull) return fail(M6A_IO_EINVAL, "more than 2^32 index rows");
+        idx.resize(total);
+        // every range fills its rows of the index and formats their text
+        on_threads(nw, NC, [&](int k) {
+            IndexChunk &c = chunks[(size_t)k];
+            size_t o = c.out;
+            c.text.reserve(c.runs.size() * 48);
+            for (size_t i = c.drop_first ? 1 : 0; i < c.runs.size(); i++) {
+                const LocalRun &r = c.runs[i];
+                const uint32_t id = c.global[r.tx];
+                idx[o++] = IdxRun{id, r.read, r.start, r.end};
+                c.text += tx_names[id];
+                c.text += ',';
+                append_ll(c.text, r.read);
+                c.text += ',';
+                append_ll(c.text, (long long)r.start);
+                c.text += ',';
+                append_ll(c.text, (long long)r.end);
+                c.text += '\n';
+            }
+            std::vector<LocalRun>().swap(c.runs);
+        });
         FILE *f = fopen(idx_path.c_str(), "w");
         if (!f) return fail(M6A_IO_EIO, "cannot write %s", idx_path.c_str());
         fputs("transcript_id,read_index,pos_start,pos_end\n", f);
-        for (const auto &r : idx) fprintf(f, "%s,%lld,%lld,%lld\n", r.tx.c_str(), r.read, (long long)r.start, (long long)r.end);
+        for (auto &c : chunks) {
+            if (!c.text.empty() && fwrite(c.text.data(), 1, c.text.size(), f) != c.text.size()) { fclose(f); return fail(M6A_IO_EIO, "cannot write %s", idx_path.c_str()); }
+            std::string().swap(c.text);
+        }
         if (fclose(f) != 0) return fail(M6A_IO_EIO, "cannot close %s", idx_path.c_str());
     }
+    trace.mark("dataprep: index stitched + written");
+    if (ev.p && ev.n) (void)madvise((void *)ev.p, ev.n, MADV_NORMAL);       // the transcript pass jumps between a read's runs
 
-    // ---- transcripts in order of first appearance, with their index rows in file order
-    std::vector<std::string> tx_order;
-    std::unordered_map<std::string, std::vector<size_t>> tx_rows;
-    for (size_t i = 0; i < idx.size(); i++) {
-        auto it = tx_rows.find(idx[i].tx);
-        if (it == tx_rows.end()) { tx_order.push_back(idx[i].tx); it = tx_rows.emplace(idx[i].tx, std::vector<size_t>()).first; }
-        it->second.push_back(i);
+    // ---- transcripts in order of first appearance (= id order), with their index rows in file order
+    const int64_t NT = (int64_t)tx_names.size();
+    std::vector<std::vector<uint32_t>> tx_rows((size_t)NT);
+    if (idx.size() > 0xffffffffull) return fail(M6A_IO_EINVAL, "more than 2^32 index rows");
+    {
+        std::vector<uint32_t> cnt((size_t)NT, 0);
+        for (const IdxRun &r : idx) cnt[r.tx]++;
+        for (int64_t t = 0; t < NT; t++) tx_rows[(size_t)t].reserve(cnt[(size_t)t]);
     }
+    for (size_t i = 0; i < idx.size(); i++) tx_rows[idx[i].tx].push_back((uint32_t)i);
 
-    // ---- per transcript: combine -> window -> DRACH filter -> group by position (parallel_preprocess_tx + preprocess_tx)
-    const int64_t NT = (int64_t)tx_order.size();
-    std::vector<TxOut> outs((size_t)NT);
-    std::vector<char> wanted((size_t)NT, 0), logged((size_t)NT, 0);
-    auto do_tx = [&](int64_t ti) {
-        TxOut &o = outs[(size_t)ti];
-        const std::string &tx = tx_order[(size_t)ti];
-        const auto &rows = tx_rows[tx];
-        // data_dict: read_index -> combined events, insertion order of first appearance (a repeated
-        // read_index overwrites its entry but keeps its place, like a Python dict)
-        std::vector<long long> read_order;
-        std::unordered_map<long long, std::vector<Pos>> by_read;
-        int readcount = 0;
-        for (size_t ri : rows) {
-            const IdxRow &r = idx[ri];
-            if (r.start < 0 || r.end > (int64_t)ev.n || r.start > r.end) { o.rc = M6A_IO_EFORMAT; o.err = "index row outside eventalign.txt"; return; }
-            std::vector<Pos> ps;
-            if (!combine_read(base + r.start, base + r.end, ps)) { o.rc = M6A_IO_EFORMAT; o.err = "malformed eventalign line for " + tx; return; }
-            if (ps.size() > 1) {                          // `if data.size > 1`
-                if (!by_read.count(r.read)) read_order.push_back(r.read);
-                by_read[r.read] = std::move(ps);
+    // ---- per transcript on all threads, written in transcript order AS SOON AS every earlier one is written: memory holds a
+    // bounded window of finished transcripts, not the whole data.json
+    FILE *fj = fopen((dir + "/data.json").c_str(), "w"), *fi = fopen((dir + "/data.info").c_str(), "w"), *fl = fopen((dir + "/data.log").c_str(), "w");
+    if (!fj || !fi || !fl) { if (fj) fclose(fj); if (fi) fclose(fi); if (fl) fclose(fl); return fail(M6A_IO_EIO, "cannot write into %s", out_dir); }
+    std::vector<char> jbuf(4 << 20), ibuf(1 << 20);
+    setvbuf(fj, jbuf.data(), _IOFBF, jbuf.size());
+    setvbuf(fi, ibuf.data(), _IOFBF, ibuf.size());
+    fputs("transcript_id,transcript_position,start,end,n_reads\n", fi);
+    const int nw = n_workers(n_threads, NT);
+    const int64_t window = std::max<int64_t>(64, (int64_t)nw * 8);
+    std::vector<std::unique_ptr<TxOut>> outs((size_t)NT);
+    std::mutex mu;
+    std::condition_variable cv;
+    std::atomic<int64_t> next{0};
+    int64_t written = 0;                               // transcripts [0, written) are on disk (guarded by mu)
+    bool writing = false, failed = false;
+    int fail_rc = 0;
+    std::string fail_msg;
+    long long off = 0;                                 // bytes of data.json written so far (writer only)
+    size_t peak_pending = 0;
+    auto write_one = [&](int64_t t, const TxOut &o) {
+        if (!o.wanted) return;
+        if (!o.json.empty()) fwrite(o.json.data(), 1, o.json.size(), fj);
+        for (const auto &r : o.recs)
+            fprintf(fi, "%s,%lld,%lld,%lld,%lld\n", tx_names[(size_t)t].c_str(), r[0], off + r[1], off + r[1] + r[2], r[3]);
+        off += (long long)o.json.size();
+        // logged like the reference: only transcripts that yielded at least one DRACH window (dataprep_utils.py:415,431,472)
+        if (o.logged) fprintf(fl, "%s: Data preparation ... Done.\n", tx_names[(size_t)t].c_str());
+    };
+    auto worker = [&]() {
+        for (;;) {
+            const int64_t t = next.fetch_add(1);
+            if (t >= NT) break;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return failed || t < written + window; });
+                if (failed) break;
             }
-            if (++readcount > readcount_max) break;      // (sic) up to readcount_max + 1 reads
-        }
-        if (readcount < readcount_min) return;
-        wanted[(size_t)ti] = 1;
-        std::vector<SiteRow> sites;
-        for (long long rd : read_order) {
-            const std::vector<Pos> &ps = by_read[rd];     // sorted by position already
-            size_t a = 0;
-            while (a < ps.size()) {                       // runs of consecutive positions
-                size_t b = a + 1;
-                while (b < ps.size() && ps[b].position == ps[b - 1].position + 1) ++b;
-                if (b - a >= 3) {
-                    for (size_t i = a + 1; i + 1 < b; i++) {
-                        if (!drach18().count(ps[i].kmer)) continue;
-                        SiteRow sr;
-                        sr.pos = ps[i].position + 2;      // centre of the 5-mer
-                        sr.kmer7 = ps[i - 1].kmer;
-                        sr.kmer7 += ps[i].kmer.back();
-                        sr.kmer7 += ps[i + 1].kmer.back();
-                        for (int w = 0; w < 3; w++) {
-                            const Pos &q = ps[i - 1 + (size_t)w];
-                            sr.f[3 * w] = q.dwell; sr.f[3 * w + 1] = q.sd; sr.f[3 * w + 2] = q.mean;
-                        }
-                        sr.read = rd;
-                        sites.push_back(std::move(sr));
-                    }
-                }
-                a = b;
+            std::unique_ptr<TxOut> o(new TxOut);
+            preprocess_transcript(base, ev.n, tx_names[(size_t)t], idx, tx_rows[(size_t)t], readcount_min, readcount_max,
+                                  min_segment_count, n_neighbors, compress, *o);
+            std::vector<uint32_t>().swap(tx_rows[(size_t)t]);
+            std::unique_lock<std::mutex> lk(mu);
+            if (o->rc && !failed) { failed = true; fail_rc = o->rc; fail_msg = o->err; cv.notify_all(); }
+            outs[(size_t)t] = std::move(o);
+            if (writing || failed) continue;
+            // this thread becomes the writer for as long as the next transcript in line is finished
+            writing = true;
+            while (!failed && written < NT && outs[(size_t)written]) {
+                std::vector<std::unique_ptr<TxOut>> batch;
+                const int64_t first = written;
+                int64_t k = written;
+                while (k < NT && outs[(size_t)k]) batch.push_back(std::move(outs[(size_t)k++]));
+                size_t pending = 0;
+                for (int64_t q = k; q < std::min(NT, first + window); q++) if (outs[(size_t)q]) pending += outs[(size_t)q]->json.size();
+                peak_pending = std::max(peak_pending, pending);
+                lk.unlock();
+                for (size_t b = 0; b < batch.size(); b++) write_one(first + (int64_t)b, *batch[b]);
+                batch.clear();
+                lk.lock();
+                written = k;
+                cv.notify_all();
             }
-        }
-        if (sites.empty()) return;                        // preprocess_tx returns before its log line (dataprep_utils.py:415,431)
-        logged[(size_t)ti] = 1;
-        // reference: np.argsort(positions) (unstable, machine-dependent order inside a position);
-        // here: stable, i.e. reads stay in index order inside a position
-        std::stable_sort(sites.begin(), sites.end(), [](const SiteRow &x, const SiteRow &y) { return x.pos < y.pos; });
-        size_t i = 0;
-        while (i < sites.size()) {
-            size_t j = i;
-            while (j < sites.size() && sites[j].pos == sites[i].pos) {
-                if (sites[j].kmer7 != sites[i].kmer7) { o.rc = M6A_IO_EFORMAT; o.err = "reads disagree on the sequence at " + tx + ":" + std::to_string(sites[i].pos); return; }
-                ++j;
-            }
-            if ((int)(j - i) >= min_segment_count) {
-                const size_t start = o.json.size();
-                o.json += "{\"" + tx + "\":{\"" + std::to_string(sites[i].pos) + "\":{\"" + sites[i].kmer7 + "\":[";
-                for (size_t k = i; k < j; k++) {
-                    o.json += k == i ? "[" : ",[";
-                    for (int c = 0; c < 9; c++) {
-                        py_repr(compress ? np_round(sites[k].f[c], 1000.0) : sites[k].f[c], o.json);
-                        o.json += ',';
-                    }
-                    py_repr((double)sites[k].read, o.json);
-                    o.json += ']';
-                }
-                o.json += "]}}}\n";
-                o.recs.push_back({sites[i].pos, (long long)start, (long long)(o.json.size() - start), (long long)(j - i)});
-            }
-            i = j;
+            writing = false;
         }
     };
     {
-        const int nw = n_workers(n_threads, NT);
         std::vector<std::thread> th;
-        std::vector<int64_t> next(1, 0);
-        std::mutex mu;
-        auto worker = [&]() {
-            for (;;) {
-                int64_t t;
-                { std::lock_guard<std::mutex> g(mu); t = next[0]++; }
-                if (t >= NT) break;
-                do_tx(t);
-            }
-        };
         for (int w = 1; w < nw; w++) th.emplace_back(worker);
         worker();
         for (auto &t : th) t.join();
     }
-    for (int64_t t = 0; t < NT; t++)
-        if (outs[(size_t)t].rc) return fail(outs[(size_t)t].rc, "%s", outs[(size_t)t].err.c_str());
-
-    // ---- write data.json / data.info / data.log in transcript order
-    FILE *fj = fopen((dir + "/data.json").c_str(), "w"), *fi = fopen((dir + "/data.info").c_str(), "w"), *fl = fopen((dir + "/data.log").c_str(), "w");
-    if (!fj || !fi || !fl) { if (fj) fclose(fj); if (fi) fclose(fi); if (fl) fclose(fl); return fail(M6A_IO_EIO, "cannot write into %s", out_dir); }
-    fputs("transcript_id,transcript_position,start,end,n_reads\n", fi);
-    long long off = 0;
-    for (int64_t t = 0; t < NT; t++) {
-        const TxOut &o = outs[(size_t)t];
-        if (!wanted[(size_t)t]) continue;
-        if (!o.json.empty()) fwrite(o.json.data(), 1, o.json.size(), fj);
-        for (const auto &r : o.recs)
-            fprintf(fi, "%s,%lld,%lld,%lld,%lld\n", tx_order[(size_t)t].c_str(), r[0], off + r[1], off + r[1] + r[2], r[3]);
-        off += (long long)o.json.size();
-        // logged like the reference: only transcripts that yielded at least one DRACH window (dataprep_utils.py:415,431,472)
-        if (logged[(size_t)t]) fprintf(fl, "%s: Data preparation ... Done.\n", tx_order[(size_t)t].c_str());
-    }
     int bad = 0;
     bad |= fclose(fj); bad |= fclose(fi); bad |= fclose(fl);
+    if (failed) return fail(fail_rc, "%s", fail_msg.c_str());
+    if (written != NT) return fail(M6A_IO_EIO, "internal: %lld of %lld transcripts written", (long long)written, (long long)NT);
     if (bad) return fail(M6A_IO_EIO, "cannot close outputs in %s", out_dir);
+    trace.mark("dataprep: transcripts");
+    if (trace.on) fprintf(stderr, "m6a_io: dataprep peak of finished-but-unwritten json: %.1f MB (window %lld transcripts)\n", peak_pending / 1e6, (long long)window);
     return M6A_IO_OK;
 }

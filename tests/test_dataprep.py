@@ -109,6 +109,82 @@ def test_dataprep_options_and_errors(eventalign, tmp_path):
     with pytest.raises(_io.M6AIOError):
         _io.dataprep(str(tmp_path / "missing.txt"), out)
     with pytest.raises(_io.M6AIOError):
-        _io.dataprep(eventalign, out, n_neighbors=2)
+        _io.dataprep(eventalign, out, n_neighbors=0)
+    _io.dataprep(eventalign, out, n_neighbors=2)                # the bundled file only holds 3-position runs: no 5-position window
+    assert open(os.path.join(out, "data.info")).read().splitlines() == ["transcript_id,transcript_position,start,end,n_reads"]
     with pytest.raises(_io.M6AIOError):
         _io.dataprep(eventalign, str(tmp_path / "fresh"), skip_index=True)            # no index to reuse
+
+
+def unpack(tmp_path, sub):
+    p = tmp_path / (sub + "_eventalign.txt")
+    p.write_bytes(gzip.open(os.path.join(GOLD, sub, "eventalign.txt.gz"), "rb").read())
+    return str(p)
+
+
+def test_parallel_index_is_stitched_at_range_boundaries(eventalign, tmp_path, monkeypatch):
+    """The index is built over byte ranges on all threads and the runs that meet at a boundary are stitched
+    (dataprep_utils.py:187-266 walks the file once).  The bundled file is smaller than one default range (8 MB), so the
+    test shrinks the ranges: ~130 ranges of 16 KB, boundaries in the middle of reads -- same bytes as the reference's index,
+    same data.json / data.info as the one-range run."""
+    one = str(tmp_path / "one")
+    _io.dataprep(eventalign, one, n_threads=1, readcount_min=1, readcount_max=1000, min_segment_count=20)
+    monkeypatch.setenv("M6A_IO_INDEX_RANGE_KB", "16")
+    for threads in (1, 3, 8):
+        out = str(tmp_path / ("t%d" % threads))
+        _io.dataprep(eventalign, out, n_threads=threads, readcount_min=1, readcount_max=1000, min_segment_count=20)
+        assert open(os.path.join(out, "eventalign.index"), "rb").read() == open(os.path.join(REF, "eventalign.index"), "rb").read()
+        for fn in ("data.json", "data.info", "data.log"):
+            assert open(os.path.join(out, fn), "rb").read() == open(os.path.join(one, fn), "rb").read(), (threads, fn)
+
+
+@pytest.mark.parametrize("nn", [1, 2, 3])
+def test_n_neighbors_against_the_reference(tmp_path, nn):
+    """--n_neighbors (m6anet/scripts/dataprep.py:45-47): windows of 2 nn + 1 consecutive positions, 3 (2 nn + 1) features and a
+    (5 + 2 nn)-mer per row (roll / partition_into_continuous_positions / combine_sequence, dataprep_utils.py:51-67,117-147,
+    170-183), against what the reference makes of tests/golden/dataprep_synthetic/eventalign.txt.gz (long runs with gaps,
+    repeated events per position, mismatching model k-mers; captured by make_golden.py)."""
+    ev = unpack(tmp_path, "dataprep_synthetic")
+    out = str(tmp_path / "o")
+    _io.dataprep(ev, out, n_threads=2, readcount_min=1, readcount_max=1000, min_segment_count=5, n_neighbors=nn)
+    syn = os.path.join(GOLD, "dataprep_synthetic")
+    assert open(os.path.join(out, "eventalign.index"), "rb").read() == open(os.path.join(syn, "eventalign.index"), "rb").read()
+    got, got_order = records(open(os.path.join(out, "data.json")).read())
+    want, want_order = records(gzip.open(os.path.join(syn, "nn%d.data.json.gz" % nn), "rt").read())
+    assert got_order == want_order and len(want) > 3
+    for key in want:
+        assert got[key][0] == want[key][0] and len(want[key][0]) == 5 + 2 * nn
+        assert got[key][1].shape[1] == 3 * (2 * nn + 1) + 1
+        assert np.array_equal(sorted_rows(got[key][1]), sorted_rows(want[key][1])), key
+    info = [l.split(",") for l in open(os.path.join(out, "data.info")).read().splitlines()[1:]]
+    ref_info = [l.split(",") for l in open(os.path.join(syn, "nn%d.data.info" % nn)).read().splitlines()[1:]]
+    assert [(r[0], r[1], r[4]) for r in info] == [(r[0], r[1], r[4]) for r in ref_info]
+
+
+def test_read_with_non_contiguous_lines_documented_divergence(tmp_path):
+    """nanopolish writes a read's events as one contiguous block; tests/golden/dataprep_noncontiguous holds the first 900
+    events of the bundled file with four lines of read 82387 moved behind read 82388's block.  The reference keys its index
+    rows by (contig, read_index) and adds up the line lengths of ALL rows with that key (dataprep_utils.py:187-208), so it
+    writes ONE row for 82387 whose byte range has the right length but is no longer the read's lines -- it swallows the head of
+    82388's block, and every later row of the chunk is still right only because the lengths add up.  Here an index row is a
+    contiguous run: 82387 gets two rows, each exactly its own lines.  Pinned so the divergence stays deliberate."""
+    ev = unpack(tmp_path, "dataprep_noncontiguous")
+    nc = os.path.join(GOLD, "dataprep_noncontiguous")
+    out = str(tmp_path / "o")
+    _io.dataprep(ev, out, n_threads=2, readcount_min=1, readcount_max=1000, min_segment_count=1)
+    blob = open(ev, "rb").read()
+    ours = [l.split(",") for l in open(os.path.join(out, "eventalign.index")).read().splitlines()[1:]]
+    ref = [l.split(",") for l in open(os.path.join(nc, "reference_index_chunk1000000.csv")).read().splitlines()[1:]]
+    assert open(os.path.join(nc, "reference_index_chunk16.csv")).read() == open(os.path.join(nc, "reference_index_chunk1000000.csv")).read()
+
+    def reads_in(row):
+        return {l.split(b"\t")[3] for l in blob[int(row[2]):int(row[3])].splitlines()}
+
+    assert all(reads_in(r) == {r[1].encode()} for r in ours)                       # every row of ours is one read's lines
+    assert [r[1] for r in ours].count("82387") == 2 and [r[1] for r in ref].count("82387") == 1
+    assert len(ours) == len(ref) + 1
+    r87 = next(r for r in ref if r[1] == "82387")
+    assert reads_in(r87) == {b"82387", b"82388"}                                  # the reference's row covers foreign lines
+    assert sum(int(r[3]) - int(r[2]) for r in ours if r[1] == "82387") == int(r87[3]) - int(r87[2])
+    # every row that does not touch the two reads is the same in both
+    assert [r for r in ours if r[1] not in ("82387", "82388")] == [r for r in ref if r[1] not in ("82387", "82388")]
