@@ -82,8 +82,17 @@ int m6a_io_format_f16(double v, char *buf336);
  * the reference on pandas >= 1.3 (Kahan-compensated group sums, np.round half-to-even, floats
  * printed as Python repr) and the reference's n_processes = 1 record order (transcripts in index
  * order, positions ascending); inside a position reads stay in index order (the reference's order
- * there comes from an unstable argsort and is machine-dependent).  n_neighbors must be 1.
- * skip_index != 0 reads an existing eventalign.index instead of rebuilding it. */
+ * there comes from an unstable argsort and is machine-dependent).  n_neighbors = 1..16 flanking positions either side
+ * (m6anet/scripts/dataprep.py:45-47; roll / partition_into_continuous_positions, dataprep_utils.py:51-67,117-147): rows
+ * of 3 (2 n + 1) features and a (5 + 2 n)-mer; the shipped models take n_neighbors = 1.
+ * skip_index != 0 reads an existing eventalign.index instead of rebuilding it.
+ * Built for files of tens to hundreds of GB: the index is computed over byte ranges on all threads and stitched where a
+ * read crosses a range boundary (one index row = one contiguous (contig, read_index) run; the reference sums the line
+ * lengths of all rows of a key per chunk instead, which only differs for reads whose lines are not contiguous --
+ * tests/golden/dataprep_noncontiguous pins that divergence); files over 2 GB (M6A_IO_POPULATE_MAX_MB) are mapped
+ * lazily; a transcript's records are written as soon as every earlier transcript's are, so memory holds the index
+ * (32 B per read) and a bounded window of finished transcripts, never the whole data.json.  M6A_IO_TRACE=1 prints
+ * the phases. */
 int m6a_io_dataprep(const char *eventalign_path, const char *out_dir, int n_threads,
                     int readcount_min, int readcount_max, int min_segment_count, int n_neighbors,
                     int compress, int skip_index);

@@ -1222,32 +1222,44 @@ extern "C" int m6a_io_dataprep(const char *eventalign_path, const char *out_dir,
         }
         if (total > 0xffffffffull) return fail(M6A_IO_EINVAL, "more than 2^32 index rows");
         idx.resize(total);
-        // every range fills its rows of the index and formats their text
+        // every range fills its rows of the index; their text is formatted and written a batch of ranges at a time, so the
+        // index file (a tenth of the eventalign.txt) never sits in memory as a whole
         on_threads(nw, NC, [&](int k) {
             IndexChunk &c = chunks[(size_t)k];
             size_t o = c.out;
-            c.text.reserve(c.runs.size() * 48);
             for (size_t i = c.drop_first ? 1 : 0; i < c.runs.size(); i++) {
                 const LocalRun &r = c.runs[i];
-                const uint32_t id = c.global[r.tx];
-                idx[o++] = IdxRun{id, r.read, r.start, r.end};
-                c.text += tx_names[id];
-                c.text += ',';
-                append_ll(c.text, r.read);
-                c.text += ',';
-                append_ll(c.text, (long long)r.start);
-                c.text += ',';
-                append_ll(c.text, (long long)r.end);
-                c.text += '\n';
+                idx[o++] = IdxRun{c.global[r.tx], r.read, r.start, r.end};
             }
             std::vector<LocalRun>().swap(c.runs);
         });
         FILE *f = fopen(idx_path.c_str(), "w");
         if (!f) return fail(M6A_IO_EIO, "cannot write %s", idx_path.c_str());
         fputs("transcript_id,read_index,pos_start,pos_end\n", f);
-        for (auto &c : chunks) {
-            if (!c.text.empty() && fwrite(c.text.data(), 1, c.text.size(), f) != c.text.size()) { fclose(f); return fail(M6A_IO_EIO, "cannot write %s", idx_path.c_str()); }
-            std::string().swap(c.text);
+        const int batch = std::max(1, nw * 2);
+        for (int k0 = 0; k0 < NC; k0 += batch) {
+            const int k1 = std::min(NC, k0 + batch);
+            on_threads(nw, k1 - k0, [&](int kk) {
+                IndexChunk &c = chunks[(size_t)(k0 + kk)];
+                const size_t o1 = k0 + kk + 1 < NC ? chunks[(size_t)(k0 + kk) + 1].out : total;
+                c.text.reserve((o1 - c.out) * 48);
+                for (size_t o = c.out; o < o1; o++) {
+                    const IdxRun &r = idx[o];
+                    c.text += tx_names[r.tx];
+                    c.text += ',';
+                    append_ll(c.text, r.read);
+                    c.text += ',';
+                    append_ll(c.text, (long long)r.start);
+                    c.text += ',';
+                    append_ll(c.text, (long long)r.end);
+                    c.text += '\n';
+                }
+            });
+            for (int k = k0; k < k1; k++) {
+                IndexChunk &c = chunks[(size_t)k];
+                if (!c.text.empty() && fwrite(c.text.data(), 1, c.text.size(), f) != c.text.size()) { fclose(f); return fail(M6A_IO_EIO, "cannot write %s", idx_path.c_str()); }
+                std::string().swap(c.text);
+            }
         }
         if (fclose(f) != 0) return fail(M6A_IO_EIO, "cannot close %s", idx_path.c_str());
     }

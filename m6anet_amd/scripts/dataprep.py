@@ -20,7 +20,7 @@ def argparser():
     parser.add_argument("--skip_index", default=False, action="store_true",
                         help="skip indexing the eventalign nanopolish output (reuse eventalign.index).")
     parser.add_argument("--n_neighbors", default=NUM_NEIGHBORING_FEATURES, type=int,
-                        help="number of neighboring features to extract (only 1 is supported).")
+                        help="number of neighboring features to extract (1..16; the shipped models take 1).")
     parser.add_argument("--compress", default=False, action="store_true",
                         help="round down the features to 3 decimal places.")
     return parser
