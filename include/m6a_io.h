@@ -71,6 +71,23 @@ int m6a_io_write_csv_n(const m6a_sites *s, const char *out_dir, const float *rea
                        const float *site_prob, const double *mod_ratio, int write_header, int n_threads,
                        int64_t n_sites_limit);
 
+/* The same rows written by SEVERAL processes at once (`inference --gpus N`: every rank maps the same store and holds the
+ * results of its own shard, so nobody has to collect the job's read probabilities -- 4 B per read -- just to print them):
+ *   m6a_io_csv_shard_size    bytes the rows of sites [site_begin, site_end) take in each file (they are formatted and
+ *                            counted, not kept); read_prob / site_prob / mod_ratio hold THAT range's values only;
+ *   m6a_io_csv_shard_write   formats them again and pwrite()s them at site_offset / indiv_offset (= header + the sizes of
+ *                            all earlier shards, exchanged by the caller); the one rank with write_header != 0 also writes
+ *                            both header lines and sets the files to their final sizes site_total / indiv_total
+ *                            (< 0: leaves the size alone), which cuts whatever an earlier run left there;
+ *   m6a_io_csv_header_bytes  length of the header line of data.site_proba.csv (which = 0) / data.indiv_proba.csv (1).
+ * The bytes are those of m6a_io_write_csv over the whole job, whatever the cut (tests/test_host_io.py). */
+int m6a_io_csv_shard_size(const m6a_sites *s, const float *read_prob, const float *site_prob, const double *mod_ratio,
+                          int64_t site_begin, int64_t site_end, int n_threads, int64_t *site_bytes, int64_t *indiv_bytes);
+int m6a_io_csv_shard_write(const m6a_sites *s, const char *out_dir, const float *read_prob, const float *site_prob,
+                           const double *mod_ratio, int64_t site_begin, int64_t site_end, int n_threads,
+                           int64_t site_offset, int64_t indiv_offset, int write_header, int64_t site_total, int64_t indiv_total);
+int64_t m6a_io_csv_header_bytes(int which);
+
 /* The writers' '%.16f' (inference_utils.py:62,66) without printf: same characters as snprintf("%.16f", v) for every
  * double (exact 128-bit arithmetic for 0 <= v < 2, snprintf itself otherwise); buf336 holds >= 336 bytes, NUL-terminated;
  * returns the length.  Exported so the tests can pin it against printf. */

@@ -8,7 +8,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libm6a_io.so")
 SYMBOLS = ["m6a_io_last_error", "m6a_io_load_sites", "m6a_io_free", "m6a_io_n_sites", "m6a_io_n_reads",
            "m6a_io_n_replicates", "m6a_io_X", "m6a_io_site_kmers", "m6a_io_off", "m6a_io_tx_pos",
-           "m6a_io_read_ids", "m6a_io_read_rep", "m6a_io_tx_id", "m6a_io_kmer5", "m6a_io_write_csv", "m6a_io_write_csv_n", "m6a_io_format_f16",
+           "m6a_io_read_ids", "m6a_io_read_rep", "m6a_io_tx_id", "m6a_io_kmer5", "m6a_io_write_csv", "m6a_io_write_csv_n", "m6a_io_csv_shard_size", "m6a_io_csv_shard_write", "m6a_io_csv_header_bytes", "m6a_io_format_f16",
            "m6a_io_save_store", "m6a_io_open_store", "m6a_io_store_tag", "m6a_io_dataprep"]
 _lib = None
 
@@ -40,6 +40,10 @@ def load():
         getattr(L, name).restype = C.c_char_p
     L.m6a_io_write_csv.argtypes = [vp, C.c_char_p, vp, vp, vp, i32, i32]
     L.m6a_io_write_csv_n.argtypes = [vp, C.c_char_p, vp, vp, vp, i32, i32, i64]
+    L.m6a_io_csv_shard_size.argtypes = [vp, vp, vp, vp, i64, i64, i32, C.POINTER(i64), C.POINTER(i64)]
+    L.m6a_io_csv_shard_write.argtypes = [vp, C.c_char_p, vp, vp, vp, i64, i64, i32, i64, i64, i32, i64, i64]
+    L.m6a_io_csv_header_bytes.argtypes = [i32]
+    L.m6a_io_csv_header_bytes.restype = i64
     L.m6a_io_format_f16.argtypes = [C.c_double, C.c_char_p]
     L.m6a_io_format_f16.restype = i32
     L.m6a_io_save_store.argtypes = [vp, C.c_char_p, C.c_char_p]
@@ -49,6 +53,21 @@ def load():
     L.m6a_io_dataprep.argtypes = [C.c_char_p, C.c_char_p, i32, i32, i32, i32, i32, i32, i32]
     _lib = L
     return L
+
+
+def usable_cpus():
+    """CPUs this process may really use: the affinity mask cut by the cgroup quota (the GPU boxes lease 16 of 256)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(per) + 0.999)))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
 
 
 def _chk(rc):
@@ -119,6 +138,33 @@ class NativeSites:
         assert rp.size == self.X.shape[0] and sp.size == self.tx_pos.size == mr.size
         _chk(self._L.m6a_io_write_csv_n(self._h, os.fsencode(out_dir), rp.ctypes.data, sp.ctypes.data, mr.ctypes.data,
                                         1 if write_header else 0, int(n_threads), -1 if n_sites is None else int(n_sites)))
+
+    def _shard_args(self, a, b, read_prob, site_prob, mod_ratio):
+        rp = np.ascontiguousarray(read_prob, np.float32)
+        sp = np.ascontiguousarray(site_prob, np.float32)
+        mr = np.ascontiguousarray(mod_ratio, np.float64)
+        assert sp.size == mr.size == b - a and rp.size == int(self.off[b] - self.off[a])
+        return rp, sp, mr
+
+    def csv_shard_size(self, a, b, read_prob, site_prob, mod_ratio, n_threads=0):
+        """Bytes the rows of sites [a, b) take in (data.site_proba.csv, data.indiv_proba.csv); the arrays hold that range only."""
+        rp, sp, mr = self._shard_args(a, b, read_prob, site_prob, mod_ratio)
+        ns, ni = C.c_int64(), C.c_int64()
+        _chk(self._L.m6a_io_csv_shard_size(self._h, rp.ctypes.data, sp.ctypes.data, mr.ctypes.data, int(a), int(b), int(n_threads),
+                                           C.byref(ns), C.byref(ni)))
+        return ns.value, ni.value
+
+    def csv_shard_write(self, out_dir, a, b, read_prob, site_prob, mod_ratio, site_offset, indiv_offset, header_and_totals=None, n_threads=0):
+        """pwrite()s the rows of sites [a, b) at the given byte offsets; `header_and_totals` = (site_total, indiv_total) on the
+        one rank that also writes the header lines and sets the files' final sizes."""
+        rp, sp, mr = self._shard_args(a, b, read_prob, site_prob, mod_ratio)
+        st, it = header_and_totals if header_and_totals is not None else (-1, -1)
+        _chk(self._L.m6a_io_csv_shard_write(self._h, os.fsencode(out_dir), rp.ctypes.data, sp.ctypes.data, mr.ctypes.data, int(a), int(b),
+                                            int(n_threads), int(site_offset), int(indiv_offset), 1 if header_and_totals is not None else 0,
+                                            int(st), int(it)))
+
+    def csv_header_bytes(self):
+        return int(self._L.m6a_io_csv_header_bytes(0)), int(self._L.m6a_io_csv_header_bytes(1))
 
     def close(self):
         if getattr(self, "_h", None):

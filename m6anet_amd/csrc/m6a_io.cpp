@@ -14,6 +14,7 @@
 #include <clocale>
 #include <cstdlib>
 #include <locale.h>
+#include <cerrno>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -706,6 +707,120 @@ int m6a_io_write_csv(const m6a_sites *s, const char *out_dir, const float *read_
     return m6a_io_write_csv_n(s, out_dir, read_prob, site_prob, mod_ratio, write_header, n_threads, -1);
 }
 
+}  // extern "C"
+
+namespace {
+
+// The rows of sites [i0, i1) appended to `a` (data.site_proba.csv) and `b` (data.indiv_proba.csv).  read_prob / site_prob /
+// mod_ratio hold the values of sites [site_base, ...) and reads [read_base, ...): the whole job (bases 0) or one rank's shard.
+void format_rows(const m6a_sites *s, int64_t i0, int64_t i1, const float *read_prob, const float *site_prob, const double *mod_ratio,
+                 int64_t site_base, int64_t read_base, std::string &a, std::string &b)
+{
+    char buf[512];
+    std::string head;
+    for (int64_t i = i0; i < i1; i++) {
+        const int64_t r0 = s->vOff[i], r1 = s->vOff[i + 1];
+        // '%s,%d,%s,%.16f,%s,%.16f'  (inference_utils.py:62)
+        a += s->tx_ids[(size_t)i];
+        int k = 0;
+        buf[k++] = ',';
+        k += format_i64((long long)s->vPos[i], buf + k);
+        buf[k++] = ',';
+        k += format_i64((long long)(r1 - r0), buf + k);
+        buf[k++] = ',';
+        k += format_f16((double)site_prob[i - site_base], buf + k);
+        buf[k++] = ',';
+        a.append(buf, (size_t)k);
+        a += s->kmer5[(size_t)i];
+        k = 0;
+        buf[k++] = ',';
+        k += format_f16(mod_ratio[i - site_base], buf + k);
+        buf[k++] = '\n';
+        a.append(buf, (size_t)k);
+        // '%s,%d,%s,%.16f'  (inference_utils.py:66); read ids: str(float64), or "<int>_<rep>"
+        head.assign(s->tx_ids[(size_t)i]);
+        k = 0;
+        buf[k++] = ',';
+        k += format_i64((long long)s->vPos[i], buf + k);
+        buf[k++] = ',';
+        head.append(buf, (size_t)k);
+        for (int64_t r = r0; r < r1; r++) {
+            b += head;
+            k = 0;
+            const double id = s->vIds[r];
+            if (s->n_rep > 1) {
+                k += format_i64((long long)id, buf + k);
+                buf[k++] = '_';
+                k += format_i64((long long)s->vRep[r], buf + k);
+            } else if (id == std::floor(id) && std::fabs(id) < 1e15 && !std::signbit(id)) {
+                k += format_i64((long long)id, buf + k);                     // str(float64) of an integral value
+                buf[k++] = '.';
+                buf[k++] = '0';
+            } else {
+                format_py_float(id, b);
+            }
+            buf[k++] = ',';
+            k += format_f16((double)read_prob[r - read_base], buf + k);
+            buf[k++] = '\n';
+            b.append(buf, (size_t)k);
+        }
+    }
+}
+
+const char kSiteHeader[] = "transcript_id,transcript_position,n_reads,probability_modified,kmer,mod_ratio\n";
+const char kIndivHeader[] = "transcript_id,transcript_position,read_index,probability_modified\n";
+
+// Sites [A, B) formatted on all threads a round of chunks at a time (chunks of at most 2^20 reads bound the text held in
+// memory, ~64 MB per worker; at least 2^14 so tiny jobs do not spawn idle threads); `sink(site_text, indiv_text)` gets the
+// chunks in site order.
+template <class Sink>
+int format_site_range(const m6a_sites *s, int64_t A, int64_t B, const float *read_prob, const float *site_prob, const double *mod_ratio,
+                      int64_t site_base, int64_t read_base, int n_threads, Sink &&sink)
+{
+    const int nw = n_workers(n_threads, B - A);
+    const int64_t R = s->vOff[B] - s->vOff[A];
+    const int64_t chunk_reads = std::max<int64_t>(1 << 14, std::min<int64_t>(1 << 20, (R + nw - 1) / nw));
+    int64_t s_begin = A;
+    while (s_begin < B) {
+        std::vector<int64_t> cuts{s_begin};
+        for (int w = 0; w < nw && cuts.back() < B; w++) {
+            const int64_t target = std::min(s->vOff[B], s->vOff[cuts.back()] + chunk_reads);
+            int64_t e = std::upper_bound(s->vOff, s->vOff + s->nS + 1, target) - s->vOff - 1;
+            e = std::min<int64_t>(B, std::max<int64_t>(e, cuts.back() + 1));
+            cuts.push_back(e);
+        }
+        const int nc = (int)cuts.size() - 1;
+        std::vector<std::string> site_txt((size_t)nc), indiv_txt((size_t)nc);
+        auto work = [&](int w) {
+            const int64_t i0 = cuts[(size_t)w], i1 = cuts[(size_t)w + 1];
+            site_txt[(size_t)w].reserve((size_t)(i1 - i0) * 96);
+            indiv_txt[(size_t)w].reserve((size_t)(s->vOff[i1] - s->vOff[i0]) * 64);
+            format_rows(s, i0, i1, read_prob, site_prob, mod_ratio, site_base, read_base, site_txt[(size_t)w], indiv_txt[(size_t)w]);
+        };
+        std::vector<std::thread> th;
+        for (int w = 1; w < nc; w++) th.emplace_back(work, w);
+        work(0);
+        for (auto &t : th) t.join();
+        for (int w = 0; w < nc; w++) {
+            const int rc = sink(site_txt[(size_t)w], indiv_txt[(size_t)w]);
+            if (rc) return rc;
+        }
+        s_begin = cuts.back();
+    }
+    return 0;
+}
+
+int check_range(const m6a_sites *s, int64_t a, int64_t b)
+{
+    if (!s) return fail(M6A_IO_EINVAL, "null argument");
+    if (a < 0 || b < a || b > m6a_io_n_sites(s)) return fail(M6A_IO_EINVAL, "site range [%lld, %lld) outside the job's %lld sites", (long long)a, (long long)b, (long long)m6a_io_n_sites(s));
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
 int m6a_io_write_csv_n(const m6a_sites *s, const char *out_dir, const float *read_prob, const float *site_prob,
                        const double *mod_ratio, int write_header, int n_threads, int64_t n_sites_limit)
 {
@@ -717,95 +832,73 @@ int m6a_io_write_csv_n(const m6a_sites *s, const char *out_dir, const float *rea
     FILE *g = fopen(fi.c_str(), write_header ? "w" : "a");
     if (!g) { fclose(f); return fail(M6A_IO_EIO, "cannot open %s", fi.c_str()); }
     if (write_header) {
-        fputs("transcript_id,transcript_position,n_reads,probability_modified,kmer,mod_ratio\n", f);
-        fputs("transcript_id,transcript_position,read_index,probability_modified\n", g);
+        fputs(kSiteHeader, f);
+        fputs(kIndivHeader, g);
     }
     // rows are formatted in parallel into per-chunk strings, written in order
-    const int nw = n_workers(n_threads, S);
-    const int64_t R = s->vOff[S];
-    int rc = 0;
-    // one chunk per worker per round; chunks of at most 2^20 reads bound the text held in memory
-    // (~64 MB per worker), at least 2^14 so tiny jobs do not spawn idle threads
-    const int64_t chunk_reads = std::max<int64_t>(1 << 14, std::min<int64_t>(1 << 20, (R + nw - 1) / nw));
-    int64_t s_begin = 0;
-    while (s_begin < S && !rc) {
-        std::vector<int64_t> cuts{s_begin};
-        for (int w = 0; w < nw && cuts.back() < S; w++) {
-            const int64_t target = std::min(R, s->vOff[cuts.back()] + chunk_reads);
-            int64_t e = std::upper_bound(s->vOff, s->vOff + s->nS + 1, target) - s->vOff - 1;
-            e = std::min<int64_t>(S, std::max<int64_t>(e, cuts.back() + 1));
-            cuts.push_back(e);
-        }
-        const int nc = (int)cuts.size() - 1;
-        std::vector<std::string> site_txt((size_t)nc), indiv_txt((size_t)nc);
-        auto work = [&](int w) {
-            std::string &a = site_txt[(size_t)w], &b = indiv_txt[(size_t)w];
-            const int64_t i0 = cuts[(size_t)w], i1 = cuts[(size_t)w + 1];
-            a.reserve((size_t)(i1 - i0) * 96);
-            b.reserve((size_t)(s->vOff[i1] - s->vOff[i0]) * 64);
-            char buf[512];
-            std::string head;
-            for (int64_t i = i0; i < i1; i++) {
-                const int64_t r0 = s->vOff[i], r1 = s->vOff[i + 1];
-                // '%s,%d,%s,%.16f,%s,%.16f'  (inference_utils.py:62)
-                a += s->tx_ids[(size_t)i];
-                int k = 0;
-                buf[k++] = ',';
-                k += format_i64((long long)s->vPos[i], buf + k);
-                buf[k++] = ',';
-                k += format_i64((long long)(r1 - r0), buf + k);
-                buf[k++] = ',';
-                k += format_f16((double)site_prob[i], buf + k);
-                buf[k++] = ',';
-                a.append(buf, (size_t)k);
-                a += s->kmer5[(size_t)i];
-                k = 0;
-                buf[k++] = ',';
-                k += format_f16(mod_ratio[i], buf + k);
-                buf[k++] = '\n';
-                a.append(buf, (size_t)k);
-                // '%s,%d,%s,%.16f'  (inference_utils.py:66); read ids: str(float64), or "<int>_<rep>"
-                head.assign(s->tx_ids[(size_t)i]);
-                k = 0;
-                buf[k++] = ',';
-                k += format_i64((long long)s->vPos[i], buf + k);
-                buf[k++] = ',';
-                head.append(buf, (size_t)k);
-                for (int64_t r = r0; r < r1; r++) {
-                    b += head;
-                    k = 0;
-                    const double id = s->vIds[r];
-                    if (s->n_rep > 1) {
-                        k += format_i64((long long)id, buf + k);
-                        buf[k++] = '_';
-                        k += format_i64((long long)s->vRep[r], buf + k);
-                    } else if (id == std::floor(id) && std::fabs(id) < 1e15 && !std::signbit(id)) {
-                        k += format_i64((long long)id, buf + k);                     // str(float64) of an integral value
-                        buf[k++] = '.';
-                        buf[k++] = '0';
-                    } else {
-                        format_py_float(id, b);
-                    }
-                    buf[k++] = ',';
-                    k += format_f16((double)read_prob[r], buf + k);
-                    buf[k++] = '\n';
-                    b.append(buf, (size_t)k);
-                }
-            }
-        };
-        std::vector<std::thread> th;
-        for (int w = 1; w < nc; w++) th.emplace_back(work, w);
-        work(0);
-        for (auto &t : th) t.join();
-        for (int w = 0; w < nc && !rc; w++) {
-            if (fwrite(site_txt[(size_t)w].data(), 1, site_txt[(size_t)w].size(), f) != site_txt[(size_t)w].size() ||
-                fwrite(indiv_txt[(size_t)w].data(), 1, indiv_txt[(size_t)w].size(), g) != indiv_txt[(size_t)w].size())
-                rc = fail(M6A_IO_EIO, "short write in %s", out_dir);
-        }
-        s_begin = cuts.back();
-    }
+    int rc = format_site_range(s, 0, S, read_prob, site_prob, mod_ratio, 0, 0, n_threads, [&](const std::string &a, const std::string &b) {
+        if (fwrite(a.data(), 1, a.size(), f) != a.size() || fwrite(b.data(), 1, b.size(), g) != b.size())
+            return fail(M6A_IO_EIO, "short write in %s", out_dir);
+        return 0;
+    });
     if (fclose(f) != 0 && !rc) rc = fail(M6A_IO_EIO, "cannot close %s", fs.c_str());
     if (fclose(g) != 0 && !rc) rc = fail(M6A_IO_EIO, "cannot close %s", fi.c_str());
+    return rc;
+}
+
+int64_t m6a_io_csv_header_bytes(int which) { return which == 0 ? (int64_t)sizeof(kSiteHeader) - 1 : (int64_t)sizeof(kIndivHeader) - 1; }
+
+int m6a_io_csv_shard_size(const m6a_sites *s, const float *read_prob, const float *site_prob, const double *mod_ratio,
+                          int64_t site_begin, int64_t site_end, int n_threads, int64_t *site_bytes, int64_t *indiv_bytes)
+{
+    int rc = check_range(s, site_begin, site_end);
+    if (rc) return rc;
+    if (!site_bytes || !indiv_bytes || (site_end > site_begin && (!read_prob || !site_prob || !mod_ratio))) return fail(M6A_IO_EINVAL, "null argument");
+    int64_t na = 0, nb = 0;
+    rc = format_site_range(s, site_begin, site_end, read_prob, site_prob, mod_ratio, site_begin, s->vOff[site_begin], n_threads,
+                           [&](const std::string &a, const std::string &b) { na += (int64_t)a.size(); nb += (int64_t)b.size(); return 0; });
+    *site_bytes = na; *indiv_bytes = nb;
+    return rc;
+}
+
+int m6a_io_csv_shard_write(const m6a_sites *s, const char *out_dir, const float *read_prob, const float *site_prob,
+                           const double *mod_ratio, int64_t site_begin, int64_t site_end, int n_threads,
+                           int64_t site_offset, int64_t indiv_offset, int write_header, int64_t site_total, int64_t indiv_total)
+{
+    int rc = check_range(s, site_begin, site_end);
+    if (rc) return rc;
+    if (!out_dir || site_offset < 0 || indiv_offset < 0 || (site_end > site_begin && (!read_prob || !site_prob || !mod_ratio))) return fail(M6A_IO_EINVAL, "bad argument");
+    const std::string fs = std::string(out_dir) + "/data.site_proba.csv", fi = std::string(out_dir) + "/data.indiv_proba.csv";
+    const int f = ::open(fs.c_str(), O_WRONLY | O_CREAT, 0644);
+    if (f < 0) return fail(M6A_IO_EIO, "cannot open %s", fs.c_str());
+    const int g = ::open(fi.c_str(), O_WRONLY | O_CREAT, 0644);
+    if (g < 0) { ::close(f); return fail(M6A_IO_EIO, "cannot open %s", fi.c_str()); }
+    auto put = [&](int fd, const char *p, size_t n, int64_t at) {
+        while (n) {
+            const ssize_t w = ::pwrite(fd, p, n, (off_t)at);
+            if (w < 0) { if (errno == EINTR) continue; return false; }
+            p += w; n -= (size_t)w; at += w;
+        }
+        return true;
+    };
+    bool ok = true;
+    if (write_header) {
+        // the rank that writes the headers also gives the files their final size: whatever an earlier run left behind them is cut
+        ok = put(f, kSiteHeader, sizeof(kSiteHeader) - 1, 0) && put(g, kIndivHeader, sizeof(kIndivHeader) - 1, 0);
+        if (ok && site_total >= 0) ok = ftruncate(f, (off_t)site_total) == 0;
+        if (ok && indiv_total >= 0) ok = ftruncate(g, (off_t)indiv_total) == 0;
+    }
+    int64_t sa = site_offset, sb = indiv_offset;
+    if (ok)
+        rc = format_site_range(s, site_begin, site_end, read_prob, site_prob, mod_ratio, site_begin, s->vOff[site_begin], n_threads,
+                               [&](const std::string &a, const std::string &b) {
+                                   if (!put(f, a.data(), a.size(), sa) || !put(g, b.data(), b.size(), sb)) return fail(M6A_IO_EIO, "short write in %s", out_dir);
+                                   sa += (int64_t)a.size(); sb += (int64_t)b.size();
+                                   return 0;
+                               });
+    if (::close(f) != 0) ok = false;
+    if (::close(g) != 0) ok = false;
+    if (!ok && !rc) rc = fail(M6A_IO_EIO, "cannot write into %s", out_dir);
     return rc;
 }
 

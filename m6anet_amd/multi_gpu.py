@@ -4,8 +4,11 @@ The reference has no multi-device path; this is north_star's: candidate sites ar
 into contiguous, flush-group-aligned shards balanced by read count (`m6a_shard_plan`), every rank -- one process per
 GPU -- runs the whole hot path on its shard with `m6a_set_job_offset(first_site)` (flush groups and RNG restarts are
 those of the whole job, so the CSVs do not depend on N), and ONE exchange at the end brings site_prob + mod_ratio
-(`m6a_gather`) and the per-read probabilities data.indiv_proba.csv needs (`m6a_gather_reads`) to rank 0 over
-RCCL/xGMI -- the library's own communicator, no torch.distributed.  Rank 0 writes the CSVs.
+(`m6a_gather`, 12 B per site) to rank 0 over RCCL/xGMI -- the library's own communicator, no torch.distributed.
+The OUTPUT is sharded like the compute: every rank maps the store, so it formats the rows of its own sites and
+pwrite()s them at its offset into data.site_proba.csv / data.indiv_proba.csv (`m6a_io_csv_shard_size / _write`; the
+byte counts meet in the exchange directory) -- the per-read probabilities, 4 B per read and the bulk of the output, never
+leave the rank that computed them, and the 8-GPU job is not one host thread's write().
 
     launcher (the process the user started)
       |- makes an exchange directory, packs data.json -> one binary site store there unless the input already is one
@@ -36,13 +39,17 @@ def _timeout():
     return float(os.environ.get("M6A_EXCHANGE_TIMEOUT", "900"))
 
 
-def _wait_for(path, what, parent):
+def _wait_for(path, what, parent, busy=None):
     """Blocks until `path` exists (written atomically by its producer).  Gives up when the launcher has gone away or
-    after M6A_EXCHANGE_TIMEOUT seconds -- a rank must never wait for ever on a peer that died."""
+    after M6A_EXCHANGE_TIMEOUT seconds -- a rank must never wait for ever on a peer that died.  While `busy` exists
+    (the launcher's "still packing" marker) the clock does not run: a very large data.json may take longer to pack than
+    any sensible exchange timeout."""
     t0, nap = time.time(), 0.0005
     while not os.path.exists(path):
         if os.getppid() != parent:
             raise RuntimeError("launcher has gone away while waiting for %s" % what)
+        if busy is not None and os.path.exists(busy):
+            t0 = time.time()
         if time.time() - t0 > _timeout():
             raise TimeoutError("timed out after %.0f s waiting for %s (%s)" % (_timeout(), what, path))
         time.sleep(nap)
@@ -69,6 +76,37 @@ def exchange_mode(world):
 # ---------------------------------------------------------------------------------------------------------------
 # launcher
 # ---------------------------------------------------------------------------------------------------------------
+def store_size_estimate(input_dirs):
+    """Upper estimate of the packed store: the normalised features (36 B per read) and the ids are about 0.45 of the JSON
+    text they were parsed from (913 MB of data.json -> 384 MB); 0.6 + 64 MB leaves room."""
+    total = 0
+    for d in input_dirs:
+        for fn in ("data.json", "data.info"):
+            try:
+                total += os.path.getsize(os.path.join(str(d), fn))
+            except OSError:
+                pass
+    return int(0.6 * total) + (64 << 20)
+
+
+def exchange_base(need_bytes, out_dir):
+    """Where the exchange directory (RCCL id, byte counts, and the packed store unless the input already is one) goes:
+    M6A_XDIR_BASE if set; /dev/shm when it is writable AND has room for the store with a margin (Docker's default /dev/shm
+    is 64 MB, and a tmpfs store is RAM next to every rank's page-cache mapping of it); else the system's temporary
+    directory if IT has room; else the output directory."""
+    forced = os.environ.get("M6A_XDIR_BASE")
+    if forced:
+        return forced
+    candidates = ["/dev/shm", tempfile.gettempdir(), os.path.abspath(str(out_dir))]
+    for c in candidates:
+        try:
+            if not (os.path.isdir(c) and os.access(c, os.W_OK)):
+                continue
+            if shutil.disk_usage(c).free >= 1.25 * need_bytes + (16 << 20):
+                return c
+        except OSError:
+            continue
+    return None                                              # tempfile's default; pack_sites will say what went wrong
 def rank_argv(args):
     """The command line of a rank: the launcher's own options (the pretrained-model defaults are resolved again there)."""
     argv = ["--input_dir"] + [str(d) for d in args.input_dir] + ["--out_dir", str(args.out_dir)]
@@ -87,8 +125,8 @@ def launch(args):
     world = int(args.gpus)
     argv = rank_argv(args)
     exchange_mode(world)                                   # fails early, with the reason, in the launcher
-    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
-    xdir = tempfile.mkdtemp(prefix="m6a_gpus_", dir=base)
+    given_store = len(args.input_dir) == 1 and str(args.input_dir[0]).endswith(STORE_SUFFIX)
+    xdir = tempfile.mkdtemp(prefix="m6a_gpus_", dir=exchange_base(0 if given_store else store_size_estimate(args.input_dir), args.out_dir))
     procs = []
     # a terminated launcher still takes its ranks down and removes the exchange directory (a packed store can be hundreds of MB
     # of /dev/shm): SIGTERM becomes an exception, so the `finally` below runs
@@ -101,14 +139,19 @@ def launch(args):
     except ValueError:                                       # not the main thread (the CLI called from a library): keep the default
         pass
     try:
-        given_store = len(args.input_dir) == 1 and str(args.input_dir[0]).endswith(STORE_SUFFIX)
         store = os.path.abspath(args.input_dir[0]) if given_store else os.path.join(xdir, "job" + STORE_SUFFIX)
         for r in range(world):
             env = dict(os.environ, M6A_RANK=str(r), M6A_WORLD=str(world), M6A_XDIR=xdir, M6A_STORE=store)
             procs.append(subprocess.Popen([sys.executable, "-m", "m6anet_amd", "inference"] + list(argv), env=env))
         if not given_store:
-            # parse + normalise ONCE, while the ranks bring their HIP runtimes up; they map the result
-            pack_sites(args.input_dir, store, DEFAULT_MIN_READS, args.norm_path, n_threads=args.n_processes)
+            # parse + normalise ONCE, while the ranks bring their HIP runtimes up; they map the result.  The marker stops the
+            # ranks' timeout clocks for as long as the packing takes.
+            marker = os.path.join(xdir, "packing")
+            _publish(marker, b"1")
+            try:
+                pack_sites(args.input_dir, store, DEFAULT_MIN_READS, args.norm_path, n_threads=args.n_processes)
+            finally:
+                os.remove(marker)
         return _wait_all(procs)
     finally:
         for p in procs:
@@ -154,11 +197,10 @@ def run_rank(args, weights):
 
     # the GPU context comes up while the launcher may still be packing the store
     engine = M6ANetEngine(weights=weights, device=device)
-    _wait_for(store, "the launcher's site store", parent)
+    _wait_for(store, "the launcher's site store", parent, busy=os.path.join(xdir, "packing"))
     batch = open_store(store, args.norm_path, DEFAULT_MIN_READS)
     off = batch.off
     cuts = shard_plan(off, world, args.batch_size, args.save_per_batch)
-    read_cuts = np.ascontiguousarray(off[cuts])
     a, b = int(cuts[rank]), int(cuts[rank + 1])
     r0, r1 = int(off[a]), int(off[b])
     if r1 - r0 >= (1 << 22):
@@ -168,6 +210,8 @@ def run_rank(args, weights):
         batch.X[r0:r1], batch.site_kmers[a:b], np.ascontiguousarray(off[a:b + 1] - r0), args.num_iterations, N_SAMPLES,
         args.read_proba_threshold, args.seed, args.batch_size, args.save_per_batch)
 
+    # ---- the job's one exchange: site_prob + mod_ratio (12 B per site) to rank 0 -- over RCCL/xGMI, or through the exchange
+    # directory in the debugging mode.  The per-read probabilities (4 B per read, the bulk of the output) never travel.
     if mode == "rccl":
         ident_path = os.path.join(xdir, "rccl_id")
         if rank == 0:
@@ -175,31 +219,56 @@ def run_rank(args, weights):
         _wait_for(ident_path, "rank 0's RCCL id", parent)
         with open(ident_path, "rb") as f:
             engine.comm_init(f.read(), rank, world)
+        seen = engine.comm_info()["ranks_seen"]
+        if seen != world:
+            raise RuntimeError("RCCL formed a communicator of %d ranks, the job has %d" % (seen, world))
         site_all, mod_all = engine.gather(site_prob, mod_ratio, cuts, dst=0)
-        read_all = engine.gather_reads(read_prob, read_cuts, dst=0)
         engine.comm_destroy()
     else:
-        site_all = mod_all = read_all = None
+        site_all = mod_all = None
         if rank != 0:
-            _publish(os.path.join(xdir, "shard%d.bin" % rank),
-                     mod_ratio.tobytes() + site_prob.tobytes() + read_prob.tobytes())
+            _publish(os.path.join(xdir, "shard%d.bin" % rank), mod_ratio.tobytes() + site_prob.tobytes())
         else:
             site_all, mod_all = np.empty(int(cuts[-1]), np.float32), np.empty(int(cuts[-1]), np.float64)
-            read_all = np.empty(int(off[-1]), np.float32)
-            site_all[a:b], mod_all[a:b], read_all[r0:r1] = site_prob, mod_ratio, read_prob
+            site_all[a:b], mod_all[a:b] = site_prob, mod_ratio
             for r in range(1, world):
                 p = os.path.join(xdir, "shard%d.bin" % r)
                 _wait_for(p, "rank %d's results" % r, parent)
-                ns, nr = int(cuts[r + 1] - cuts[r]), int(read_cuts[r + 1] - read_cuts[r])
+                ns = int(cuts[r + 1] - cuts[r])
                 raw = np.fromfile(p, np.uint8)
-                if raw.size != 12 * ns + 4 * nr:
-                    raise RuntimeError("rank %d delivered %d bytes, expected %d" % (r, raw.size, 12 * ns + 4 * nr))
+                if raw.size != 12 * ns:
+                    raise RuntimeError("rank %d delivered %d bytes, expected %d" % (r, raw.size, 12 * ns))
                 mod_all[cuts[r]:cuts[r + 1]] = raw[:8 * ns].view(np.float64)
                 site_all[cuts[r]:cuts[r + 1]] = raw[8 * ns:12 * ns].view(np.float32)
-                read_all[read_cuts[r]:read_cuts[r + 1]] = raw[12 * ns:].view(np.float32)
     engine.close()
+
+    # ---- every rank writes the rows of ITS sites: they are formatted once to learn their size, the sizes meet in the exchange
+    # directory (16 bytes per rank), and each rank pwrite()s its rows at its offset into the two CSVs -- N hosts' worth of
+    # formatting and write() instead of rank 0's alone, and nobody holds the job's 4 B per read
+    n_write = batch.n_sites
+    if getattr(args, "drop_unflushed_tail", False):
+        n_write = reference_written_sites(batch.n_sites, args.batch_size, args.save_per_batch)
+    wa, wb = min(a, n_write), min(b, n_write)                # the reference's row set may end inside (or before) this shard
+    nr = int(off[wb] - off[wa])
+    from ._io import usable_cpus
+    threads = max(1, usable_cpus() // world)                 # the ranks share one host: each formats on its share of the CPUs
+    sizes = batch.native.csv_shard_size(wa, wb, read_prob[:nr], site_prob[:wb - wa], mod_ratio[:wb - wa], n_threads=threads)
+    _publish(os.path.join(xdir, "csv_size%d" % rank), np.array(sizes, np.int64).tobytes())
+    all_sizes = np.zeros((world, 2), np.int64)
+    for r in range(world):
+        p = os.path.join(xdir, "csv_size%d" % r)
+        _wait_for(p, "rank %d's CSV sizes" % r, parent)
+        all_sizes[r] = np.fromfile(p, np.int64, 2)
+    head = np.array(batch.native.csv_header_bytes(), np.int64)
+    start = head + all_sizes[:rank].sum(axis=0)
+    totals = head + all_sizes.sum(axis=0)
+    batch.native.csv_shard_write(args.out_dir, wa, wb, read_prob[:nr], site_prob[:wb - wa], mod_ratio[:wb - wa], int(start[0]), int(start[1]),
+                                 header_and_totals=(int(totals[0]), int(totals[1])) if rank == 0 else None, n_threads=threads)
+    _publish(os.path.join(xdir, "csv_done%d" % rank), b"1")
     if rank == 0:
-        n_write = None
-        if getattr(args, "drop_unflushed_tail", False):
-            n_write = reference_written_sites(batch.n_sites, args.batch_size, args.save_per_batch)
-        batch.native.write_csv(args.out_dir, read_all, site_all, mod_all, write_header=True, n_sites=n_write)
+        # rank 0 is the job: it leaves when every rank's rows are in the files, and checks the gathered site results against
+        # what it can see of them (its own shard) -- the launcher's exit code is the job's
+        for r in range(world):
+            _wait_for(os.path.join(xdir, "csv_done%d" % r), "rank %d's rows" % r, parent)
+        if not (np.array_equal(site_all[a:b], site_prob) and np.array_equal(mod_all[a:b], mod_ratio, equal_nan=True)):
+            raise RuntimeError("the gathered site results do not contain rank 0's own shard")

@@ -289,3 +289,42 @@ def test_loader_reads_the_non_finite_literals_python_json_writes(tmp_path):
     nat = data_utils.load_sites_native([str(tmp_path)], 20, "norm_hct116.npz", n_threads=2)
     assert np.array_equal(nat.X, ref.X, equal_nan=True)
     assert np.isnan(nat.X).sum() >= 1 and np.isinf(nat.X).sum() >= 2
+
+
+@pytest.mark.parametrize("cuts", [[0, 101], [0, 1, 101], [0, 16, 48, 80, 101], [0, 0, 33, 33, 101, 101], [0, 7, 9, 50, 90, 101]])
+def test_sharded_csv_writer_gives_the_bytes_of_one_writer(golden, tmp_path, cuts):
+    """`inference --gpus N`: every rank formats the rows of ITS sites, learns their size, and pwrite()s them at its offset
+    (m6a_io_csv_shard_size / m6a_io_csv_shard_write).  Whatever the cut -- empty shards included -- and whatever order the
+    ranks write in, the two files are byte for byte m6a_io_write_csv's; a longer file left by an earlier run is cut to size;
+    the single-sample and the replicate read-id forms both go through."""
+    from m6anet_amd import _io
+    for dirs in ([DATA], [DATA, DATA]):
+        nat = _io.NativeSites(dirs, 20, data_utils.load_norm_factors("norm_hct116.npz"), 2)
+        S, R = nat.tx_pos.size, nat.X.shape[0]
+        cuts = [c * S // 101 for c in cuts]                      # 101 sites alone, 171 as two pooled replicates
+        g = np.random.Generator(np.random.PCG64(5))
+        rp, sp, mr = g.random(R, dtype=np.float32), g.random(S, dtype=np.float32), g.random(S)
+        mr[3] = np.nan                                           # a site without reads prints 'nan'
+        one = tmp_path / ("one%d" % len(dirs))
+        one.mkdir(exist_ok=True)
+        nat.write_csv(str(one), rp, sp, mr, write_header=True)
+        want = [(one / fn).read_bytes() for fn in ("data.site_proba.csv", "data.indiv_proba.csv")]
+        out = tmp_path / ("sharded%d" % len(dirs))
+        out.mkdir(exist_ok=True)
+        for fn in ("data.site_proba.csv", "data.indiv_proba.csv"):
+            (out / fn).write_bytes(b"x" * (len(want[1]) + 12345))            # stale, longer files
+        off = nat.off
+        n = len(cuts) - 1
+        sizes = np.array([nat.csv_shard_size(cuts[r], cuts[r + 1], rp[off[cuts[r]]:off[cuts[r + 1]]], sp[cuts[r]:cuts[r + 1]],
+                                             mr[cuts[r]:cuts[r + 1]]) for r in range(n)], np.int64).reshape(n, 2)
+        head = np.array(nat.csv_header_bytes(), np.int64)
+        assert tuple(head + sizes.sum(axis=0)) == (len(want[0]), len(want[1]))
+        for r in reversed(range(n)):                             # last rank first: rank 0 (header + final size) comes LAST
+            start = head + sizes[:r].sum(axis=0)
+            nat.csv_shard_write(str(out), cuts[r], cuts[r + 1], rp[off[cuts[r]]:off[cuts[r + 1]]], sp[cuts[r]:cuts[r + 1]], mr[cuts[r]:cuts[r + 1]],
+                                int(start[0]), int(start[1]), header_and_totals=tuple(int(x) for x in head + sizes.sum(axis=0)) if r == 0 else None,
+                                n_threads=1 + r % 3)
+        assert [(out / fn).read_bytes() for fn in ("data.site_proba.csv", "data.indiv_proba.csv")] == want
+        with pytest.raises(_io.M6AIOError):                      # a range outside the job
+            _io._chk(_io.load().m6a_io_csv_shard_size(nat._h, None, None, None, 5, S + 1, 1, None, None))
+        nat.close()
