@@ -74,8 +74,10 @@ int m6a_io_write_csv_n(const m6a_sites *s, const char *out_dir, const float *rea
 /* The same rows written by SEVERAL processes at once (`inference --gpus N`: every rank maps the same store and holds the
  * results of its own shard, so nobody has to collect the job's read probabilities -- 4 B per read -- just to print them):
  *   m6a_io_csv_shard_size    bytes the rows of sites [site_begin, site_end) take in each file (they are formatted and
- *                            counted, not kept); read_prob / site_prob / mod_ratio hold THAT range's values only;
- *   m6a_io_csv_shard_write   formats them again and pwrite()s them at site_offset / indiv_offset (= header + the sizes of
+ *                            counted; up to M6A_IO_CSV_KEEP_MB = 1024 MB of the text stays with the handle, and the
+ *                            m6a_io_csv_shard_write that follows with the same range and arrays writes it instead of
+ *                            formatting again); read_prob / site_prob / mod_ratio hold THAT range's values only;
+ *   m6a_io_csv_shard_write   pwrite()s them at site_offset / indiv_offset (= header + the sizes of
  *                            all earlier shards, exchanged by the caller); the one rank with write_header != 0 also writes
  *                            both header lines and sets the files to their final sizes site_total / indiv_total
  *                            (< 0: leaves the size alone), which cuts whatever an earlier run left there;

@@ -294,6 +294,14 @@ struct m6a_sites {
     void *map = nullptr;
     size_t map_len = 0;
     std::string tag;
+    // m6a_io_csv_shard_size keeps the text it formatted (up to M6A_IO_CSV_KEEP_MB, default 1024) so that the
+    // m6a_io_csv_shard_write that follows for the same range and the same arrays writes it instead of formatting again
+    struct CsvKeep {
+        int64_t a = -1, b = -1;
+        const void *rp = nullptr, *sp = nullptr, *mr = nullptr;
+        std::vector<std::string> site, indiv;
+        void clear() { a = b = -1; std::vector<std::string>().swap(site); std::vector<std::string>().swap(indiv); }
+    } csv_keep;
     void view_owned()
     {
         vX = X.data(); vK = site_kmers.data(); vOff = off.data(); vPos = tx_pos.data();
@@ -802,7 +810,7 @@ int format_site_range(const m6a_sites *s, int64_t A, int64_t B, const float *rea
         work(0);
         for (auto &t : th) t.join();
         for (int w = 0; w < nc; w++) {
-            const int rc = sink(site_txt[(size_t)w], indiv_txt[(size_t)w]);
+            const int rc = sink(site_txt[(size_t)w], indiv_txt[(size_t)w]);       // the sink may move the strings out
             if (rc) return rc;
         }
         s_begin = cuts.back();
@@ -836,7 +844,7 @@ int m6a_io_write_csv_n(const m6a_sites *s, const char *out_dir, const float *rea
         fputs(kIndivHeader, g);
     }
     // rows are formatted in parallel into per-chunk strings, written in order
-    int rc = format_site_range(s, 0, S, read_prob, site_prob, mod_ratio, 0, 0, n_threads, [&](const std::string &a, const std::string &b) {
+    int rc = format_site_range(s, 0, S, read_prob, site_prob, mod_ratio, 0, 0, n_threads, [&](std::string &a, std::string &b) {
         if (fwrite(a.data(), 1, a.size(), f) != a.size() || fwrite(b.data(), 1, b.size(), g) != b.size())
             return fail(M6A_IO_EIO, "short write in %s", out_dir);
         return 0;
@@ -855,8 +863,20 @@ int m6a_io_csv_shard_size(const m6a_sites *s, const float *read_prob, const floa
     if (rc) return rc;
     if (!site_bytes || !indiv_bytes || (site_end > site_begin && (!read_prob || !site_prob || !mod_ratio))) return fail(M6A_IO_EINVAL, "null argument");
     int64_t na = 0, nb = 0;
+    m6a_sites::CsvKeep &keep = const_cast<m6a_sites *>(s)->csv_keep;     // a cache, not part of the sites' value
+    keep.clear();
+    const char *km = getenv("M6A_IO_CSV_KEEP_MB");
+    const int64_t budget = (int64_t)(km ? atoll(km) : 1024) << 20;
+    bool keeping = budget > 0;
     rc = format_site_range(s, site_begin, site_end, read_prob, site_prob, mod_ratio, site_begin, s->vOff[site_begin], n_threads,
-                           [&](const std::string &a, const std::string &b) { na += (int64_t)a.size(); nb += (int64_t)b.size(); return 0; });
+                           [&](std::string &a, std::string &b) {
+                               na += (int64_t)a.size(); nb += (int64_t)b.size();
+                               if (keeping && na + nb > budget) { keeping = false; keep.clear(); }
+                               if (keeping) { keep.site.push_back(std::move(a)); keep.indiv.push_back(std::move(b)); }
+                               return 0;
+                           });
+    if (!rc && keeping) { keep.a = site_begin; keep.b = site_end; keep.rp = read_prob; keep.sp = site_prob; keep.mr = mod_ratio; }
+    else keep.clear();
     *site_bytes = na; *indiv_bytes = nb;
     return rc;
 }
@@ -889,9 +909,17 @@ int m6a_io_csv_shard_write(const m6a_sites *s, const char *out_dir, const float 
         if (ok && indiv_total >= 0) ok = ftruncate(g, (off_t)indiv_total) == 0;
     }
     int64_t sa = site_offset, sb = indiv_offset;
-    if (ok)
+    m6a_sites::CsvKeep &keep = const_cast<m6a_sites *>(s)->csv_keep;
+    if (ok && keep.a == site_begin && keep.b == site_end && keep.rp == read_prob && keep.sp == site_prob && keep.mr == mod_ratio) {
+        // the text m6a_io_csv_shard_size formatted a moment ago
+        for (size_t i = 0; i < keep.site.size() && ok; i++) {
+            ok = put(f, keep.site[i].data(), keep.site[i].size(), sa) && put(g, keep.indiv[i].data(), keep.indiv[i].size(), sb);
+            sa += (int64_t)keep.site[i].size(); sb += (int64_t)keep.indiv[i].size();
+        }
+        keep.clear();
+    } else if (ok)
         rc = format_site_range(s, site_begin, site_end, read_prob, site_prob, mod_ratio, site_begin, s->vOff[site_begin], n_threads,
-                               [&](const std::string &a, const std::string &b) {
+                               [&](std::string &a, std::string &b) {
                                    if (!put(f, a.data(), a.size(), sa) || !put(g, b.data(), b.size(), sb)) return fail(M6A_IO_EIO, "short write in %s", out_dir);
                                    sa += (int64_t)a.size(); sb += (int64_t)b.size();
                                    return 0;

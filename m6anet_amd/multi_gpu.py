@@ -10,11 +10,13 @@ pwrite()s them at its offset into data.site_proba.csv / data.indiv_proba.csv (`m
 byte counts meet in the exchange directory) -- the per-read probabilities, 4 B per read and the bulk of the output, never
 leave the rank that computed them, and the 8-GPU job is not one host thread's write().
 
-    launcher (the process the user started)
-      |- makes an exchange directory, packs data.json -> one binary site store there unless the input already is one
-      |  (every rank maps the same file: nothing is parsed N times, a rank touches only its shard's pages)
-      |- starts N ranks: the same command line with M6A_RANK / M6A_WORLD / M6A_XDIR / M6A_STORE in the environment
-      '- waits; a rank that dies takes the others down (exact pids) and the launcher exits non-zero
+    the process the user started = rank 0
+      |- makes an exchange directory, starts ranks 1..N-1: the same command line with M6A_RANK / M6A_WORLD / M6A_XDIR /
+      |  M6A_STORE in the environment
+      |- packs data.json -> one binary site store there unless the input already is one (every rank maps the same file:
+      |  nothing is parsed N times, a rank touches only its shard's pages)
+      |- runs its own shard, joins the exchange, writes its rows
+      '- waits for the others; a rank that dies ends the job (exact pids) with its exit code
 
 The 128-byte RCCL id travels through the exchange directory (rank 0 writes it, the others wait for it).
 M6A_EXCHANGE=host is a debugging aid like bench.py's M6A_BENCH_BACKEND=gloo: the gather goes through files in the
@@ -44,7 +46,7 @@ def _wait_for(path, what, parent, busy=None):
     after M6A_EXCHANGE_TIMEOUT seconds -- a rank must never wait for ever on a peer that died.  While `busy` exists
     (the launcher's "still packing" marker) the clock does not run: a very large data.json may take longer to pack than
     any sensible exchange timeout."""
-    t0, nap = time.time(), 0.0005
+    t0, nap = time.time(), 0.0002
     while not os.path.exists(path):
         if os.getppid() != parent:
             raise RuntimeError("launcher has gone away while waiting for %s" % what)
@@ -53,7 +55,7 @@ def _wait_for(path, what, parent, busy=None):
         if time.time() - t0 > _timeout():
             raise TimeoutError("timed out after %.0f s waiting for %s (%s)" % (_timeout(), what, path))
         time.sleep(nap)
-        nap = min(nap * 2, 0.05)
+        nap = min(nap * 1.5, 0.004)                # a rank waits a few times per job; 4 ms naps cost nothing and add nothing
 
 
 def _publish(path, data):
@@ -120,17 +122,20 @@ def rank_argv(args):
     return argv
 
 
-def launch(args):
-    """Starts `args.gpus` ranks of this command line and waits for them.  Returns the exit code."""
+def launch(args, weights):
+    """The process the user started IS rank 0: it starts ranks 1..N-1 (the same command line with M6A_RANK / M6A_WORLD / M6A_XDIR /
+    M6A_STORE in the environment), packs the store if the input is not one, runs its own shard, and waits for the others --
+    no interpreter start-up sits between the command and rank 0's work.  Returns the exit code."""
     world = int(args.gpus)
     argv = rank_argv(args)
-    exchange_mode(world)                                   # fails early, with the reason, in the launcher
+    exchange_mode(world)                                   # fails early, with the reason
     given_store = len(args.input_dir) == 1 and str(args.input_dir[0]).endswith(STORE_SUFFIX)
     xdir = tempfile.mkdtemp(prefix="m6a_gpus_", dir=exchange_base(0 if given_store else store_size_estimate(args.input_dir), args.out_dir))
     procs = []
     # a terminated launcher still takes its ranks down and removes the exchange directory (a packed store can be hundreds of MB
     # of /dev/shm): SIGTERM becomes an exception, so the `finally` below runs
     import signal
+    import threading
 
     def on_term(signum, frame):
         raise SystemExit(128 + signum)
@@ -138,11 +143,36 @@ def launch(args):
         signal.signal(signal.SIGTERM, on_term)
     except ValueError:                                       # not the main thread (the CLI called from a library): keep the default
         pass
+    stop = threading.Event()
+
+    def watch():
+        # rank 0 may be blocked in the exchange, waiting for a rank that has died: a failed child ends the job with its code
+        while not stop.wait(0.005):
+            bad = [p.returncode for p in procs if p.poll() not in (None, 0)]
+            if bad:
+                for p in procs:
+                    if p.poll() is None:
+                        p.kill()
+                shutil.rmtree(xdir, ignore_errors=True)
+                sys.stderr.flush()
+                os._exit(bad[0] if 0 < bad[0] < 256 else 1)
     try:
         store = os.path.abspath(args.input_dir[0]) if given_store else os.path.join(xdir, "job" + STORE_SUFFIX)
-        for r in range(world):
-            env = dict(os.environ, M6A_RANK=str(r), M6A_WORLD=str(world), M6A_XDIR=xdir, M6A_STORE=store)
-            procs.append(subprocess.Popen([sys.executable, "-m", "m6anet_amd", "inference"] + list(argv), env=env))
+        rank_env = dict(M6A_WORLD=str(world), M6A_XDIR=xdir, M6A_STORE=store)
+        for r in range(1, world):
+            procs.append(subprocess.Popen([sys.executable, "-m", "m6anet_amd", "inference"] + list(argv),
+                                          env=dict(os.environ, M6A_RANK=str(r), **rank_env)))
+        threading.Thread(target=watch, daemon=True).start()
+        # rank 0's GPU context comes up on a thread while the store is packed, like the other ranks' in their processes
+        made = {}
+
+        def make_engine():
+            try:
+                made["engine"] = M6ANetEngine(weights=weights, device=0)
+            except BaseException as exc:                    # noqa: BLE001 -- re-raised on the main thread
+                made["error"] = exc
+        starter = threading.Thread(target=make_engine)
+        starter.start()
         if not given_store:
             # parse + normalise ONCE, while the ranks bring their HIP runtimes up; they map the result.  The marker stops the
             # ranks' timeout clocks for as long as the packing takes.
@@ -152,8 +182,19 @@ def launch(args):
                 pack_sites(args.input_dir, store, DEFAULT_MIN_READS, args.norm_path, n_threads=args.n_processes)
             finally:
                 os.remove(marker)
+        starter.join()
+        if "error" in made:
+            raise made["error"]
+        os.environ.update(rank_env, M6A_RANK="0")
+        try:
+            run_rank(args, weights, engine=made["engine"])
+        finally:
+            for k in ("M6A_RANK", "M6A_WORLD", "M6A_XDIR", "M6A_STORE"):
+                os.environ.pop(k, None)
+        stop.set()
         return _wait_all(procs)
     finally:
+        stop.set()
         for p in procs:
             if p.poll() is None:
                 p.kill()
@@ -182,21 +223,22 @@ def _wait_all(procs):
             return bad[0] if bad else 124
         if all(c == 0 for c in codes):
             return 0
-        time.sleep(0.01)
+        time.sleep(0.002)
 
 
 # ---------------------------------------------------------------------------------------------------------------
 # one rank
 # ---------------------------------------------------------------------------------------------------------------
-def run_rank(args, weights):
+def run_rank(args, weights, engine=None):
     rank, world = int(os.environ["M6A_RANK"]), int(os.environ["M6A_WORLD"])
     xdir, store = os.environ["M6A_XDIR"], os.environ["M6A_STORE"]
-    parent = os.getppid()
+    parent = os.getppid()                                    # ranks 1..: the launcher (= rank 0); rank 0: whoever started the job
     mode = exchange_mode(world)
     device = rank if mode == "rccl" else rank % max(device_count(), 1)
 
     # the GPU context comes up while the launcher may still be packing the store
-    engine = M6ANetEngine(weights=weights, device=device)
+    if engine is None:
+        engine = M6ANetEngine(weights=weights, device=device)
     _wait_for(store, "the launcher's site store", parent, busy=os.path.join(xdir, "packing"))
     batch = open_store(store, args.norm_path, DEFAULT_MIN_READS)
     off = batch.off

@@ -99,7 +99,7 @@ def main(args):
     if args.gpus > 1:
         from .. import multi_gpu
         pathlib.Path(args.out_dir).mkdir(parents=True, exist_ok=True)
-        rc = multi_gpu.launch(args)
+        rc = multi_gpu.launch(args, weights)
         if rc != 0:
             raise SystemExit(rc)
         return
