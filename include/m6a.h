@@ -124,9 +124,11 @@ int m6a_infer(m6a_ctx *ctx, const float *X, const uint8_t *site_kmers, const int
  *                   off [n+1] batch-local CSR offsets (off[0] = 0).  ASYNCHRONOUS: host rows are copied into a pinned
  *                   ring (the buffers are the caller's again on return), cross PCIe while earlier chunks are being
  *                   encoded, and the encoder is queued per chunk of <= ~130 k reads.  X / site_kmers may be host or
- *                   device pointers (both of a kind; device rows are read in place, stream-ordered); off is ALWAYS a
- *                   host pointer -- it is the loader's n_reads vector (data_utils.py:499).  Batches of any size, in
- *                   job order.
+ *                   device pointers (both of a kind).  DEVICE rows are NOT copied: the encoder queued on the context's
+ *                   stream reads them in place, possibly after the call has returned -- they must stay allocated and
+ *                   unmodified until m6a_job_end / m6a_job_abort returns, and whatever produced them must be ordered
+ *                   before the context's stream (same stream, or completed).  off is ALWAYS a host pointer -- it is
+ *                   the loader's n_reads vector (data_utils.py:499).  Batches of any size, in job order.
  *   m6a_job_end     pools all sites fed so far exactly as m6a_infer would (same flush groups, same random stream) and
  *                   delivers read_prob [R] (or NULL), site_prob [S], mod_ratio [S] -- all host (synchronous) or all
  *                   device (the call still synchronises).  Closes the job, also on error.  Results are bit-identical

@@ -8,8 +8,9 @@ CSRC = os.path.join(PKG, "csrc")
 INCLUDE = os.path.join(os.path.dirname(PKG), "include")
 LIB = os.path.join(PKG, "libm6a_hip.so")
 IO_LIB = os.path.join(PKG, "libm6a_io.so")
-SOURCES = ["m6a_kernels.hip", "m6a_pool_reg.hip", "m6a_pool_rtab.hip", "m6a_api.hip"]
-DEPS = SOURCES + ["m6a_kernels.h", "m6a_host_cpus.h", os.path.join(INCLUDE, "m6a.h"), os.path.join(PKG, "assets", "mt19937_jump.bin")]
+SOURCES = ["m6a_kernels.hip", "m6a_pool_reg.hip", "m6a_pool_rtab.hip", "m6a_api.hip", "m6a_host_ring.hip", "m6a_job.hip", "m6a_comm.hip",
+           "m6a_validate.hip"]
+DEPS = SOURCES + ["m6a_kernels.h", "m6a_ctx.h", "m6a_host_cpus.h", os.path.join(INCLUDE, "m6a.h"), os.path.join(PKG, "assets", "mt19937_jump.bin")]
 
 
 def needs_build():

@@ -77,6 +77,7 @@ struct RtabBuild {
     uint32_t n_blk;               // stream blocks of 64 words covered by the tables
     const int32_t *build_n;       // [n_build] bag sizes to build
     const int32_t *build_slot;    // [n_build] their slots
+    int n_build;
     uint16_t *C;
     uint32_t *RS;
     int64_t c_stride;             // entries per slot in C (= 64 * n_blk)

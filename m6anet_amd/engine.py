@@ -131,10 +131,13 @@ class M6ANetEngine:
 
     def set_stream(self, stream_handle):
         self._chk(self._L.m6a_set_stream(self._h, C.c_void_p(stream_handle or 0)))
+        self._torch_stream = None
 
     def use_torch_stream(self):
         import torch
-        self.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+        st = torch.cuda.current_stream(self.device)
+        self.set_stream(st.cuda_stream)
+        self._torch_stream = st.cuda_stream
 
     def set_job_offset(self, first_site):
         """The sites given to calculate_site_proba/infer are sites [first_site, ...) of a larger
@@ -311,11 +314,23 @@ class M6ANetEngine:
                                         int(seed) & 0xffffffff, _lib.RNG_NUMPY, int(batch_size), int(save_per_batch),
                                         int(expect_sites), int(expect_reads)))
         self._job_dev = False
+        self._job_keep = []                                  # device tensors fed to the open job (released by job_end / job_abort)
 
     def job_feed(self, X, site_kmers, off):
         """One batch: X [r,9], site_kmers [n,3] (numpy or torch-on-GPU), off [n+1] batch-local CSR offsets (host).
-        Asynchronous: returns once the rows are in the pinned ring; the arrays are the caller's again."""
+        Asynchronous.  HOST arrays are copied into the pinned ring: they are the caller's again on return.  DEVICE tensors
+        are read in place by the encoder queued on the context's stream, possibly after this call has returned
+        (include/m6a.h): the engine keeps them referenced until job_end / job_abort, so the caching allocator cannot hand
+        their memory to the next batch, and -- unless the context runs on the very stream torch is producing on
+        (use_torch_stream) -- waits for torch's current stream first, so whatever wrote them is done before the encoder
+        reads."""
         aX, aK = _Arg(X, np.float32, "float32"), _Arg(site_kmers, np.uint8, "uint8")
+        if aX.is_dev or aK.is_dev:
+            import torch
+            cur = torch.cuda.current_stream(self.device)
+            if getattr(self, "_torch_stream", None) != cur.cuda_stream:
+                cur.synchronize()
+            self._job_keep.append((aX.keep, aK.keep))
         o = off if (isinstance(off, np.ndarray) and off.dtype == np.int64 and off.flags.c_contiguous) else \
             np.ascontiguousarray(off.cpu().numpy() if _is_torch(off) else off, dtype=np.int64)
         n = o.size - 1
@@ -339,11 +354,18 @@ class M6ANetEngine:
         mod = self._out(dev, S, np.float64, "float64")
         aP = _Arg(rp, np.float32, "float32") if rp is not None else None
         aS, aM = _Arg(site, np.float32, "float32"), _Arg(mod, np.float64, "float64")
-        self._chk(self._L.m6a_job_end(self._h, aP.ptr if aP else None, aS.ptr, aM.ptr))
+        try:
+            self._chk(self._L.m6a_job_end(self._h, aP.ptr if aP else None, aS.ptr, aM.ptr))     # synchronises: every encoder has read its rows
+        finally:
+            self._job_keep = []
         return rp, site, mod
 
     def job_abort(self):
-        self._chk(self._L.m6a_job_abort(self._h))
+        try:
+            self._chk(self._L.m6a_job_abort(self._h))
+            self.sync()                                      # queued encoders may still be reading device batches
+        finally:
+            self._job_keep = []
 
     def forward(self, X, kmer, bag=N_SAMPLES):
         """Site probability of fixed-size bags: X [B, bag, 9], kmer [B, 3] -> [B]."""

@@ -47,7 +47,9 @@ def build():
              '-DM6A_MT_JUMP_PATH="%s"' % os.path.join(REPO, "m6anet_amd", "assets", "mt19937_jump.bin"),
              "-I" + os.path.join(REPO, "include"), "-I" + CSRC]
     objs = []
-    for f in ("m6a_kernels.hip", "m6a_pool_reg.hip", "m6a_api.hip"):
+    sys.path.insert(0, REPO)
+    from m6anet_amd.build import SOURCES
+    for f in [x for x in SOURCES if x != "m6a_pool_rtab.hip"]:
         o = os.path.join(KO, "rt_" + f.replace(".hip", ".o"))
         if not os.path.exists(o) or os.path.getmtime(o) < os.path.getmtime(os.path.join(CSRC, f)):
             subprocess.check_call([hipcc] + flags + ["-c", os.path.join(CSRC, f), "-o", o])
