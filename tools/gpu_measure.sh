@@ -29,12 +29,13 @@ rocprofv3 --hip-trace --kernel-trace --memory-copy-trace --output-format csv -d 
 python tools/first_call_timeline.py $O/${T}_tl > $O/${T}_first_call_timeline.txt 2>&1
 python tools/first_call_probe.py > $O/${T}_first_call.json 2> $O/${T}_first_call.err
 # microbenchmarks behind the ceilings, the stream generator, the feed API from plain C
-./tools/gpr_variants > $O/${T}_gpr_variants.txt 2>&1
+./tools/valu_rate_bench > $O/${T}_valu_rate.json 2>&1
 ./tools/rg_probe > $O/${T}_rg_probe.txt 2>&1
 python tools/stream_probe.py > $O/${T}_stream.json 2> $O/${T}_stream.err
 { ./tools/feed_probe 20000 16; ./tools/feed_probe 20000 1024; ./tools/feed_probe 1000000 16 20 20; ./tools/feed_probe 1000000 4096 20 20; } > $O/${T}_feed_probe.json 2>&1
 python tools/measure_misc.py > $O/${T}_misc.json 2> $O/${T}_misc.err
 python tools/measure_cli.py > $O/${T}_cli.json 2> $O/${T}_cli.err
+bash tools/measure_cli_gpus.sh > $O/${T}_cli_gpus.json 2>> $O/${T}_cli.err
 find $O -name "*.db" -path "*${T}_*" -size +20M -delete
 find $O -path "*${T}_tl*" -size +10M -delete
 echo done
