@@ -59,6 +59,7 @@ __device__ __forceinline__ int wave_sum_i32(int v)
 // (tools/valu_rate_bench, profiles/r04_valu_rate.json) -- the encoder issues 92 of them per tile on the datapath its f32
 // MFMAs use, and |x| is a free source modifier of v_add_f32: encoder 2.093 -> 2.065 ms.  (Rounds 1-3 used one v_max_i32 on
 // the float's bits; fmaxf() costs two VALU ops, a canonicalising v_max first; v_max_f32 through inline asm pins the schedule.)
+// One difference at infinity: a pre-activation of -inf gives -inf + inf = NaN where max gives 0 -- it takes |x * w| beyond 3e38 to get there.
 __device__ __forceinline__ float relu2(float x)
 {
     return x + __builtin_fabsf(x);
