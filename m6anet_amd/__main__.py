@@ -1,9 +1,15 @@
 """`python -m m6anet_amd {dataprep,pack,inference} ...` -- the hot path and the steps before it
 (dispatcher shape of m6anet/__init__.py:11-30)."""
 import sys
-from argparse import ArgumentParser
 
-from .scripts import dataprep, inference, pack
+from . import _early
+
+if __name__ == "__main__":
+    _early.maybe_start(sys.argv[1:])        # `inference --gpus N`: the other ranks start before the heavy imports below
+
+from argparse import ArgumentParser  # noqa: E402
+
+from .scripts import dataprep, inference, pack  # noqa: E402
 
 
 def main(argv=None):

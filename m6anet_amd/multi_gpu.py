@@ -32,6 +32,8 @@ import time
 
 import numpy as np
 
+from . import _early
+from ._early import exchange_base, store_size_estimate  # noqa: F401  (re-exported: tests and docs name them here)
 from .constants import DEFAULT_MIN_READS, N_SAMPLES
 from .data_utils import STORE_SUFFIX, open_store, pack_sites
 from .engine import M6ANetEngine, comm_unique_id, device_count, reference_written_sites, shard_plan
@@ -78,37 +80,6 @@ def exchange_mode(world):
 # ---------------------------------------------------------------------------------------------------------------
 # launcher
 # ---------------------------------------------------------------------------------------------------------------
-def store_size_estimate(input_dirs):
-    """Upper estimate of the packed store: the normalised features (36 B per read) and the ids are about 0.45 of the JSON
-    text they were parsed from (913 MB of data.json -> 384 MB); 0.6 + 64 MB leaves room."""
-    total = 0
-    for d in input_dirs:
-        for fn in ("data.json", "data.info"):
-            try:
-                total += os.path.getsize(os.path.join(str(d), fn))
-            except OSError:
-                pass
-    return int(0.6 * total) + (64 << 20)
-
-
-def exchange_base(need_bytes, out_dir):
-    """Where the exchange directory (RCCL id, byte counts, and the packed store unless the input already is one) goes:
-    M6A_XDIR_BASE if set; /dev/shm when it is writable AND has room for the store with a margin (Docker's default /dev/shm
-    is 64 MB, and a tmpfs store is RAM next to every rank's page-cache mapping of it); else the system's temporary
-    directory if IT has room; else the output directory."""
-    forced = os.environ.get("M6A_XDIR_BASE")
-    if forced:
-        return forced
-    candidates = ["/dev/shm", tempfile.gettempdir(), os.path.abspath(str(out_dir))]
-    for c in candidates:
-        try:
-            if not (os.path.isdir(c) and os.access(c, os.W_OK)):
-                continue
-            if shutil.disk_usage(c).free >= 1.25 * need_bytes + (16 << 20):
-                return c
-        except OSError:
-            continue
-    return None                                              # tempfile's default; pack_sites will say what went wrong
 def rank_argv(args):
     """The command line of a rank: the launcher's own options (the pretrained-model defaults are resolved again there)."""
     argv = ["--input_dir"] + [str(d) for d in args.input_dir] + ["--out_dir", str(args.out_dir)]
@@ -127,11 +98,15 @@ def launch(args, weights):
     M6A_STORE in the environment), packs the store if the input is not one, runs its own shard, and waits for the others --
     no interpreter start-up sits between the command and rank 0's work.  Returns the exit code."""
     world = int(args.gpus)
-    argv = rank_argv(args)
-    exchange_mode(world)                                   # fails early, with the reason
-    given_store = len(args.input_dir) == 1 and str(args.input_dir[0]).endswith(STORE_SUFFIX)
-    xdir = tempfile.mkdtemp(prefix="m6a_gpus_", dir=exchange_base(0 if given_store else store_size_estimate(args.input_dir), args.out_dir))
-    procs = []
+    # ranks 1..N-1 were normally started by m6anet_amd/_early.py, before this process imported NumPy; if not (the CLI called
+    # as a function), they are started here
+    st = _early.state
+    if st is None or st["world"] != world:
+        _early.cleanup()
+        exchange_mode(world)                               # fails before anything is started, with the reason
+        st = _early.start_ranks(world, [str(d) for d in args.input_dir], args.out_dir, rank_argv(args))
+    xdir, store, given_store, procs = st["xdir"], st["store"], st["given_store"], st["procs"]
+    exchange_mode(world)                                   # more ranks than devices etc.: the `finally` below ends the early ranks
     # a terminated launcher still takes its ranks down and removes the exchange directory (a packed store can be hundreds of MB
     # of /dev/shm): SIGTERM becomes an exception, so the `finally` below runs
     import signal
@@ -157,11 +132,7 @@ def launch(args, weights):
                 sys.stderr.flush()
                 os._exit(bad[0] if 0 < bad[0] < 256 else 1)
     try:
-        store = os.path.abspath(args.input_dir[0]) if given_store else os.path.join(xdir, "job" + STORE_SUFFIX)
         rank_env = dict(M6A_WORLD=str(world), M6A_XDIR=xdir, M6A_STORE=store)
-        for r in range(1, world):
-            procs.append(subprocess.Popen([sys.executable, "-m", "m6anet_amd", "inference"] + list(argv),
-                                          env=dict(os.environ, M6A_RANK=str(r), **rank_env)))
         threading.Thread(target=watch, daemon=True).start()
         # rank 0's GPU context comes up on a thread while the store is packed, like the other ranks' in their processes
         made = {}
@@ -195,10 +166,7 @@ def launch(args, weights):
         return _wait_all(procs)
     finally:
         stop.set()
-        for p in procs:
-            if p.poll() is None:
-                p.kill()
-        shutil.rmtree(xdir, ignore_errors=True)
+        _early.cleanup()                                     # kills what is still running, removes the exchange directory
 
 
 def _wait_all(procs):
