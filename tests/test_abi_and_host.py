@@ -224,3 +224,34 @@ def test_bundled_weights_halve_exactly(weights):
         assert np.array_equal(half * np.float32(2.0), tail), name
         nz = np.abs(tail[tail != 0])
         assert nz.min() > 2.0 ** -100, (name, float(nz.min()))
+
+
+def test_early_rank_start_helpers(tmp_path, monkeypatch):
+    """m6anet_amd/_early.py (standard library only: it runs before the heavy imports of `python -m m6anet_amd`): option
+    scanning, the exchange directory's home, and the cases in which it must NOT start anything."""
+    from m6anet_amd import _early
+    argv = ["--input_dir", "a", "b", "--out_dir", "o", "--gpus=3", "--num_iterations", "5"]
+    assert _early._values(argv, "--input_dir") == ["a", "b"] and _early._values(argv, "--gpus") == ["3"]
+    assert _early._values(argv, "--out_dir") == ["o"] and _early._values(argv, "--seed") is None
+    (tmp_path / "d").mkdir()
+    (tmp_path / "d" / "data.json").write_bytes(b"x" * 1000)
+    assert _early.store_size_estimate([tmp_path / "d"]) == 600 + (64 << 20)
+    # a store that fits nowhere but the output directory's file system ends there or nowhere; an override wins
+    assert _early.exchange_base(1 << 62, str(tmp_path)) is None
+    assert _early.exchange_base(0, str(tmp_path)) in ("/dev/shm", __import__("tempfile").gettempdir(), str(tmp_path))
+    monkeypatch.setenv("M6A_XDIR_BASE", str(tmp_path))
+    assert _early.exchange_base(1 << 62, "/nonexistent") == str(tmp_path)
+    monkeypatch.delenv("M6A_XDIR_BASE")
+    # nothing is started: not inference, one GPU, a rank itself, help, more ranks than render nodes without the host transport
+    for av, env in ((["dataprep", "--gpus", "2"], {}), (["inference", "--input_dir", "a", "--out_dir", "o"], {}),
+                    (["inference", "--input_dir", "a", "--out_dir", "o", "--gpus", "1"], {}),
+                    (["inference", "--input_dir", "a", "--out_dir", "o", "--gpus", "2"], {"M6A_RANK": "1"}),
+                    (["inference", "--input_dir", "a", "--out_dir", "o", "--gpus", "2", "--help"], {}),
+                    (["inference", "--input_dir", "a", "--out_dir", "o", "--gpus", "63"], {}),
+                    (["inference", "--input_dir", "a", "--gpus", "2"], {"M6A_EXCHANGE": "host"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        _early.maybe_start(av)
+        assert _early.state is None, av
+        for k in env:
+            monkeypatch.delenv(k)
