@@ -197,6 +197,36 @@ def _wait_all(procs):
 # ---------------------------------------------------------------------------------------------------------------
 # one rank
 # ---------------------------------------------------------------------------------------------------------------
+def write_rows_sharded(native, out_dir, xdir, rank, world, a, b, read_prob, site_prob, mod_ratio, n_write, parent):
+    """Every rank writes the rows of ITS sites [a, b) (clipped to the first n_write sites of the job: the reference's row set may
+    end inside or before this shard): they are formatted once to learn their size, the sizes meet in the exchange directory
+    (16 bytes per rank), and each rank pwrite()s its rows at its offset into the two CSVs -- N hosts' worth of formatting and
+    write() instead of rank 0's alone, and nobody holds the job's 4 B per read.  `native` = the mapped sites (_io.NativeSites);
+    the arrays hold the shard's values.  Rank 0 returns when every rank's rows are in the files."""
+    from ._io import usable_cpus
+    off = native.off
+    wa, wb = min(a, n_write), min(b, n_write)
+    nr = int(off[wb] - off[wa])
+    threads = max(1, usable_cpus() // world)                 # the ranks share one host: each formats on its share of the CPUs
+    rp, sp, mr = read_prob[:nr], site_prob[:wb - wa], mod_ratio[:wb - wa]
+    sizes = native.csv_shard_size(wa, wb, rp, sp, mr, n_threads=threads)
+    _publish(os.path.join(xdir, "csv_size%d" % rank), np.array(sizes, np.int64).tobytes())
+    all_sizes = np.zeros((world, 2), np.int64)
+    for r in range(world):
+        p = os.path.join(xdir, "csv_size%d" % r)
+        _wait_for(p, "rank %d's CSV sizes" % r, parent)
+        all_sizes[r] = np.fromfile(p, np.int64, 2)
+    head = np.array(native.csv_header_bytes(), np.int64)
+    start = head + all_sizes[:rank].sum(axis=0)
+    totals = head + all_sizes.sum(axis=0)
+    native.csv_shard_write(out_dir, wa, wb, rp, sp, mr, int(start[0]), int(start[1]),
+                           header_and_totals=(int(totals[0]), int(totals[1])) if rank == 0 else None, n_threads=threads)
+    _publish(os.path.join(xdir, "csv_done%d" % rank), b"1")
+    if rank == 0:
+        for r in range(world):
+            _wait_for(os.path.join(xdir, "csv_done%d" % r), "rank %d's rows" % r, parent)
+
+
 def run_rank(args, weights, engine=None):
     rank, world = int(os.environ["M6A_RANK"]), int(os.environ["M6A_WORLD"])
     xdir, store = os.environ["M6A_XDIR"], os.environ["M6A_STORE"]
@@ -252,33 +282,12 @@ def run_rank(args, weights, engine=None):
                 site_all[cuts[r]:cuts[r + 1]] = raw[8 * ns:12 * ns].view(np.float32)
     engine.close()
 
-    # ---- every rank writes the rows of ITS sites: they are formatted once to learn their size, the sizes meet in the exchange
-    # directory (16 bytes per rank), and each rank pwrite()s its rows at its offset into the two CSVs -- N hosts' worth of
-    # formatting and write() instead of rank 0's alone, and nobody holds the job's 4 B per read
     n_write = batch.n_sites
     if getattr(args, "drop_unflushed_tail", False):
         n_write = reference_written_sites(batch.n_sites, args.batch_size, args.save_per_batch)
-    wa, wb = min(a, n_write), min(b, n_write)                # the reference's row set may end inside (or before) this shard
-    nr = int(off[wb] - off[wa])
-    from ._io import usable_cpus
-    threads = max(1, usable_cpus() // world)                 # the ranks share one host: each formats on its share of the CPUs
-    sizes = batch.native.csv_shard_size(wa, wb, read_prob[:nr], site_prob[:wb - wa], mod_ratio[:wb - wa], n_threads=threads)
-    _publish(os.path.join(xdir, "csv_size%d" % rank), np.array(sizes, np.int64).tobytes())
-    all_sizes = np.zeros((world, 2), np.int64)
-    for r in range(world):
-        p = os.path.join(xdir, "csv_size%d" % r)
-        _wait_for(p, "rank %d's CSV sizes" % r, parent)
-        all_sizes[r] = np.fromfile(p, np.int64, 2)
-    head = np.array(batch.native.csv_header_bytes(), np.int64)
-    start = head + all_sizes[:rank].sum(axis=0)
-    totals = head + all_sizes.sum(axis=0)
-    batch.native.csv_shard_write(args.out_dir, wa, wb, read_prob[:nr], site_prob[:wb - wa], mod_ratio[:wb - wa], int(start[0]), int(start[1]),
-                                 header_and_totals=(int(totals[0]), int(totals[1])) if rank == 0 else None, n_threads=threads)
-    _publish(os.path.join(xdir, "csv_done%d" % rank), b"1")
+    write_rows_sharded(batch.native, args.out_dir, xdir, rank, world, a, b, read_prob, site_prob, mod_ratio, n_write, parent)
     if rank == 0:
-        # rank 0 is the job: it leaves when every rank's rows are in the files, and checks the gathered site results against
-        # what it can see of them (its own shard) -- the launcher's exit code is the job's
-        for r in range(world):
-            _wait_for(os.path.join(xdir, "csv_done%d" % r), "rank %d's rows" % r, parent)
+        # rank 0 is the job: it checks the gathered site results against what it can see of them (its own shard) -- its exit
+        # code is the job's
         if not (np.array_equal(site_all[a:b], site_prob) and np.array_equal(mod_all[a:b], mod_ratio, equal_nan=True)):
             raise RuntimeError("the gathered site results do not contain rank 0's own shard")

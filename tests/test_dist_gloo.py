@@ -78,3 +78,47 @@ def test_site_gather_single_rank_odd_count():
         assert torch.equal(s_all, site) and torch.equal(m_all, mod)
     finally:
         dist.destroy_process_group()
+
+
+def _sharded_writer_rank(rank, world, xdir, out_dir, cuts, seed):
+    import numpy as np
+    from m6anet_amd import _io, data_utils, multi_gpu
+    data = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_tests_data")
+    nat = _io.NativeSites([data], 20, data_utils.load_norm_factors("norm_hct116.npz"), 1)
+    S, R = nat.tx_pos.size, nat.X.shape[0]
+    g = np.random.Generator(np.random.PCG64(seed))
+    rp, sp, mr = g.random(R, dtype=np.float32), g.random(S, dtype=np.float32), g.random(S)
+    a, b = cuts[rank], cuts[rank + 1]
+    off = nat.off
+    multi_gpu.write_rows_sharded(nat, out_dir, xdir, rank, world, a, b, rp[off[a]:off[b]].copy(), sp[a:b].copy(), mr[a:b].copy(),
+                                 n_write=90, parent=os.getppid())
+
+
+def test_ranks_write_their_rows_concurrently(tmp_path):
+    """The output protocol of `inference --gpus N` on CPU, real processes: four ranks map the same sites, publish the byte
+    counts of their rows in the exchange directory, and pwrite() concurrently into the two CSVs -- with the reference's row set
+    ending inside the third shard (n_write = 90 of 101 sites: the last rank writes nothing).  The files are m6a_io_write_csv's."""
+    import multiprocessing as mp
+    import numpy as np
+    from m6anet_amd import _io, data_utils
+    data = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_tests_data")
+    nat = _io.NativeSites([data], 20, data_utils.load_norm_factors("norm_hct116.npz"), 1)
+    S, R = nat.tx_pos.size, nat.X.shape[0]
+    g = np.random.Generator(np.random.PCG64(11))
+    rp, sp, mr = g.random(R, dtype=np.float32), g.random(S, dtype=np.float32), g.random(S)
+    one = tmp_path / "one"
+    one.mkdir()
+    nat.write_csv(str(one), rp, sp, mr, write_header=True, n_sites=90)
+    xdir, out = tmp_path / "x", tmp_path / "out"
+    xdir.mkdir()
+    out.mkdir()
+    cuts = [0, 32, 64, 96, 101]
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_sharded_writer_rank, args=(r, 4, str(xdir), str(out), cuts, 11)) for r in (3, 1, 2, 0)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for fn in ("data.site_proba.csv", "data.indiv_proba.csv"):
+        assert (out / fn).read_bytes() == (one / fn).read_bytes(), fn
