@@ -44,6 +44,7 @@ enum { M6A_RNG_NUMPY = 0 /* exact replay of the reference's NumPy stream */ };
 #define M6A_N_WEIGHTS 7997
 #define M6A_N_FEATURES 9     /* [dwell, std, mean] x {-1,0,+1}: DeaggregateNanopolish, blocks.py:113 */
 #define M6A_MAX_SAMPLES 64
+#define M6A_N_KMERS 66       /* vocabulary of 5-mers the DRACH 7-mers are made of (constants.py:29-36): k-mer ids are 0..65 */
 
 /* Flat float32 weight blob, in this order (state-dict keys of m6anet/model/model.py:40-69,
  * files under m6anet/model/model_states/):
@@ -143,6 +144,11 @@ int m6a_infer(m6a_ctx *ctx, const float *X, const uint8_t *site_kmers, const int
 int m6a_job_begin(m6a_ctx *ctx, int n_iters, int n_samples, float read_proba_threshold, uint32_t seed, int rng_mode,
                   int64_t batch_size, int64_t save_per_batch, int64_t expect_sites, int64_t expect_reads);
 int m6a_job_feed(m6a_ctx *ctx, const float *X, const uint8_t *site_kmers, const int64_t *off, int64_t n_sites);
+/* The same batch in the layout the reference's loader hands its loop -- inference_collate's first three tensors
+ * (m6anet/utils/data_utils.py:498-506): features f32 [r][9], kmers int64 [r][3] (every read repeats its site's three
+ * vocabulary ids, :221-224), n_reads int64 [n] -- so a reference-side binding passes three data_ptr()s and converts
+ * nothing.  HOST pointers only; ids outside 0..65 are M6A_EINVAL. */
+int m6a_job_feed_collated(m6a_ctx *ctx, const float *features, const int64_t *kmers, const int64_t *n_reads, int64_t n_sites);
 int m6a_job_size(const m6a_ctx *ctx, int64_t *n_sites, int64_t *n_reads);
 int m6a_job_end(m6a_ctx *ctx, float *read_prob, float *site_prob, double *mod_ratio);
 int m6a_job_abort(m6a_ctx *ctx);

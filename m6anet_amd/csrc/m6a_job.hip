@@ -253,6 +253,48 @@ int m6a_job_feed(m6a_ctx *c, const float *X, const uint8_t *km, const int64_t *o
     return rc;
 }
 
+int m6a_job_feed_collated(m6a_ctx *c, const float *features, const int64_t *kmers, const int64_t *n_reads, int64_t n_sites)
+{
+    settle(c);
+    if (!c) return M6A_EINVAL;
+    auto &j = c->job;
+    if (!j.open) return fail(c, M6A_EINVAL, "no streaming job is open (m6a_job_begin)");
+    if (j.failed) { c->err = j.failed_msg; return j.failed; }
+    if (n_sites < 0) return fail(c, M6A_EINVAL, "n_sites < 0");
+    if (n_sites == 0) return M6A_OK;
+    if (!n_reads || !kmers) return fail(c, M6A_EINVAL, "null pointer argument");
+    int rc;
+    try {
+        // inference_collate's layout -> the library's: CSR offsets from n_reads, one k-mer row per SITE from the per-read rows
+        // (every read of a site repeats its site's three ids, data_utils.py:221-224: the first read's row is the site's)
+        static thread_local std::vector<int64_t> off;
+        static thread_local std::vector<uint8_t> km;
+        off.resize((size_t)n_sites + 1);
+        km.resize((size_t)n_sites * 3);
+        off[0] = 0;
+        for (int64_t s = 0; s < n_sites; s++) {
+            if (n_reads[s] < 0) return fail(c, M6A_EINVAL, "n_reads[%lld] < 0", (long long)s);
+            off[(size_t)s + 1] = off[(size_t)s] + n_reads[s];
+        }
+        const int64_t R = off[(size_t)n_sites];
+        if (R > 0 && !features) return fail(c, M6A_EINVAL, "null pointer argument");
+        if (R > 0 && is_device_ptr(features)) return fail(c, M6A_EINVAL, "m6a_job_feed_collated takes the collate's HOST tensors");
+        for (int64_t s = 0; s < n_sites; s++)
+            for (int q = 0; q < 3; q++) {
+                // a site without reads has no row of its own in `kmers`: its ids are never used (id 0 stands in)
+                const int64_t v = n_reads[s] > 0 ? kmers[off[(size_t)s] * 3 + q] : 0;
+                if (v < 0 || v >= M6A_N_KMERS) return fail(c, M6A_EINVAL, "k-mer id %lld outside the %d-word vocabulary", (long long)v, M6A_N_KMERS);
+                km[(size_t)s * 3 + (size_t)q] = (uint8_t)v;
+            }
+        HIPCHK(c, hipSetDevice(c->device));
+        rc = job_feed_impl(c, features, km.data(), off.data(), n_sites, false);
+    } catch (const std::bad_alloc &) {
+        rc = fail(c, M6A_ENOMEM, "out of host memory");
+    }
+    if (rc) { j.failed = rc; j.failed_msg = c->err; }
+    return rc;
+}
+
 int m6a_job_size(const m6a_ctx *c, int64_t *n_sites, int64_t *n_reads)
 {
     if (!c) return M6A_EINVAL;

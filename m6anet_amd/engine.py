@@ -339,6 +339,16 @@ class M6ANetEngine:
         self._job_dev = self._job_dev or aX.is_dev
         self._chk(self._L.m6a_job_feed(self._h, aX.ptr, aK.ptr, o.ctypes.data, n))
 
+    def job_feed_collated(self, features, kmers, n_reads):
+        """One batch exactly as the reference's inference_collate builds it (m6anet/utils/data_utils.py:498-506): features
+        [r,9] float32, kmers [r,3] int64 (per READ), n_reads [n] int64 -- host tensors or arrays; nothing is converted here."""
+        aX, aK, aN = _Arg(features, np.float32, "float32"), _Arg(kmers, np.int64, "int64"), _Arg(n_reads, np.int64, "int64")
+        if aX.is_dev or aK.is_dev or aN.is_dev:
+            raise TypeError("job_feed_collated takes the collate's host tensors")
+        if aK.size * 3 != aX.size:
+            raise ValueError("batch shapes disagree: features [r, 9], kmers [r, 3]")
+        self._chk(self._L.m6a_job_feed_collated(self._h, aX.ptr, aK.ptr, aN.ptr, aN.size))
+
     def job_size(self):
         S, R = C.c_int64(), C.c_int64()
         self._chk(self._L.m6a_job_size(self._h, C.byref(S), C.byref(R)))

@@ -62,6 +62,43 @@ def test_job_stream_equals_infer(eng, bag, S, T, batch):
         assert g.dtype == w.dtype and np.array_equal(g, w), name
 
 
+def test_job_feed_collated_is_the_collate_layout(eng):
+    """m6a_job_feed_collated takes what inference_collate returns (m6anet/utils/data_utils.py:498-506): features [r,9] f32,
+    kmers [r,3] int64 per READ, n_reads [n] int64 -- as numpy arrays or host torch tensors -- and gives the job m6a_job_feed
+    gives, bit for bit; empty sites among the batches, ids outside the vocabulary and device tensors are handled / refused."""
+    import torch
+    from m6anet_amd import _lib
+    g = np.random.Generator(np.random.PCG64(3))
+    bags = g.integers(16, 80, size=2500)
+    bags[::211] = 0
+    d = synthetic.make_sites(len(bags), seed=9, n_reads=bags)
+    kw = dict(n_iters=150, read_proba_threshold=THR, seed=2, batch_size=16, save_per_batch=2)
+    want = feed_in_batches(eng, d, 16, **kw)
+    X, km, off = d["X"], d["site_kmers"], d["off"]
+    for as_torch in (False, True):
+        eng.job_begin(**kw)
+        for s0 in range(0, len(bags), 16):
+            s1 = min(len(bags), s0 + 16)
+            n = np.diff(off[s0:s1 + 1])
+            kp = np.repeat(km[s0:s1].astype(np.int64), n, axis=0)
+            f = X[off[s0]:off[s1]]
+            if as_torch:
+                eng.job_feed_collated(torch.from_numpy(f), torch.from_numpy(kp), torch.from_numpy(n))
+            else:
+                eng.job_feed_collated(f, kp, n)
+        got = eng.job_end()
+        for a, b in zip(got, want):
+            assert np.array_equal(a, b, equal_nan=True)
+    eng.job_begin(**kw)
+    with pytest.raises(_lib.M6AError, match="vocabulary"):
+        eng.job_feed_collated(X[:20], np.full((20, 3), 66, np.int64), np.array([20], np.int64))
+    eng.job_abort()
+    eng.job_begin(**kw)
+    with pytest.raises(TypeError):
+        eng.job_feed_collated(torch.from_numpy(X[:20]).cuda(), torch.zeros((20, 3), dtype=torch.int64), torch.tensor([20]))
+    eng.job_abort()
+
+
 def test_job_stream_small_and_empty_bags(eng, orc, weights):
     """Bags below 16 reads, single reads and empty sites among the batches: a chunk then takes the general encoder
     where the whole-job call might not, so read probabilities are held to the oracle's bar and the pooling to
