@@ -213,6 +213,27 @@ def test_pool_uniform_table_vs_oracle(eng, orc, n, T):
         assert np.array_equal(mod, want_mod), name
 
 
+@pytest.mark.parametrize("n", [4, 8, 12, 16, 20, 24, 28, 32])
+@pytest.mark.parametrize("shift", [0, 1, 2, 3])
+def test_pool_register_kernel_quad_loads_at_any_dword_alignment(eng, orc, n, shift):
+    """pool_reg_kernel loads bags of n % 4 == 0 reads with global_load_dwordx4; the read-probability array a caller hands
+    over is only dword-aligned in general (a view into a larger device buffer, a rank's slice of a job): every alignment
+    mod 16 bytes, device pointers, against the oracle bit for bit."""
+    import torch
+    S = 700
+    off = np.arange(S + 1, dtype=np.int64) * n
+    p = rand_probs(n * 10 + shift, off)
+    want_site, want_mod = orc.site_pool(p, off, 130, THR, seed=1)
+    buf = torch.zeros(p.size + 8, dtype=torch.float32, device="cuda")
+    view = buf[shift:shift + p.size]
+    view.copy_(torch.from_numpy(p))
+    assert view.data_ptr() % 16 == (buf.data_ptr() + 4 * shift) % 16
+    with table_variant(eng, 2):
+        site, mod = eng.calculate_site_proba(view, torch.from_numpy(off).cuda(), 130, 20, THR, seed=1)
+    assert eng.last_pool_variant == "table-reg"
+    assert same_sites(site.cpu().numpy(), want_site) and np.array_equal(mod.cpu().numpy(), want_mod)
+
+
 @pytest.mark.parametrize("bags", [
     [33] * 40, [64] * 35, [65] * 33, [1000] * 3, [1024, 1025, 1500, 20], [4096, 20, 4097, 30], [3000, 25] * 20 + [4096], [20, 21] * 30,
     [1, 2, 1, 20, 1, 40], list(range(20, 84)), [2048, 20, 4097],
