@@ -95,6 +95,12 @@ int64_t m6a_io_csv_header_bytes(int which);
  * returns the length.  Exported so the tests can pin it against printf. */
 int m6a_io_format_f16(double v, char *buf336);
 
+/* How dataprep prints a float into data.json: Python's repr(float) -- what ujson / json.dump write in the reference
+ * (dataprep_utils.py:473-480) -- shortest digits that round-trip, positional for 1e-4 <= |v| < 1e16, exponent form
+ * otherwise.  buf40 holds >= 40 bytes, NUL-terminated; returns the length.  Exported so the tests can pin it against
+ * Python's own repr. */
+int m6a_io_py_repr(double v, char *buf40);
+
 /* `m6anet dataprep` (m6anet/scripts/dataprep.py:54-70 -> m6anet/utils/dataprep_utils.py):
  * eventalign.txt -> <out_dir>/eventalign.index (parallel_index, :187-266), data.json + data.info +
  * data.log (combine :269-325, filter_events :19-168, preprocess_tx :399-488).  Same arithmetic as

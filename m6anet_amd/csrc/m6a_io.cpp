@@ -947,6 +947,15 @@ void py_repr(double v, std::string &out)
     if (v == 0) { out += std::signbit(v) ? "-0.0" : "0.0"; return; }
     if (!std::isfinite(v)) { out += std::isnan(v) ? "NaN" : (v < 0 ? "-Infinity" : "Infinity"); return; }
     char buf[64];
+    const double av = std::fabs(v);
+    if (av >= 1e-4 && av < 1e16) {
+        // repr's fixed-notation range: the shortest digits that round-trip, written positionally -- exactly what
+        // std::to_chars(fixed) without a precision produces; an integral value gets its ".0"
+        auto r = std::to_chars(buf, buf + sizeof buf, v, std::chars_format::fixed);
+        if (std::memchr(buf, '.', (size_t)(r.ptr - buf)) == nullptr) { *r.ptr++ = '.'; *r.ptr++ = '0'; }
+        out.append(buf, (size_t)(r.ptr - buf));
+        return;
+    }
     auto r = std::to_chars(buf, buf + sizeof buf, v, std::chars_format::scientific);   // shortest, d.ddde+XX
     std::string sci(buf, r.ptr);
     size_t epos = sci.find('e');
@@ -1042,11 +1051,31 @@ bool combine_read(const char *p, const char *e, std::vector<Pos> &out)
             // reference_kmer == model_kmer  (dataprep_utils.py:287)
             if ((en[2] - b[2]) == (en[9] - b[9]) && memcmp(b[2], b[9], (size_t)(en[2] - b[2])) == 0) {
                 Ev ev;
-                double pos, st, ed;
-                Cursor c1{b[1], en[1]}, c6{b[6], en[6]}, c7{b[7], en[7]}, c8{b[8], en[8]}, c13{b[13], en[13]}, c14{b[14], en[14]};
-                if (!c1.num(pos) || !c6.num(ev.mean) || !c7.num(ev.sd) || !c8.num(ev.len_s) || !c13.num(st) || !c14.num(ed)) return false;
-                ev.position = (long long)pos;
-                ev.length = (long long)ed - (long long)st;
+                // position, start_idx, end_idx are integers in every eventalign.txt (pandas reads them as int64): plain digits
+                // take the integer path, anything else (a sign, a dot, an exponent) the general number parser
+                auto int_field = [](const char *p, const char *e, long long &out) {
+                    if (p >= e || e - p > 18) return false;
+                    long long v = 0;
+                    for (const char *q = p; q < e; ++q) {
+                        if (*q < '0' || *q > '9') return false;
+                        v = v * 10 + (*q - '0');
+                    }
+                    out = v;
+                    return true;
+                };
+                auto any_field = [&](const char *p, const char *e, long long &out) {
+                    if (int_field(p, e, out)) return true;
+                    double d;
+                    Cursor c{p, e};
+                    if (!c.num(d)) return false;
+                    out = (long long)d;
+                    return true;
+                };
+                long long st, ed;
+                Cursor c6{b[6], en[6]}, c7{b[7], en[7]}, c8{b[8], en[8]};
+                if (!any_field(b[1], en[1], ev.position) || !c6.num(ev.mean) || !c7.num(ev.sd) || !c8.num(ev.len_s) ||
+                    !any_field(b[13], en[13], st) || !any_field(b[14], en[14], ed)) return false;
+                ev.length = ed - st;
                 ev.kmer.assign(b[2], en[2]);
                 evs.push_back(std::move(ev));
             }
@@ -1172,7 +1201,12 @@ void preprocess_transcript(const char *base, size_t file_size, const std::string
                     py_repr(compress ? np_round(v, 1000.0) : v, o.json);
                     o.json += ',';
                 }
-                py_repr((double)sites[k].read, o.json);
+                if (sites[k].read >= 0 && sites[k].read < (1LL << 53)) {      // repr(float(int)): the digits and ".0"
+                    char ib[24];
+                    const int n = format_i64(sites[k].read, ib);
+                    o.json.append(ib, (size_t)n);
+                    o.json += ".0";
+                } else py_repr((double)sites[k].read, o.json);
                 o.json += ']';
             }
             o.json += "]}}}\n";
@@ -1243,6 +1277,15 @@ void on_threads(int nw, int n_items, F &&f)
 }
 
 }  // namespace
+
+extern "C" int m6a_io_py_repr(double v, char *buf40)
+{
+    std::string s;
+    py_repr(v, s);
+    if (s.size() >= 40) return -1;
+    std::memcpy(buf40, s.c_str(), s.size() + 1);
+    return (int)s.size();
+}
 
 extern "C" int m6a_io_dataprep(const char *eventalign_path, const char *out_dir, int n_threads,
                                int readcount_min, int readcount_max, int min_segment_count, int n_neighbors,

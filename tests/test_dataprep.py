@@ -188,3 +188,28 @@ def test_read_with_non_contiguous_lines_documented_divergence(tmp_path):
     assert sum(int(r[3]) - int(r[2]) for r in ours if r[1] == "82387") == int(r87[3]) - int(r87[2])
     # every row that does not touch the two reads is the same in both
     assert [r for r in ours if r[1] not in ("82387", "82388")] == [r for r in ref if r[1] not in ("82387", "82388")]
+
+
+def test_float_text_is_pythons_repr():
+    """data.json holds repr(float) (json.dump in the reference, dataprep_utils.py:473-480): 400 000 doubles -- random bit
+    patterns, decimal-looking values of every magnitude from 1e-320 to 1e300, integers around 2**53, the 1e-4 / 1e16
+    boundaries of repr's two notations, signed zeros, non-finite values in json's spelling."""
+    import ctypes as C
+    L = _io.load()
+    buf = C.create_string_buffer(40)
+    g = np.random.Generator(np.random.PCG64(1))
+    vals = list(g.integers(0, 2**64 - 1, size=150_000, dtype=np.uint64).view(np.float64))
+    vals += list(np.round(g.normal(100, 30, 60_000), 2)) + list(np.round(g.random(60_000) * 0.02, 5)) + list(g.random(30_000) * 10.0 ** g.integers(-320, 300, 30_000))
+    vals += list(g.integers(-2**60, 2**60, 50_000).astype(np.float64)) + [float(2**53 + k) for k in range(-5, 6)]
+    for e in range(-6, 18):
+        for m in (1.0, 0.9999999999999999, 1.0000000000000002, 9.999999999999999, 5.0, 1.5):
+            vals += [m * 10.0 ** e, -m * 10.0 ** e]
+    vals += [0.0, -0.0, 1e-4, 9.999e-5, 1e16, 9999999999999998.0, 123456789012345.6, 5e-324, 1.7976931348623157e308]
+    bad = []
+    for v in vals:
+        v = float(v)
+        n = L.m6a_io_py_repr(v, buf)
+        want = repr(v) if np.isfinite(v) else ("NaN" if np.isnan(v) else ("Infinity" if v > 0 else "-Infinity"))
+        if n < 0 or buf.value.decode() != want:
+            bad.append((v.hex(), buf.value.decode(), want))
+    assert not bad, bad[:5]
