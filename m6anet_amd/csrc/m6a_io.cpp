@@ -1450,7 +1450,13 @@ extern "C" int m6a_io_dataprep(const char *eventalign_path, const char *out_dir,
     setvbuf(fi, ibuf.data(), _IOFBF, ibuf.size());
     fputs("transcript_id,transcript_position,start,end,n_reads\n", fi);
     const int nw = n_workers(n_threads, NT);
-    const int64_t window = std::max<int64_t>(64, (int64_t)nw * 8);
+    // How far the workers may run ahead of the writer is bounded by the BYTES of finished-but-unwritten JSON, not by a
+    // transcript count: transcripts differ in size by orders of magnitude, and with a window of 8 per thread everybody
+    // stood waiting behind each large one (16 threads were 7 x one thread; profiles/r04_dataprep_sweep.txt)
+    const char *pb = getenv("M6A_IO_PENDING_MB");
+    const size_t pending_budget = (size_t)(pb && atoll(pb) > 0 ? atoll(pb) : 256) << 20;
+    const int64_t window = std::max<int64_t>(4096, (int64_t)nw * 256);      // and a count, so that `outs` bookkeeping stays small
+    size_t pending_bytes = 0;                          // JSON of deposited, not yet written transcripts (guarded by mu)
     std::vector<std::unique_ptr<TxOut>> outs((size_t)NT);
     std::mutex mu;
     std::condition_variable cv;
@@ -1476,7 +1482,7 @@ extern "C" int m6a_io_dataprep(const char *eventalign_path, const char *out_dir,
             if (t >= NT) break;
             {
                 std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return failed || t < written + window; });
+                cv.wait(lk, [&] { return failed || t == written || (t < written + window && pending_bytes < pending_budget); });
                 if (failed) break;
             }
             std::unique_ptr<TxOut> o(new TxOut);
@@ -1485,6 +1491,8 @@ extern "C" int m6a_io_dataprep(const char *eventalign_path, const char *out_dir,
             std::vector<uint32_t>().swap(tx_rows[(size_t)t]);
             std::unique_lock<std::mutex> lk(mu);
             if (o->rc && !failed) { failed = true; fail_rc = o->rc; fail_msg = o->err; cv.notify_all(); }
+            pending_bytes += o->json.size();
+            peak_pending = std::max(peak_pending, pending_bytes);
             outs[(size_t)t] = std::move(o);
             if (writing || failed) continue;
             // this thread becomes the writer for as long as the next transcript in line is finished
@@ -1494,14 +1502,14 @@ extern "C" int m6a_io_dataprep(const char *eventalign_path, const char *out_dir,
                 const int64_t first = written;
                 int64_t k = written;
                 while (k < NT && outs[(size_t)k]) batch.push_back(std::move(outs[(size_t)k++]));
-                size_t pending = 0;
-                for (int64_t q = k; q < std::min(NT, first + window); q++) if (outs[(size_t)q]) pending += outs[(size_t)q]->json.size();
-                peak_pending = std::max(peak_pending, pending);
+                size_t batch_bytes = 0;
+                for (const auto &bo : batch) batch_bytes += bo->json.size();
                 lk.unlock();
                 for (size_t b = 0; b < batch.size(); b++) write_one(first + (int64_t)b, *batch[b]);
                 batch.clear();
                 lk.lock();
                 written = k;
+                pending_bytes -= batch_bytes;
                 cv.notify_all();
             }
             writing = false;
@@ -1519,6 +1527,6 @@ extern "C" int m6a_io_dataprep(const char *eventalign_path, const char *out_dir,
     if (written != NT) return fail(M6A_IO_EIO, "internal: %lld of %lld transcripts written", (long long)written, (long long)NT);
     if (bad) return fail(M6A_IO_EIO, "cannot close outputs in %s", out_dir);
     trace.mark("dataprep: transcripts");
-    if (trace.on) fprintf(stderr, "m6a_io: dataprep peak of finished-but-unwritten json: %.1f MB (window %lld transcripts)\n", peak_pending / 1e6, (long long)window);
+    if (trace.on) fprintf(stderr, "m6a_io: dataprep peak of finished-but-unwritten json: %.1f MB (budget %.0f MB, window %lld transcripts)\n", peak_pending / 1e6, pending_budget / 1e6, (long long)window);
     return M6A_IO_OK;
 }

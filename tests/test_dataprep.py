@@ -213,3 +213,25 @@ def test_float_text_is_pythons_repr():
         if n < 0 or buf.value.decode() != want:
             bad.append((v.hex(), buf.value.decode(), want))
     assert not bad, bad[:5]
+
+
+def test_workers_run_ahead_by_bytes_and_write_in_order(tmp_path, monkeypatch):
+    """Transcripts are processed on all threads and written in index order as soon as their predecessors are; how far the
+    workers run ahead is a budget of finished-but-unwritten JSON.  With the budget at its minimum (1 MB against ~12 MB of
+    output) and 8 threads the workers block and resume constantly: the three files are those of one thread."""
+    text = gzip.open(os.path.join(REF, "eventalign.txt.gz"), "rt").read()
+    header, body = text.split("\\n", 1)
+    big = tmp_path / "big.txt"
+    with open(big, "w") as f:
+        f.write(header + "\\n")
+        for k in range(30):
+            f.write(body.replace("ENST", "C%dENST" % k) if k else body)
+    one = str(tmp_path / "one")
+    _io.dataprep(str(big), one, n_threads=1, readcount_min=1, readcount_max=1000, min_segment_count=5)
+    assert os.path.getsize(os.path.join(one, "data.json")) > 8 << 20
+    monkeypatch.setenv("M6A_IO_PENDING_MB", "1")
+    monkeypatch.setenv("M6A_IO_INDEX_RANGE_KB", "256")
+    out = str(tmp_path / "t8")
+    _io.dataprep(str(big), out, n_threads=8, readcount_min=1, readcount_max=1000, min_segment_count=5)
+    for fn in ("eventalign.index", "data.json", "data.info", "data.log"):
+        assert open(os.path.join(out, fn), "rb").read() == open(os.path.join(one, fn), "rb").read(), fn
