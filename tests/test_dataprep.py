@@ -220,10 +220,10 @@ def test_workers_run_ahead_by_bytes_and_write_in_order(tmp_path, monkeypatch):
     workers run ahead is a budget of finished-but-unwritten JSON.  With the budget at its minimum (1 MB against ~12 MB of
     output) and 8 threads the workers block and resume constantly: the three files are those of one thread."""
     text = gzip.open(os.path.join(REF, "eventalign.txt.gz"), "rt").read()
-    header, body = text.split("\\n", 1)
+    header, body = text.split("\n", 1)
     big = tmp_path / "big.txt"
     with open(big, "w") as f:
-        f.write(header + "\\n")
+        f.write(header + "\n")
         for k in range(30):
             f.write(body.replace("ENST", "C%dENST" % k) if k else body)
     one = str(tmp_path / "one")
