@@ -116,7 +116,7 @@ int m6a_io_py_repr(double v, char *buf40);
  * lengths of all rows of a key per chunk instead, which only differs for reads whose lines are not contiguous --
  * tests/golden/dataprep_noncontiguous pins that divergence); files over 2 GB (M6A_IO_POPULATE_MAX_MB) are mapped
  * lazily; a transcript's records are written as soon as every earlier transcript's are, so memory holds the index
- * (32 B per read) and a bounded window of finished transcripts, never the whole data.json.  M6A_IO_TRACE=1 prints
+ * (32 B per read) and at most M6A_IO_PENDING_MB (256) of finished-but-unwritten records, never the whole data.json.  M6A_IO_TRACE=1 prints
  * the phases. */
 int m6a_io_dataprep(const char *eventalign_path, const char *out_dir, int n_threads,
                     int readcount_min, int readcount_max, int min_segment_count, int n_neighbors,

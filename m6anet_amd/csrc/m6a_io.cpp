@@ -1385,6 +1385,7 @@ extern "C" int m6a_io_dataprep(const char *eventalign_path, const char *out_dir,
             if (c.runs.size() > (c.drop_first ? 1u : 0u)) open_c = &c;
         }
         if (total > 0xffffffffull) return fail(M6A_IO_EINVAL, "more than 2^32 index rows");
+        trace.mark("dataprep: index names merged");
         idx.resize(total);
         // every range fills its rows of the index; their text is formatted and written a batch of ranges at a time, so the
         // index file (a tenth of the eventalign.txt) never sits in memory as a whole
@@ -1397,6 +1398,7 @@ extern "C" int m6a_io_dataprep(const char *eventalign_path, const char *out_dir,
             }
             std::vector<LocalRun>().swap(c.runs);
         });
+        trace.mark("dataprep: index rows filled");
         // the index file: a batch of ranges is formatted on all threads, then every range pwrite()s its own text at its offset
         // (one thread's write() of the 2.6 GB index of a 21 GB file was a sixth of the whole run)
         const int fd = ::open(idx_path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
@@ -1443,7 +1445,7 @@ extern "C" int m6a_io_dataprep(const char *eventalign_path, const char *out_dir,
         if (::close(fd) != 0) io_ok = false;
         if (!io_ok) return fail(M6A_IO_EIO, "cannot write %s", idx_path.c_str());
     }
-    trace.mark("dataprep: index stitched + written");
+    trace.mark("dataprep: index file written");
     if (ev.p && ev.n) (void)madvise((void *)ev.p, ev.n, MADV_NORMAL);       // the transcript pass jumps between a read's runs
 
     // ---- transcripts in order of first appearance (= id order), with their index rows in file order
@@ -1457,6 +1459,7 @@ extern "C" int m6a_io_dataprep(const char *eventalign_path, const char *out_dir,
     }
     for (size_t i = 0; i < idx.size(); i++) tx_rows[idx[i].tx].push_back((uint32_t)i);
 
+    trace.mark("dataprep: rows per transcript");
     // ---- per transcript on all threads, written in transcript order AS SOON AS every earlier one is written: memory holds a
     // bounded window of finished transcripts, not the whole data.json
     FILE *fj = fopen((dir + "/data.json").c_str(), "w"), *fi = fopen((dir + "/data.info").c_str(), "w"), *fl = fopen((dir + "/data.log").c_str(), "w");
