@@ -719,6 +719,17 @@ int m6a_io_write_csv(const m6a_sites *s, const char *out_dir, const float *read_
 
 namespace {
 
+template <class F>
+void on_threads_io(int nw, int n_items, F &&f)
+{
+    std::atomic<int> next{0};
+    auto worker = [&]() { for (int k; (k = next.fetch_add(1)) < n_items;) f(k); };
+    std::vector<std::thread> th;
+    for (int t = 1; t < std::min(nw, n_items); t++) th.emplace_back(worker);
+    worker();
+    for (auto &t : th) t.join();
+}
+
 // The rows of sites [i0, i1) appended to `a` (data.site_proba.csv) and `b` (data.indiv_proba.csv).  read_prob / site_prob /
 // mod_ratio hold the values of sites [site_base, ...) and reads [read_base, ...): the whole job (bases 0) or one rank's shard.
 void format_rows(const m6a_sites *s, int64_t i0, int64_t i1, const float *read_prob, const float *site_prob, const double *mod_ratio,
@@ -781,9 +792,9 @@ const char kIndivHeader[] = "transcript_id,transcript_position,read_index,probab
 // Sites [A, B) formatted on all threads a round of chunks at a time (chunks of at most 2^20 reads bound the text held in
 // memory, ~64 MB per worker; at least 2^14 so tiny jobs do not spawn idle threads); `sink(site_text, indiv_text)` gets the
 // chunks in site order.
-template <class Sink>
-int format_site_range(const m6a_sites *s, int64_t A, int64_t B, const float *read_prob, const float *site_prob, const double *mod_ratio,
-                      int64_t site_base, int64_t read_base, int n_threads, Sink &&sink)
+template <class RoundSink>
+int format_site_rounds(const m6a_sites *s, int64_t A, int64_t B, const float *read_prob, const float *site_prob, const double *mod_ratio,
+                       int64_t site_base, int64_t read_base, int n_threads, RoundSink &&round_sink)
 {
     const int nw = n_workers(n_threads, B - A);
     const int64_t R = s->vOff[B] - s->vOff[A];
@@ -809,13 +820,51 @@ int format_site_range(const m6a_sites *s, int64_t A, int64_t B, const float *rea
         for (int w = 1; w < nc; w++) th.emplace_back(work, w);
         work(0);
         for (auto &t : th) t.join();
-        for (int w = 0; w < nc; w++) {
-            const int rc = sink(site_txt[(size_t)w], indiv_txt[(size_t)w]);       // the sink may move the strings out
-            if (rc) return rc;
-        }
+        const int rc = round_sink(site_txt, indiv_txt, nw);                        // the chunks of one round, in site order
+        if (rc) return rc;
         s_begin = cuts.back();
     }
     return 0;
+}
+
+// ... with a sink per chunk, called in site order (it may move the strings out)
+template <class Sink>
+int format_site_range(const m6a_sites *s, int64_t A, int64_t B, const float *read_prob, const float *site_prob, const double *mod_ratio,
+                      int64_t site_base, int64_t read_base, int n_threads, Sink &&sink)
+{
+    return format_site_rounds(s, A, B, read_prob, site_prob, mod_ratio, site_base, read_base, n_threads,
+                              [&](std::vector<std::string> &a, std::vector<std::string> &b, int) {
+                                  for (size_t w = 0; w < a.size(); w++) {
+                                      const int rc = sink(a[w], b[w]);
+                                      if (rc) return rc;
+                                  }
+                                  return 0;
+                              });
+}
+
+// every chunk of a round pwrite()n at its offset by its own thread: the page-cache copy of a 436 MB data.indiv_proba.csv
+// is worth several threads (one thread's write() was most of the writer's time)
+bool pwrite_all(int fd, const char *p, size_t n, int64_t at)
+{
+    while (n) {
+        const ssize_t w = ::pwrite(fd, p, n, (off_t)at);
+        if (w < 0) { if (errno == EINTR) continue; return false; }
+        p += w; n -= (size_t)w; at += w;
+    }
+    return true;
+}
+
+int pwrite_round(int fd_site, int fd_indiv, const std::vector<std::string> &a, const std::vector<std::string> &b, int64_t &at_site, int64_t &at_indiv, int nw)
+{
+    const size_t nc = a.size();
+    std::vector<int64_t> oa(nc), ob(nc);
+    for (size_t w = 0; w < nc; w++) { oa[w] = at_site; at_site += (int64_t)a[w].size(); ob[w] = at_indiv; at_indiv += (int64_t)b[w].size(); }
+    std::atomic<bool> ok{true};
+    on_threads_io(std::min<int>(nw, (int)nc), (int)nc, [&](int w) {
+        if (!pwrite_all(fd_site, a[(size_t)w].data(), a[(size_t)w].size(), oa[(size_t)w]) ||
+            !pwrite_all(fd_indiv, b[(size_t)w].data(), b[(size_t)w].size(), ob[(size_t)w])) ok = false;
+    });
+    return ok ? 0 : M6A_IO_EIO;
 }
 
 int check_range(const m6a_sites *s, int64_t a, int64_t b)
@@ -835,22 +884,33 @@ int m6a_io_write_csv_n(const m6a_sites *s, const char *out_dir, const float *rea
     if (!s || !out_dir || !read_prob || !site_prob || !mod_ratio) return fail(M6A_IO_EINVAL, "null argument");
     const int64_t S = n_sites_limit >= 0 ? std::min<int64_t>(n_sites_limit, m6a_io_n_sites(s)) : m6a_io_n_sites(s);
     const std::string fs = std::string(out_dir) + "/data.site_proba.csv", fi = std::string(out_dir) + "/data.indiv_proba.csv";
-    FILE *f = fopen(fs.c_str(), write_header ? "w" : "a");
-    if (!f) return fail(M6A_IO_EIO, "cannot open %s", fs.c_str());
-    FILE *g = fopen(fi.c_str(), write_header ? "w" : "a");
-    if (!g) { fclose(f); return fail(M6A_IO_EIO, "cannot open %s", fi.c_str()); }
+    const int flags = O_WRONLY | O_CREAT | (write_header ? O_TRUNC : 0);
+    const int f = ::open(fs.c_str(), flags, 0644);
+    if (f < 0) return fail(M6A_IO_EIO, "cannot open %s", fs.c_str());
+    const int g = ::open(fi.c_str(), flags, 0644);
+    if (g < 0) { ::close(f); return fail(M6A_IO_EIO, "cannot open %s", fi.c_str()); }
+    int64_t at_site = 0, at_indiv = 0;
+    bool ok = true;
     if (write_header) {
-        fputs(kSiteHeader, f);
-        fputs(kIndivHeader, g);
+        ok = pwrite_all(f, kSiteHeader, sizeof(kSiteHeader) - 1, 0) && pwrite_all(g, kIndivHeader, sizeof(kIndivHeader) - 1, 0);
+        at_site = (int64_t)sizeof(kSiteHeader) - 1; at_indiv = (int64_t)sizeof(kIndivHeader) - 1;
+    } else {                                                   // append: behind whatever the files hold
+        struct stat st;
+        ok = fstat(f, &st) == 0;
+        at_site = ok ? (int64_t)st.st_size : 0;
+        ok = ok && fstat(g, &st) == 0;
+        at_indiv = ok ? (int64_t)st.st_size : 0;
     }
-    // rows are formatted in parallel into per-chunk strings, written in order
-    int rc = format_site_range(s, 0, S, read_prob, site_prob, mod_ratio, 0, 0, n_threads, [&](std::string &a, std::string &b) {
-        if (fwrite(a.data(), 1, a.size(), f) != a.size() || fwrite(b.data(), 1, b.size(), g) != b.size())
-            return fail(M6A_IO_EIO, "short write in %s", out_dir);
-        return 0;
-    });
-    if (fclose(f) != 0 && !rc) rc = fail(M6A_IO_EIO, "cannot close %s", fs.c_str());
-    if (fclose(g) != 0 && !rc) rc = fail(M6A_IO_EIO, "cannot close %s", fi.c_str());
+    int rc = ok ? 0 : fail(M6A_IO_EIO, "cannot write into %s", out_dir);
+    // rows are formatted on all threads a round of chunks at a time; every chunk is written at its offset by its own thread
+    if (!rc)
+        rc = format_site_rounds(s, 0, S, read_prob, site_prob, mod_ratio, 0, 0, n_threads,
+                                [&](std::vector<std::string> &a, std::vector<std::string> &b, int nw) {
+                                    if (pwrite_round(f, g, a, b, at_site, at_indiv, nw)) return fail(M6A_IO_EIO, "short write in %s", out_dir);
+                                    return 0;
+                                });
+    if (::close(f) != 0 && !rc) rc = fail(M6A_IO_EIO, "cannot close %s", fs.c_str());
+    if (::close(g) != 0 && !rc) rc = fail(M6A_IO_EIO, "cannot close %s", fi.c_str());
     return rc;
 }
 
@@ -912,18 +972,14 @@ int m6a_io_csv_shard_write(const m6a_sites *s, const char *out_dir, const float 
     m6a_sites::CsvKeep &keep = const_cast<m6a_sites *>(s)->csv_keep;
     if (ok && keep.a == site_begin && keep.b == site_end && keep.rp == read_prob && keep.sp == site_prob && keep.mr == mod_ratio) {
         // the text m6a_io_csv_shard_size formatted a moment ago
-        for (size_t i = 0; i < keep.site.size() && ok; i++) {
-            ok = put(f, keep.site[i].data(), keep.site[i].size(), sa) && put(g, keep.indiv[i].data(), keep.indiv[i].size(), sb);
-            sa += (int64_t)keep.site[i].size(); sb += (int64_t)keep.indiv[i].size();
-        }
+        ok = pwrite_round(f, g, keep.site, keep.indiv, sa, sb, n_workers(n_threads, (int64_t)keep.site.size())) == 0;
         keep.clear();
     } else if (ok)
-        rc = format_site_range(s, site_begin, site_end, read_prob, site_prob, mod_ratio, site_begin, s->vOff[site_begin], n_threads,
-                               [&](std::string &a, std::string &b) {
-                                   if (!put(f, a.data(), a.size(), sa) || !put(g, b.data(), b.size(), sb)) return fail(M6A_IO_EIO, "short write in %s", out_dir);
-                                   sa += (int64_t)a.size(); sb += (int64_t)b.size();
-                                   return 0;
-                               });
+        rc = format_site_rounds(s, site_begin, site_end, read_prob, site_prob, mod_ratio, site_begin, s->vOff[site_begin], n_threads,
+                                [&](std::vector<std::string> &a, std::vector<std::string> &b, int nw) {
+                                    if (pwrite_round(f, g, a, b, sa, sb, nw)) return fail(M6A_IO_EIO, "short write in %s", out_dir);
+                                    return 0;
+                                });
     if (::close(f) != 0) ok = false;
     if (::close(g) != 0) ok = false;
     if (!ok && !rc) rc = fail(M6A_IO_EIO, "cannot write into %s", out_dir);
