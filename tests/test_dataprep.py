@@ -235,3 +235,38 @@ def test_workers_run_ahead_by_bytes_and_write_in_order(tmp_path, monkeypatch):
     _io.dataprep(str(big), out, n_threads=8, readcount_min=1, readcount_max=1000, min_segment_count=5)
     for fn in ("eventalign.index", "data.json", "data.info", "data.log"):
         assert open(os.path.join(out, fn), "rb").read() == open(os.path.join(one, fn), "rb").read(), fn
+
+
+def test_dataprep_edge_files(tmp_path):
+    """Header only; a last line without its newline; CRLF line ends; a single read: the indexer's byte ranges stay exact and
+    nothing is lost or invented."""
+    text = gzip.open(os.path.join(REF, "eventalign.txt.gz"), "rt").read()
+    header, body = text.split("\n", 1)
+    lines = body.rstrip("\n").split("\n")
+    # header only
+    p = tmp_path / "h.txt"
+    p.write_text(header + "\n")
+    out = str(tmp_path / "h")
+    _io.dataprep(str(p), out, n_threads=2)
+    assert open(os.path.join(out, "eventalign.index")).read() == "transcript_id,read_index,pos_start,pos_end\n"
+    assert open(os.path.join(out, "data.info")).read() == "transcript_id,transcript_position,start,end,n_reads\n"
+    assert open(os.path.join(out, "data.json")).read() == ""
+    # the first 600 events, with and without the final newline, and with CRLF: same index rows (CRLF: longer lines), same sites
+    base = header + "\n" + "\n".join(lines[:600])
+    res = {}
+    for tag, txt in (("nl", base + "\n"), ("nonl", base), ("crlf", (base + "\n").replace("\n", "\r\n"))):
+        p = tmp_path / (tag + ".txt")
+        p.write_bytes(txt.encode())
+        out = str(tmp_path / tag)
+        _io.dataprep(str(p), out, n_threads=3, readcount_min=1, readcount_max=1000, min_segment_count=1)
+        idx = [l.split(",") for l in open(os.path.join(out, "eventalign.index")).read().splitlines()[1:]]
+        blob = p.read_bytes()
+        for tx, read, a, b in idx:                                   # every row is exactly one read's whole lines
+            seg = blob[int(a):int(b)]
+            assert seg and all(l.split(b"\t")[0].decode() == tx and l.split(b"\t")[3].decode() == read for l in seg.splitlines())
+        assert int(idx[-1][3]) == len(blob) and int(idx[0][2]) == len(header) + (2 if tag == "crlf" else 1)
+        res[tag] = (len(idx), records(open(os.path.join(out, "data.json")).read()))
+    assert res["nl"][0] == res["nonl"][0] == res["crlf"][0] > 5
+    for tag in ("nonl", "crlf"):
+        got, want = res[tag][1], res["nl"][1]
+        assert got[1] == want[1] and all(np.array_equal(got[0][k][1], want[0][k][1]) for k in want[0])
