@@ -188,7 +188,7 @@ def host_cpu_facts():
 
 
 def cpu_calibration():
-    """tools/calibrate_cpu_baseline.py (build container, imports the reference): oracle vs the reference's own NumPy / torch
+    """tests/golden/calibrate_cpu_baseline.py (build container, imports the reference): oracle vs the reference's own NumPy / torch
     code on the same inputs, one thread.  BASELINE.md section 3: the port stands for the reference within +-10 % or this factor."""
     path = os.path.join(REPO, "profiles", "r04_cpu_calibration.json")
     try:

@@ -5,7 +5,7 @@ import os
 import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("M6A_IO_LIB") or os.path.join(_PKG, "libm6a_io.so")   # M6A_IO_LIB: e.g. the sanitizer build (tools/sanitize.sh)
+LIB_PATH = os.environ.get("M6A_IO_LIB") or os.path.join(_PKG, "libm6a_io.so")   # M6A_IO_LIB: e.g. the sanitizer build (tests/sanitize.sh)
 SYMBOLS = ["m6a_io_last_error", "m6a_io_load_sites", "m6a_io_free", "m6a_io_n_sites", "m6a_io_n_reads",
            "m6a_io_n_replicates", "m6a_io_X", "m6a_io_site_kmers", "m6a_io_off", "m6a_io_tx_pos",
            "m6a_io_read_ids", "m6a_io_read_rep", "m6a_io_tx_id", "m6a_io_kmer5", "m6a_io_write_csv", "m6a_io_write_csv_n", "m6a_io_csv_shard_size", "m6a_io_csv_shard_write", "m6a_io_csv_header_bytes", "m6a_io_format_f16", "m6a_io_py_repr",

@@ -7,7 +7,7 @@ tests/golden/make_golden.py -- times both on the SAME inputs, one thread each, a
                get_read_representation + probability_layer per 16-site batch (:33-37), torch on one thread
     oracle     oracle/m6a_oracle.c through oracle/m6a_oracle.py, n_threads = 1
 
-    python tools/calibrate_cpu_baseline.py        # -> profiles/r04_cpu_calibration.json
+    python tests/golden/calibrate_cpu_baseline.py        # -> profiles/r04_cpu_calibration.json
 
 bench.py's cpu_baseline carries the factor (`calibration`, `reference_equivalent_value` = oracle sites/s / factor).
 """
@@ -18,7 +18,7 @@ import tempfile
 import time
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-REPO = os.path.dirname(HERE)
+REPO = os.path.dirname(os.path.dirname(HERE))
 REF = "/root/reference"
 _shim = tempfile.mkdtemp(prefix="m6a_shims_")
 with open(os.path.join(_shim, "toml.py"), "w") as f:

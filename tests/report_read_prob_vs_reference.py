@@ -4,7 +4,7 @@ each encoder kernel and by the oracle, measured DIRECTLY against the reference's
 (tests/golden/reference_at_scale.npz: 1.0 M reads of configs[2], 1.1 M reads of configs[4], four checkpoints), plus the
 end-to-end site-probability distance at T = 1000.  Runs on the GPU box:
 
-    python tools/read_prob_vs_reference.py > gpurun_out/r04_read_prob_vs_reference.json
+    python tests/report_read_prob_vs_reference.py > gpurun_out/r04_read_prob_vs_reference.json
 """
 import json
 import os
@@ -28,7 +28,7 @@ def use(got, want):
 
 
 def main():
-    from oracle import m6a_oracle as orc      # the checker, reported beside the kernels (tools/, not the product)
+    from oracle import m6a_oracle as orc      # the checker, reported beside the kernels (tests/: the oracle is test infrastructure)
     G = np.load(os.path.join(REPO, "tests", "golden", "reference_at_scale.npz"))
     out = {"bar": "rtol 1e-5, atol 1e-8 (m6anet/tests/test_inference.py:32); use = |got-ref| / (atol + rtol*|ref|)",
            "reference": "tests/golden/make_golden.py --only-scale: encoder per 16-site batch (inference_utils.py:33-37)",

@@ -2,7 +2,7 @@
 # SURVEY.md section 5 / VERDICT r3 item 8: AddressSanitizer + UndefinedBehaviorSanitizer builds of the host-side native code --
 # libm6a_io.so (loader, writers, dataprep), the oracle, tools/feed_probe, and the HOST half of libm6a_hip.so (device code is
 # not instrumented: -fno-gpu-sanitize) -- and the whole CPU test suite run against them.
-#   tools/sanitize.sh            -> profiles/r04_sanitizers.txt
+#   tests/sanitize.sh            -> profiles/r04_sanitizers.txt   (under tests/: it builds and runs the oracle, which is test infrastructure)
 set -u
 cd "$(dirname "$0")/.."
 B=build/sanitize
