@@ -1172,7 +1172,11 @@ bool combine_read(const char *p, const char *e, std::vector<Pos> &out)
     return true;
 }
 
-struct IdxRun { uint32_t tx; long long read; int64_t start, end; };      // tx = id in order of first appearance
+struct IdxRun {                                       // tx = id in order of first appearance
+    uint32_t tx; long long read; int64_t start, end;
+    IdxRun() {}                                       // no zero-fill on vector::resize: the rows are first touched by the threads that fill them
+    IdxRun(uint32_t t, long long r, int64_t a, int64_t b) : tx(t), read(r), start(a), end(b) {}
+};
 
 struct SiteRow { long long pos; std::string kmer; long long read; size_t f; };   // f = offset of its 3 (2w+1) features
 
@@ -1415,16 +1419,20 @@ extern "C" int m6a_io_dataprep(const char *eventalign_path, const char *out_dir,
             if (c.rc) return fail(c.rc, "%s: short line at byte %lld", eventalign_path, (long long)c.bad_at);
         // sequential, per RANGE (not per run): contig names into the file-wide table in order of first appearance; a first
         // run that continues the previous range's last one (same contig, same read, adjacent bytes) is folded into it
-        size_t total = 0;
+        size_t total = 0, n_local = 0;
+        for (const auto &c : chunks) n_local += c.names.size();
+        std::unordered_map<std::string_view, uint32_t> view_ids;      // keys are views into the mapping: nothing is copied to look a name up
+        view_ids.reserve(n_local);
+        tx_names.reserve(n_local);
         IndexChunk *open_c = nullptr;                                  // the range holding the file's last run so far
         for (auto &c : chunks) {
             c.global.resize(c.names.size());
             for (size_t i = 0; i < c.names.size(); i++) {
-                auto it = tx_ids.find(std::string(c.names[i]));
-                if (it == tx_ids.end()) {
+                auto it = view_ids.find(c.names[i]);
+                if (it == view_ids.end()) {
                     const uint32_t id = (uint32_t)tx_names.size();
                     tx_names.emplace_back(c.names[i]);
-                    tx_ids.emplace(tx_names.back(), id);
+                    view_ids.emplace(c.names[i], id);
                     c.global[i] = id;
                 } else c.global[i] = it->second;
             }
