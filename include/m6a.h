@@ -8,7 +8,8 @@
  *
  * Conventions
  *   - every function returns M6A_OK (0) or a negative M6A_E* code; m6a_last_error(ctx) gives text;
- *   - the caller owns every buffer; the library keeps no input pointer after a call returns;
+ *   - the caller owns every buffer; the library keeps no input pointer after a call returns (one exception, stated
+ *     there: DEVICE batches of a streaming job are read in place until m6a_job_end / m6a_job_abort);
  *   - data pointers may be HOST or DEVICE pointers (detected with hipPointerGetAttributes):
  *       all-host   -> the library stages through its own device buffers and the call is
  *                     synchronous (results are in the host buffers on return);
