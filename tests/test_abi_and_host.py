@@ -255,3 +255,16 @@ def test_early_rank_start_helpers(tmp_path, monkeypatch):
         assert _early.state is None, av
         for k in env:
             monkeypatch.delenv(k)
+
+
+def test_cpu_baseline_reports_what_the_process_may_use():
+    """bench.py's cpu_baseline states its CPUs honestly: effective_cores = affinity mask cut by the cgroup quota (the GPU boxes
+    lease 16 of 256 logical CPUs), never more than the host has; the product's own thread counts use the same figure."""
+    import bench
+    from m6anet_amd import _io
+    f = bench.host_cpu_facts()
+    assert 1 <= f["effective_cores"] <= f["affinity_cpus"] <= f["logical_cpus"]
+    assert f["cgroup_cpu_quota"] is None or f["effective_cores"] <= int(f["cgroup_cpu_quota"] + 0.5) or f["effective_cores"] == 1
+    assert _io.usable_cpus() <= f["affinity_cpus"] and abs(_io.usable_cpus() - f["effective_cores"]) <= 1
+    cal = bench.cpu_calibration()
+    assert cal is None or 0.5 < cal["oracle_over_reference"]["whole_path"] < 2.0
