@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""One-off, BUILD CONTAINER ONLY (imports the reference like make_golden.py): the reference's read probabilities for ALL
+20 000 000 reads of BASELINE.json configs[2] (this repository's generator), four checkpoints, encoder per 16-site batch
+(m6anet/utils/inference_utils.py:33-37) -> tests/golden/_big/configs2_<model>.npy (80 MB each: git-ignored, but they travel
+to the GPU box with the snapshot).  tests/report_full_size_vs_reference.py compares both HIP encoder kernels with them there
+and writes the summary that IS committed (profiles/r04_full_size_vs_reference.json)."""
+import os
+import sys
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+_shim = tempfile.mkdtemp(prefix="m6a_shims_")
+with open(os.path.join(_shim, "toml.py"), "w") as f:
+    f.write("import tomli\ndef load(p):\n    with open(p,'rb') as f:\n        return tomli.load(f)\n")
+with open(os.path.join(_shim, "ujson.py"), "w") as f:
+    f.write("from json import *\n")
+sys.dont_write_bytecode = True
+sys.path[:0] = [_shim, REF, REPO]
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import toml  # noqa: E402
+from m6anet.model.model import MILModel  # noqa: E402
+from m6anet.utils import constants as C  # noqa: E402
+from m6anet_amd import synthetic  # noqa: E402
+
+MODELS = {"hct116": C.DEFAULT_MODEL_WEIGHTS, "arabidopsis": C.ARABIDOPSIS_MODEL_WEIGHTS,
+          "hek293t_glori": C.HEK293TRNA004_GLORI_MODEL_WEIGHTS, "hek293t_m6ace": C.HEK293TRNA004_M6ACE_MODEL_WEIGHTS}
+
+
+def main():
+    torch.set_num_threads(8)
+    out = os.path.join(HERE, "_big")
+    os.makedirs(out, exist_ok=True)
+    S = 1_000_000
+    d = synthetic.make_sites(S, 20, seed=20250328)
+    X, sk, off = d["X"], d["site_kmers"], d["off"]
+    for name, path in MODELS.items():
+        m = MILModel(toml.load(C.DEFAULT_MODEL_CONFIG))
+        m.load_state_dict(torch.load(path, map_location="cpu"))
+        m.eval()
+        p = np.empty(int(off[-1]), np.float32)
+        with torch.no_grad():
+            for a in range(0, S, 16):
+                b = min(S, a + 16)
+                lo, hi = int(off[a]), int(off[b])
+                kpr = torch.from_numpy(np.repeat(sk[a:b].astype(np.int64), 20, axis=0))
+                f = m.get_read_representation({"X": torch.from_numpy(X[lo:hi]), "kmer": kpr})
+                p[lo:hi] = m.pooling_filter.probability_layer(f).flatten().numpy()
+        np.save(os.path.join(out, "configs2_%s.npy" % name), p)
+        print(name, p.size, float(p.min()), float(p.max()), flush=True)
+        if name in sys.argv[1:]:                       # e.g. `make_full_size_reference.py hek293t_glori`: also the model in float64
+            m = m.double()
+            q = np.empty(int(off[-1]), np.float64)
+            with torch.no_grad():
+                for a in range(0, S, 4096):
+                    b = min(S, a + 4096)
+                    lo, hi = int(off[a]), int(off[b])
+                    kpr = torch.from_numpy(np.repeat(sk[a:b].astype(np.int64), 20, axis=0))
+                    f = m.get_read_representation({"X": torch.from_numpy(X[lo:hi]).double(), "kmer": kpr})
+                    q[lo:hi] = m.pooling_filter.probability_layer(f).flatten().numpy()
+            np.save(os.path.join(out, "configs2_%s_f64.npy" % name), q)
+
+
+if __name__ == "__main__":
+    main()
