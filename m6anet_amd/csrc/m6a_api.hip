@@ -69,57 +69,81 @@ enum { O_E = 0, O_W1 = 132, O_B1 = 2382, O_G = 2532, O_BE = 2682, O_MU = 2832, O
 
 void build_fragments(const float *w, std::vector<float> &frag, std::vector<float> &frag2, std::vector<float> &w1e)
 {
-    // W1aug[160][16]: columns 0..14 = alpha*W1, column 15 = alpha*b1 + (beta - mean*alpha)
-    // (torch eval BatchNorm1d: y*alpha + beta - mean*alpha, alpha = gamma/sqrt(var+eps), blocks.py:250);
-    // row 150 = constant-one unit (carries b2), rows 151..159 = 0.
-    std::vector<float> w1(160 * 16, 0.f), w2(32 * 160, 0.f);
+    // The encoder follows the ORDER OF OPERATIONS of the reference's float32 arithmetic, pinned against torch's own
+    // intermediate tensors (tools/emulate_encoder.py; DESIGN.md section 2 "order of operations"):
+    //   Linear 15 -> 150 : acc = 0; acc = fma(x[k], W1[u][k], acc) for k = 0..14; then acc + b1[u]
+    //   BatchNorm (eval) : alpha = gamma / sqrt(var + eps) as float32, beta = fma(-mean, alpha, bias); fma(y, alpha, beta)
+    //   Linear 150 -> 32 : acc = 0; acc = fma(h[k], W2[o][k], acc) for k = 0..149; then acc + b2[o]
+    // A v_mfma_f32_32x32x2_f32 is two such fmas per output (k = the half-0 lane's operand first), so it is all in WHICH
+    // weight sits in which fragment -- plus the batch norm as one v_fma_f32 per hidden unit in the kernel (it was folded
+    // into W1 until round 4: one rounding fewer than the reference, and 2x its distance from the reference's values).
+    //
+    // W1aug[160][16]: columns 0..14 = W1, column 15 = b1 (the constant-one feature adds it last); row 150 = the
+    // constant-one unit that carries b2 into layer 2 (its batch norm is alpha 1, beta 0); rows 151..159 = 0.
+    std::vector<float> w1(160 * 16, 0.f), w2(32 * 160, 0.f), alpha(160, 0.f), beta(160, 0.f);
     for (int j = 0; j < 150; j++) {
+        for (int k = 0; k < 15; k++) w1[j * 16 + k] = w[O_W1 + 15 * j + k];
+        w1[j * 16 + 15] = w[O_B1 + j];
         const float invstd = 1.0f / std::sqrt(w[O_VAR + j] + 1e-5f);
-        const float alpha = w[O_G + j] * invstd;
-        const float shift = w[O_BE + j] - w[O_MU + j] * alpha;
-        for (int k = 0; k < 15; k++) w1[j * 16 + k] = alpha * w[O_W1 + 15 * j + k];
-        w1[j * 16 + 15] = alpha * w[O_B1 + j] + shift;
+        alpha[j] = w[O_G + j] * invstd;
+        beta[j] = std::fmaf(-w[O_MU + j], alpha[j], w[O_BE + j]);
     }
     w1[150 * 16 + 15] = 1.0f;
+    alpha[150] = 1.0f;
     for (int o = 0; o < 32; o++) {
         for (int k = 0; k < 150; k++) w2[o * 160 + k] = w[O_W2 + 150 * o + k];
         w2[o * 160 + 150] = w[O_B2 + o];
     }
-    // the kernels' ReLU is x + |x| = 2 * relu(x) (one full-rate v_add_f32; max is half rate, m6a_kernels.hip): the 0.5 rides in
-    // the weights that consume the activations -- exact for every normal float (a weight below 2^-125 would lose its last bit:
-    // a contribution under 1e-37 per unit of activation)
-    for (float &v : w2) v *= 0.5f;
+    // Layer 1's ReLU is the clamp modifier of the batch-norm fma on alpha, beta scaled by 2^-64 (m6a_kernels.hip, bn_relu):
+    // layer 2's weights carry the 2^64 back.  Layer 2's ReLU is x + |x| = 2 * relu(x) (one full-rate v_add_f32; max is half
+    // rate): the 0.5 rides in W3.  Powers of two: every product the MFMAs and the epilogue form is the one relu(h) would give.
+    const float bn_scale = 0x1p-64f;
+    for (float &v : alpha) v *= bn_scale;
+    for (float &v : beta) v *= bn_scale;
+    for (float &v : w2) v *= 0x1p+64f;
     const float w3_scale = 0.5f;
+    // Row i of a 32x32 accumulator tile lives in register (i&3) + 4(i>>3) of lane half (i>>2)&1.  Layer 1's row i of unit
+    // tile m is hidden unit 32m + 2q + half, so that layer 2's MFMA q of that tile -- whose two k operands are exactly
+    // register q of the two halves -- adds units 32m + 2q and 32m + 2q + 1, in that order: k = 0, 1, 2, ... 149, then the
+    // constant-one unit 150 (b2, added last as the reference adds it) and the zero unit 151.
+    auto unit_of_row = [](int m, int i) { return 32 * m + 2 * ((i & 3) + 4 * (i >> 3)) + ((i >> 2) & 1); };
     frag.assign(M6A_WFRAG_FLOATS, 0.f);
     for (int lane = 0; lane < 64; lane++) {
         const int col = lane & 31, half = lane >> 5;
         for (int m = 0; m < 5; m++) {
-            for (int st = 0; st < 8; st++)      // A[i=col][k=2st+half] <-> feature st + 8*half
-                frag[(m * 8 + st) * 64 + lane] = w1[(32 * m + col) * 16 + st + 8 * half];
-            for (int q = 0; q < 16; q++) {      // K index = hidden unit held by acc register q
-                const int unit = 32 * m + (q & 3) + 8 * (q >> 2) + 4 * half;
-                frag[(40 + m * 16 + q) * 64 + lane] = w2[col * 160 + unit];
-            }
+            for (int st = 0; st < 8; st++)      // A[i=col][k=half] of step st <-> feature 2st + half
+                frag[(m * 8 + st) * 64 + lane] = w1[unit_of_row(m, col) * 16 + 2 * st + half];
+            for (int q = 0; q < 16; q++)        // A[o=col][k=half] of step q <-> hidden unit 32m + 2q + half
+                frag[(40 + m * 16 + q) * 64 + lane] = w2[col * 160 + 32 * m + 2 * q + half];
         }
-        for (int q = 0; q < 16; q++)
+        for (int q = 0; q < 16; q++)            // layer 2's output rows stay in register order (layer 3's sum has no pinned order)
             frag[(120 + q) * 64 + lane] = w3_scale * w[O_W3 + (q & 3) + 8 * (q >> 2) + 4 * half];
     }
-    // 12-slot kernel: x-slot fragments W1'[u][2st+half] (st<4), W1'[u][8]; and the per-unit rows the
-    // per-site c vectors are folded from: W1'[u][9..14], b1'[u]  (w1 column 15 is the folded bias)
+    // 12-slot kernel: x-slot fragments W1[u][2st+half] (st<4), W1[u][8]; and the per-unit rows the per-site c vectors are
+    // formed from: W1[u][9..14], b1[u]
     frag2.assign(M6A_WFRAG2_FLOATS, 0.f);
-    w1e.assign(M6A_W1E_FLOATS, 0.f);
+    w1e.assign(M6A_W1E_FLOATS + M6A_BN_FLOATS, 0.f);
     for (int lane = 0; lane < 64; lane++) {
         const int col = lane & 31, half = lane >> 5;
         for (int m = 0; m < 5; m++) {
-            for (int st = 0; st < 4; st++) frag2[(m * 4 + st) * 64 + lane] = w1[(32 * m + col) * 16 + 2 * st + half];
-            frag2[(20 + m) * 64 + lane] = w1[(32 * m + col) * 16 + 8];
+            for (int st = 0; st < 4; st++) frag2[(m * 4 + st) * 64 + lane] = w1[unit_of_row(m, col) * 16 + 2 * st + half];
+            frag2[(20 + m) * 64 + lane] = w1[unit_of_row(m, col) * 16 + 8];
         }
     }
     for (int m = 0; m < 5; m++)
         for (int col = 0; col < 32; col++) {
-            for (int e = 0; e < 6; e++) w1e[(m * 7 + e) * 32 + col] = w1[(32 * m + col) * 16 + 9 + e];
-            w1e[(m * 7 + 6) * 32 + col] = w1[(32 * m + col) * 16 + 15];
+            for (int e = 0; e < 6; e++) w1e[(m * 7 + e) * 32 + col] = w1[unit_of_row(m, col) * 16 + 9 + e];
+            w1e[(m * 7 + 6) * 32 + col] = w1[unit_of_row(m, col) * 16 + 15];
         }
+    // batch-norm pairs behind the w1e rows: [m][half][q] -> (alpha, beta) of unit 32m + 2q + half, so that a lane reads the
+    // pairs of registers q, q+1 with one 16-byte LDS load
+    for (int m = 0; m < 5; m++)
+        for (int half = 0; half < 2; half++)
+            for (int q = 0; q < 16; q++) {
+                const int u = 32 * m + 2 * q + half;
+                w1e[M6A_W1E_FLOATS + ((m * 2 + half) * 16 + q) * 2] = alpha[u];
+                w1e[M6A_W1E_FLOATS + ((m * 2 + half) * 16 + q) * 2 + 1] = beta[u];
+            }
 }
 
 // ---- flush groups (inference_utils.py:33,47) --------------------------------------------------
@@ -648,7 +672,7 @@ int launch_encode(m6a_ctx *c, const float *X, const uint8_t *km, const int64_t *
     if (R <= 0 || S <= 0) return M6A_OK;
     EncArgs a;
     a.X = X; a.site_kmers = km; a.off = off; a.wfrag = c->d_wfrag; a.emb = c->d_emb; a.read_prob = rp;
-    a.wfrag2 = c->d_wfrag2; a.w1e_tab = c->d_w1e; a.err = c->d_err;
+    a.wfrag2 = c->d_wfrag2; a.w1e_tab = c->d_w1e; a.bn = c->d_w1e + M6A_W1E_FLOATS; a.err = c->d_err;
     a.n_sites = S; a.n_reads = R; a.n_tiles = (R + 31) / 32; a.b3 = c->b3;
     const int64_t max_waves = (int64_t)c->n_cu * 8;        // 2 blocks/CU x 4 waves
     a.tiles_per_wave = (a.n_tiles + max_waves - 1) / max_waves;

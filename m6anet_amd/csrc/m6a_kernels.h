@@ -8,6 +8,7 @@
 #define M6A_WFRAG_FLOATS (136 * 64)   // 40 (W1) + 80 (W2) + 16 (W3) registers x 64 lanes
 #define M6A_WFRAG2_FLOATS (25 * 64)   // 20 (W1 x-slots) + 5 (W1[:,8]) registers x 64 lanes
 #define M6A_W1E_FLOATS (35 * 32)
+#define M6A_BN_FLOATS (5 * 2 * 16 * 2)  // (alpha, beta) of eval batch norm per hidden unit, [unit tile][lane half][register]
 #define M6A_MEAN_STACK 32             // pairwise-sum merge stack (tree height + 1 fits for any T*K < 2^30)
 #define M6A_CSITE_MIN_BAG 16          // enc_csite_kernel: a 32-read tile must span <= 3 sites
 #define M6A_TABLE_MAX_N 32        // pool_table_kernel: byte offsets 8*idx must fit a byte; pool_reg_kernel: 32 register pairs
@@ -33,7 +34,8 @@ struct EncArgs {
     const int64_t *off;           // [S+1]
     const float *wfrag;           // [136][64] lane-major MFMA weight fragments (16-slot kernel; W2/W3 shared)
     const float *wfrag2;          // [25][64]  layer-1 fragments of the 12-slot kernel
-    const float *w1e_tab;         // [35][32]  W1'[:, 9..14] and b1' per unit, for the per-site c vectors
+    const float *w1e_tab;         // [35][32]  W1[:, 9..14] and b1 per unit, for the per-site c vectors
+    const float *bn;              // [5][2][16][2] batch-norm (alpha, beta) pairs (M6A_BN_FLOATS)
     const float *emb;             // [66][2]
     float *read_prob;             // [R]
     int *err;

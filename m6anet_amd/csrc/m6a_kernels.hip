@@ -1,9 +1,10 @@
 // m6a_kernels.hip -- gfx950 (MI355X / CDNA4) kernels of the m6A inference hot path.
 //
 //   enc_kernel, enc_csite_kernel
-//                      read encoder: [x(9) | emb(6) | 1] -> 150 (BN folded) -> ReLU -> 32 -> ReLU
-//                      -> 1 -> sigmoid, all in registers on v_mfma_f32_32x32x2_f32 (exact f32); the
-//                      csite variant folds the per-site constants (12 K-slots, bags >= 16 reads).
+//                      read encoder: [x(9) | emb(6) | 1] -> 150 -> batch norm -> ReLU -> 32 -> ReLU
+//                      -> 1 -> sigmoid, all in registers on v_mfma_f32_32x32x2_f32 (two IEEE fmas per output, k = the
+//                      half-0 operand first), every sum through layer 2 in the order the reference's float32 arithmetic
+//                      runs it; the csite variant folds the per-site constants (12 K-slots, bags >= 16 reads).
 //   pool_scan_start_kernel + pool_scan_site_kernel, pool_scan_group_kernel
 //                      site pooling, exact NumPy-stream replay, any bag sizes: a counting pass per
 //                      flush group finds where each site starts in the shared MT19937 word stream
@@ -45,24 +46,82 @@ __device__ __forceinline__ int wave_sum_i32(int v)
     return v;
 }
 
-// Accumulator registers of layer-1 unit group m that feed layer 2: register q of a lane holds units
-// 32m + (q&3) + 8(q>>2) + 4*half, so in the last group (units 128..159) registers 12..15 are units 152..159:
-// padding beyond the 150 hidden units and the constant-one unit (150) -- zero weights, skipped (76 instead of
-// 80 layer-2 MFMAs per tile, same bits).
+// Accumulator registers of layer-1 unit group m that feed layer 2: register q of lane half h holds hidden unit
+// 32m + 2q + h (the host wires the units to the tile rows that way, m6a_api.hip build_fragments), so in the last group
+// (units 128..159) registers 12..15 are units 152..159: padding beyond the 150 hidden units, the constant-one unit (150)
+// and its zero partner (151) -- zero weights, skipped (76 instead of 80 layer-2 MFMAs per tile, same bits).
 #define L2_REGS(m) ((m) == 4 ? 12 : 16)
 
-// ReLU, doubled: x + |x| is exactly 2*max(x, 0) (2x for x > 0 -- doubling is exact --, x + (-x) = +0 otherwise, -0 + 0 = +0),
-// and the 0.5 rides in the next layer's weights (W2aug, W3: halving a normal float is exact too), so every product the
-// MFMAs and the epilogue's fmaf chain form is the one they formed before, bit for bit (checked on 2.1 M reads x 4
-// checkpoints x both kernels, tools/compare_encoder_builds.py).  Why: max is a HALF-rate VALU operation on gfx950 --
-// v_max_i32, v_max_f32 and v_med3_f32 all take 4.2-4.9 cycles per wave64 where v_add_f32 / v_mul_f32 take 2.2-2.4
-// (tools/valu_rate_bench, profiles/r04_valu_rate.json) -- the encoder issues 92 of them per tile on the datapath its f32
-// MFMAs use, and |x| is a free source modifier of v_add_f32: encoder 2.093 -> 2.065 ms.  (Rounds 1-3 used one v_max_i32 on
-// the float's bits; fmaxf() costs two VALU ops, a canonicalising v_max first; v_max_f32 through inline asm pins the schedule.)
+// Layer 2's ReLU, doubled: x + |x| is exactly 2*max(x, 0) (2x for x > 0 -- doubling is exact --, x + (-x) = +0 otherwise,
+// -0 + 0 = +0), and the 0.5 rides in W3 (halving a normal float is exact too), so the epilogue's fmaf chain forms the
+// products it would form from max(x, 0).  Why: max is a HALF-rate VALU operation on gfx950 -- v_max_i32, v_max_f32 and
+// v_med3_f32 all take 4.2-4.9 cycles per wave64 where v_add_f32 / v_mul_f32 take 2.2-2.4 (tools/valu_rate_bench,
+// profiles/r04_valu_rate.json) -- on the datapath the f32 MFMAs use, and |x| is a free source modifier of v_add_f32.  (It
+// was layer 1's ReLU too, 92 per tile, until the batch norm moved into the kernel: bn_relu below.  Rounds 1-3 used one
+// v_max_i32 on the float's bits; fmaxf() costs two VALU ops, a canonicalising v_max first.)
 // One difference at infinity: a pre-activation of -inf gives -inf + inf = NaN where max gives 0 -- it takes |x * w| beyond 3e38 to get there.
 __device__ __forceinline__ float relu2(float x)
 {
     return x + __builtin_fabsf(x);
+}
+
+// Eval batch norm + ReLU of a finished layer-1 unit tile, rounded as the reference rounds it: torch's batch_norm on the CPU
+// forms alpha = gamma * invstd and beta = fma(-mean, alpha, bias) once and applies ONE fma(y, alpha, beta) per hidden unit
+// (pinned bit for bit against torch's own tensors, tools/emulate_encoder.py).  Rounds 1-3 folded alpha into W1 on the host:
+// one rounding fewer than the reference, and twice its distance from the reference's values.
+//
+// Batch norm AND ReLU are one VALU instruction: the host scales alpha and beta by 2^-64 (exact), so fma(y, alpha', beta') is
+// exactly 2^-64 * fma(y, alpha, beta), and the instruction's clamp modifier (result to [0, 1]) is the ReLU of every
+// activation below 2^64; layer 2's weights carry the 2^64 back (exact again), so its MFMAs form the very products relu(h)
+// would give.  fma then x + |x| -- two instructions on the datapath the f32 MFMAs use -- cost the 12-slot kernel 3 %
+// (2.202 -> 2.135 ms on the bench shape).  What the trick costs: an activation beyond 2^64 = 1.8e19 saturates there (the
+// reference carries it on towards inf; normalised signal features give |h| < 1e4, tests go to 1e7), and one below 2^-62
+// loses low bits (a contribution under 1e-19).  Both kernels clear MODE.DX10_CLAMP first: with it set (the default for
+// compute kernels) clamp turns NaN into 0, and a NaN feature must come out as a NaN probability, as the reference's does
+// (tests/test_gpu_parity.py::test_encoder_nan_and_huge_features).
+//
+// The (alpha', beta') pairs sit in LDS as [unit tile][lane half][register]: 16 bytes = two hidden units per load, all 32
+// lanes of a half reading the same address (a broadcast, no conflicts).  These 38 loads per tile and their waits are what
+// the reference's order costs: 2.065 -> 2.135 ms for the 12-slot kernel (2.080 with the loads knocked out).  enc_kernel
+// has the 16 registers to run them through a buffer that is always a step ahead -- registers 0..7 of unit tile m are in it
+// when the tile's layer-1 MFMAs have issued; 8..15 are fetched as soon as those are consumed, 0..7 of tile m+1 after that,
+// under the layer-2 MFMAs -- worth 1 %; enc_csite_kernel (245 VGPRs) reads them where it uses them (a two-load head start
+// measured no different).
+__device__ __forceinline__ void clamp_keeps_nan()
+{
+    __builtin_amdgcn_s_setreg(1 | (8 << 6) | (0 << 11), 0);      // hwreg(HW_REG_MODE, offset 8, size 1) = DX10_CLAMP
+}
+__device__ __forceinline__ float bn_relu(float y, float alpha, float beta)
+{
+    float r;
+    asm("v_fma_f32 %0, %1, %2, %3 clamp" : "=v"(r) : "v"(y), "v"(alpha), "v"(beta));
+    return r;
+}
+struct BnBuf { float4 ab[4]; };
+__device__ __forceinline__ void bn_fetch(BnBuf &b, const float *bn, int q0)
+{
+#pragma unroll
+    for (int i = 0; i < 4; i++) b.ab[i] = *(const float4 *)(bn + 2 * q0 + 4 * i);
+}
+__device__ __forceinline__ void bn_relu_buf(f32x16 &t, const BnBuf &b, int q0, int n)
+{
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int q = q0 + 2 * i;
+        if (q >= n) break;
+        t[q] = bn_relu(t[q], b.ab[i].x, b.ab[i].y);
+        t[q + 1] = bn_relu(t[q + 1], b.ab[i].z, b.ab[i].w);
+    }
+}
+__device__ __forceinline__ void bn_relu_lds(f32x16 &t, const float *bn, int n)
+{
+#pragma unroll
+    for (int q = 0; q < 16; q += 2) {
+        if (q >= n) break;
+        const float4 ab = *(const float4 *)(bn + 2 * q);
+        t[q] = bn_relu(t[q], ab.x, ab.y);
+        t[q + 1] = bn_relu(t[q + 1], ab.z, ab.w);
+    }
 }
 
 // A value the program knows to be wave-uniform, made provably so: addresses built from it use
@@ -89,15 +148,20 @@ __device__ __forceinline__ void wave_lds_fence()
 // One wavefront owns a tile of 32 reads.  Everything is computed transposed,
 //     H1^T[160 x 32] = W1aug[160 x 16] . F^T[16 x 32],   H2^T[32 x 32] = W2aug[32 x 160] . H1^T,
 // so the reads sit on the MFMA N axis (lane & 31) in both layers and layer 1's accumulator
-// registers ARE layer 2's B operands: D register q of half h holds hidden unit
-// 32m + (q&3) + 8(q>>2) + 4h for read (lane&31), and an MFMA K-step wants
-// B[k = 2s + h][n = lane&31] -- the K axis of a matmul can be walked in any order, so the
-// weights are pre-permuted on the host to the order the accumulators come in.  No LDS, no
-// shuffles between layers.
-//   F (16 features) = x0..x8, e0..e5 (three 2-float embeddings), 1.0 -- the constant carries
-//   b1 (BatchNorm folded into W1aug/b1 on the host); hidden unit 150 is wired to the constant
-//   1.0 and carries b2 through W2aug[:,150]; units 151..159 are zero padding.
-// Lane halves load different features: h=0 lanes x0..x7, h=1 lanes x8, e0..e5, 1.
+// registers ARE layer 2's B operands: an MFMA K-step takes B[k = h][n = lane&31] from register q of the
+// two lane halves, and D register q of half h holds row (q&3) + 8(q>>2) + 4h of the tile.  WHICH hidden
+// unit a row is, is the host's choice (the rows of W1 can be handed to the MFMA in any order): row -> unit
+// 32m + 2q + h, so that layer 2's step q adds units 32m+2q and 32m+2q+1, in that order -- k = 0, 1, ..., 149,
+// then b2: the order the reference's sgemm adds them in (acc = fma(h[k], W2[o][k], acc), then + b2; pinned
+// against torch's tensors bit for bit, tools/emulate_encoder.py).  No LDS, no shuffles between layers.
+//   F (16 features) = x0..x8, e0..e5 (three 2-float embeddings), 1.0 -- the constant adds b1 last, as the
+//   reference does; batch norm + ReLU is one clamped fma per unit on the finished tile (bn_relu above);
+//   hidden unit 150 is wired to the constant 1.0 (alpha 1, beta 0) and adds b2 through W2aug[:,150];
+//   units 151..159 are zero padding.
+// K slot 2s + h holds feature 2s + h: half 0 lanes load x0, x2, x4, x6, x8, e1, e3, e5; half 1 lanes x1, x3,
+// x5, x7, e0, e2, e4, 1.  With that, layers 1 and 2 of this kernel are the reference's bits; what is left
+// between its read probabilities and the reference's is the 32 -> 1 sum (an MKL gemv there, whose lane order
+// depends on row count and alignment) and the exp.
 // =====================================================================================
 // Input pipeline: the features of tile t+1 are fetched while tile t is on the matrix pipe.  The
 // site lookup is a dependent chain (CSR offsets -> k-mer ids -> embedding rows); its three links
@@ -112,13 +176,17 @@ struct EncTile {
 
 __global__ __launch_bounds__(256, 2) void enc_kernel(EncArgs a)
 {
+    clamp_keeps_nan();
     __shared__ float s_emb[132];
+    __shared__ __attribute__((aligned(16))) float s_bn[M6A_BN_FLOATS];
     for (int i = threadIdx.x; i < 132; i += 256) s_emb[i] = a.emb[i];
+    for (int i = threadIdx.x; i < M6A_BN_FLOATS; i += 256) s_bn[i] = a.bn[i];
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
     const int col = lane & 31;
     const int half = lane >> 5;
+    const float *bn_half = s_bn + half * 32;
     const int64_t wave = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // scalar tile loop
     const int64_t tile0 = wave * a.tiles_per_wave;
     if (tile0 >= a.n_tiles) return;
@@ -169,22 +237,22 @@ __global__ __launch_bounds__(256, 2) void enc_kernel(EncArgs a)
         s = s < last_site ? s : last_site;
         const uint8_t *kp = a.site_kmers + s * 3;
         km[0] = kp[0]; km[1] = kp[1]; km[2] = kp[2];
-        // every lane issues the same 8 loads (no divergent branch, so nothing has to be merged and
-        // waited for here): half 0 reads x0..x7; half 1 reads x8 into x[0] and re-reads x1..x7,
-        // which link 2 overwrites
-        const float *xp = a.X + rc * 9;
-        x[0] = xp[half ? 8 : 0];
+        // K slot 2i + half holds feature 2i + half (the order the reference's dot product adds them in): half 0 loads
+        // x0, x2, x4, x6, x8, half 1 x1, x3, x5, x7 (and x7 again, which link 2 overwrites) -- every lane issues the same
+        // five loads, no divergent branch, so nothing has to be merged and waited for here
+        const float *xp = a.X + rc * 9 + half;
 #pragma unroll
-        for (int i = 1; i < 8; i++) x[i] = xp[i];
+        for (int i = 0; i < 4; i++) x[i] = xp[2 * i];
+        x[4] = xp[half ? 6 : 8];
     };
-    // link 2: embedding rows from LDS
+    // link 2: embedding floats from LDS: features 9..14 = e0..e5 (float c&1 of k-mer c>>1), feature 15 = the constant 1
+    // that adds b1; half 0 takes the odd floats into slots 5..7, half 1 the even ones into slots 4..6
     auto link2 = [&](const int (&km)[3], float (&x)[8]) {
-        if (half == 1) {
-            x[1] = s_emb[2 * km[0]]; x[2] = s_emb[2 * km[0] + 1];
-            x[3] = s_emb[2 * km[1]]; x[4] = s_emb[2 * km[1] + 1];
-            x[5] = s_emb[2 * km[2]]; x[6] = s_emb[2 * km[2] + 1];
-            x[7] = 1.0f;
-        }
+        const float e0 = s_emb[2 * km[0] + 1 - half], e1 = s_emb[2 * km[1] + 1 - half], e2 = s_emb[2 * km[2] + 1 - half];
+        x[4] = half ? e0 : x[4];
+        x[5] = half ? e1 : e0;
+        x[6] = half ? e2 : e1;
+        x[7] = half ? 1.0f : e2;
     };
 
     // prologue: first tile, unpipelined
@@ -199,6 +267,8 @@ __global__ __launch_bounds__(256, 2) void enc_kernel(EncArgs a)
         s_base = uniform_i64(__shfl(s, 31, 64));
     }
 
+    BnBuf bnb;
+    bn_fetch(bnb, bn_half, 0);
     for (int64_t tile = tile0; tile < tile1; ++tile) {
         // the chain always runs (for the last tile it refetches that tile): no guard, no merge
         const int64_t tn = tile + 1 < tile1 ? tile + 1 : tile;
@@ -231,8 +301,11 @@ __global__ __launch_bounds__(256, 2) void enc_kernel(EncArgs a)
             __builtin_amdgcn_sched_barrier(0);
             if (m == 0) link1(tn, s_base, o, sn, km, fn);
             if (m == 2) link2(km, fn);
-#pragma unroll
-            for (int q = 0; q < L2_REGS(m); q++) cur[q] = relu2(cur[q]);
+            bn_relu_buf(cur, bnb, 0, L2_REGS(m));
+            bn_fetch(bnb, bn_half + m * 64, 8);
+            __builtin_amdgcn_sched_barrier(0);
+            bn_relu_buf(cur, bnb, 8, L2_REGS(m));
+            bn_fetch(bnb, bn_half + (m < 4 ? m + 1 : 0) * 64, 0);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int q = 0; q < L2_REGS(m); q++)
@@ -259,14 +332,18 @@ __global__ __launch_bounds__(256, 2) void enc_kernel(EncArgs a)
 // Six of the 16 inputs (the three k-mer embeddings) and the bias are constant per SITE, and a
 // 32-read tile that starts in site `a` ends by site a+2 when bags have >= 16 reads.  Layer 1 is
 // therefore run with K = 12 slots instead of 16:
-//     slots 0..8   the nine signal features, against W1'[:, 0..8];
+//     slots 0..8   the nine signal features, against W1[:, 0..8];
 //     slots 9..11  one-hot "read belongs to site a / a+1 / a+2", against the per-site vectors
-//                  c_s[u] = b1'[u] + sum_e W1'[u][9+e] * emb_e(s)          (exact same terms),
-// i.e. 6 K-steps per unit tile instead of 8: 110 MFMAs per tile instead of 120.  The c vectors
+//                  c_s[u] = b1[u] + sum_e W1[u][9+e] * emb_e(s)            (the same terms),
+// i.e. 6 K-steps per unit tile instead of 8: 106 MFMAs per tile instead of 116.  It is the one place where this
+// kernel's sums leave the reference's order: the reference adds x0..x8, then the six embedding terms, then b1, each an
+// fma on the running sum; here the embedding terms and b1 are summed per site first and enter with ONE addition after x8.
+// Everything after that (batch norm, layer 2) is the reference's order again.  On all 20 M reads of configs[2] x 4
+// checkpoints the worst use of the reference's rtol 1e-5 bar is 0.72 here, 0.53 in enc_kernel (rounds 1-3: 1.06 / 1.05).  The c vectors
 // (A operands of the indicator steps) are rebuilt for every tile on the VALU, in the shadow of the
 // matrix pipe: the 18 embedding floats of the three sites are fetched by lanes 0..17, pulled into
 // (x, y) pairs over the LDS crossbar with ds_bpermute (not a VALU instruction), and folded against
-// W1'[:, 9..14] (kept in LDS, one row per lane) with 30 v_pk_fma_f32 -- two site vectors per FMA.
+// W1[:, 9..14] (kept in LDS, one row per lane) with 30 v_pk_fma_f32 -- two site vectors per FMA.
 // Lane halves: h=0 supplies slots x0,x2,x4,x6,x8,I(a+1); h=1 supplies x1,x3,x5,x7,I(a),I(a+2).
 // Everything else (layer 2, ReLU batching, ping-pong, epilogue, input prefetch chain) is as in
 // enc_kernel.  A tile that would need a fourth site raises the error flag (the host only
@@ -274,10 +351,13 @@ __global__ __launch_bounds__(256, 2) void enc_kernel(EncArgs a)
 // =====================================================================================
 __global__ __launch_bounds__(256, 2) void enc_csite_kernel(EncArgs a)
 {
+    clamp_keeps_nan();
     __shared__ float s_emb[132];
-    __shared__ float s_w1e[35 * 32];             // [m*7 + e][col]: W1'[32m+col][9+e] (e<6), b1'[32m+col] (e=6)
+    __shared__ float s_w1e[35 * 32];             // [m*7 + e][col]: W1[u][9+e] (e<6), b1[u] (e=6), u = the unit of row col of tile m
     for (int i = threadIdx.x; i < 132; i += 256) s_emb[i] = a.emb[i];
     for (int i = threadIdx.x; i < 35 * 32; i += 256) s_w1e[i] = a.w1e_tab[i];
+    __shared__ __attribute__((aligned(16))) float s_bn[M6A_BN_FLOATS];
+    for (int i = threadIdx.x; i < M6A_BN_FLOATS; i += 256) s_bn[i] = a.bn[i];
     // W3 in the order the layer-2 accumulator holds the 32 units: [half][q] (16 VGPRs the tile loop needs more)
     __shared__ float s_w3[32];
     if (threadIdx.x < 64) s_w3[(threadIdx.x >> 5) * 16 + (threadIdx.x & 15)] = a.wfrag[(120 + (threadIdx.x & 15)) * 64 + (threadIdx.x & 32)];
@@ -286,6 +366,7 @@ __global__ __launch_bounds__(256, 2) void enc_csite_kernel(EncArgs a)
     const int lane = threadIdx.x & 63;
     const int col = lane & 31;
     const int half = lane >> 5;
+    const float *bn_half = s_bn + half * 32;
     // Tile and site indices are 32-bit here (the host sends jobs beyond 2^31 sites or tiles to enc_kernel)
     // and wave-uniform: the SALU has 32-bit ordered compares but no 64-bit ones, so 64-bit indices would put
     // every clamp and loop test on the VALU -- at half rate, on the datapath the MFMAs need.
@@ -297,7 +378,7 @@ __global__ __launch_bounds__(256, 2) void enc_csite_kernel(EncArgs a)
     const int n_sites = (int)a.n_sites;
     const int last_lim = (int)(a.n_reads - 1 - (int64_t)(n_tiles - 1) * 32);   // last valid column of the last tile
 
-    // static weight fragments: w1x[m*4+st] = W1'[32m+col][2st+half], w8[m] = W1'[32m+col][8]
+    // static weight fragments: w1x[m*4+st] = W1[u][2st+half], w8[m] = W1[u][8], u = the unit of row col of tile m
     float w1x[20], w8[5], w2[80];
 #pragma unroll
     for (int i = 0; i < 20; i++) w1x[i] = a.wfrag2[i * 64 + lane];
@@ -445,8 +526,7 @@ __global__ __launch_bounds__(256, 2) void enc_csite_kernel(EncArgs a)
             if (m == 0) link1(tn, s_base, o, reln, kidn, fn);
             if (m == 1) link2(kidn, evn);
             if (m == 3) link3(evn, reln, fn[4], f, a4, a5);             // layer1(4) has issued: in place
-#pragma unroll
-            for (int q = 0; q < L2_REGS(m); q++) cur[q] = relu2(cur[q]);
+            bn_relu_lds(cur, bn_half + m * 64, L2_REGS(m));
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int q = 0; q < L2_REGS(m); q++)

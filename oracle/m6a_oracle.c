@@ -9,7 +9,14 @@
  *     np.random.seed(int) does (called at m6anet/scripts/inference.py:86);
  *   - legacy RandomState.randint/choice bounded draw: masked rejection on 32-bit words;
  *   - NumPy's float32 pairwise summation (block 128, 8 accumulators) behind ndarray.mean();
- *   - torch eval-mode BatchNorm1d: y*alpha + (beta - mean*alpha), alpha = gamma/sqrt(var+eps).
+ *   - torch's float32 Linear and eval-mode BatchNorm1d on the CPU, operation by operation (the reference runs them at
+ *     m6anet/model/model_blocks/blocks.py:249-254 through torch.nn): pinned in the build container against torch's own
+ *     intermediate tensors, every candidate order compared bit for bit (tools/emulate_encoder.py):
+ *       Linear      : acc = 0; acc = fma(x[k], W[j][k], acc) for k = 0, 1, 2, ...; then acc + b[j]   (MKL sgemm, any batch >= 7 rows)
+ *       BatchNorm1d : alpha = gamma * (1 / sqrt(var + eps)); beta = fma(-mean, alpha, bias); y -> fma(y, alpha, beta)
+ *     Layers 1 and 2 below reproduce torch's values bit for bit; the 32 -> 1 layer is an MKL gemv whose lane order
+ *     depends on row count and alignment (no fixed order to restate: summed left to right here), and the sigmoid's exp
+ *     is Sleef's in torch, libm's here (1 ulp apart on a few percent of the reads).
  */
 #include "m6a_oracle.h"
 
@@ -120,7 +127,7 @@ static void enc_prepare(const float *w, enc_tables *t)
         for (int k = 0; k < 15; k++) t->w1t[k][j] = w[O_W1 + 15 * j + k];
         float invstd = 1.0f / sqrtf(w[O_VAR + j] + 1e-5f);
         t->alpha[j] = w[O_G + j] * invstd;
-        t->shift[j] = w[O_BE + j] - w[O_MU + j] * t->alpha[j];
+        t->shift[j] = fmaf(-w[O_MU + j], t->alpha[j], w[O_BE + j]);
         t->b1[j] = w[O_B1 + j];
     }
     for (int j = 0; j < 32; j++) {
@@ -132,9 +139,11 @@ static void enc_prepare(const float *w, enc_tables *t)
     t->emb = w + O_E;
 }
 
-__attribute__((target_clones("avx2", "default")))
+/* fmaf is one instruction in the first two clones (any x86 with FMA3: the GPU boxes and the build container have it) and
+ * libm's correctly rounded software fma in the last: same bits, ~35x slower */
+__attribute__((target_clones("avx512f", "fma", "default")))
 static void enc_range(const enc_tables *t, const float *X, const uint8_t *site_kmers,
-                      const int64_t *off, int64_t s0, int64_t s1, float *read_prob)
+                      const int64_t *off, int64_t s0, int64_t s1, float *read_prob, float *hidden, float *logit)
 {
     for (int64_t s = s0; s < s1; s++) {
         float in[15], h1[152], h2[32];
@@ -148,24 +157,27 @@ static void enc_range(const enc_tables *t, const float *X, const uint8_t *site_k
             for (int j = 0; j < 152; j++) h1[j] = 0.0f;
             for (int k = 0; k < 15; k++) {
                 const float xk = in[k];
-                for (int j = 0; j < 152; j++) h1[j] += xk * t->w1t[k][j];
+                for (int j = 0; j < 152; j++) h1[j] = fmaf(xk, t->w1t[k][j], h1[j]);
             }
             for (int j = 0; j < 152; j++) {
-                float a = (h1[j] + t->b1[j]) * t->alpha[j] + t->shift[j];
-                h1[j] = a > 0.0f ? a : 0.0f;
+                float a = fmaf(h1[j] + t->b1[j], t->alpha[j], t->shift[j]);
+                h1[j] = a < 0.0f ? 0.0f : a;                 /* torch's relu keeps NaN (a > 0 ? a : 0 would not) */
             }
             for (int j = 0; j < 32; j++) h2[j] = 0.0f;
             for (int k = 0; k < 150; k++) {
                 const float hk = h1[k];
-                for (int j = 0; j < 32; j++) h2[j] += hk * t->w2t[k][j];
+                for (int j = 0; j < 32; j++) h2[j] = fmaf(hk, t->w2t[k][j], h2[j]);
             }
             float z = 0.0f;
             for (int j = 0; j < 32; j++) {
                 float a = h2[j] + t->b2[j];
-                a = a > 0.0f ? a : 0.0f;
-                z += a * t->w3[j];
+                a = a < 0.0f ? 0.0f : a;
+                z = fmaf(a, t->w3[j], z);
             }
             z += t->b3;
+            if (hidden)
+                for (int j = 0; j < 32; j++) { float a = h2[j] + t->b2[j]; hidden[32 * r + j] = a < 0.0f ? 0.0f : a; }
+            if (logit) logit[r] = z;
             read_prob[r] = 1.0f / (1.0f + expf(-z));
         }
     }
@@ -179,7 +191,7 @@ typedef struct {
 static void *enc_worker(void *arg)
 {
     enc_job *j = (enc_job *)arg;
-    enc_range(j->t, j->X, j->km, j->off, j->s0, j->s1, j->out);
+    enc_range(j->t, j->X, j->km, j->off, j->s0, j->s1, j->out, NULL, NULL);
     return NULL;
 }
 
@@ -189,7 +201,7 @@ void m6a_or_encode_reads_mt(const float *w, const float *X, const uint8_t *site_
     enc_tables *t = (enc_tables *)malloc(sizeof(enc_tables));
     enc_prepare(w, t);
     if (n_threads <= 1 || n_sites < 2 * n_threads) {
-        enc_range(t, X, site_kmers, off, 0, n_sites, read_prob);
+        enc_range(t, X, site_kmers, off, 0, n_sites, read_prob, NULL, NULL);
     } else {
         pthread_t *th = (pthread_t *)malloc((size_t)n_threads * sizeof(pthread_t));
         enc_job *jobs = (enc_job *)malloc((size_t)n_threads * sizeof(enc_job));
@@ -206,6 +218,18 @@ void m6a_or_encode_reads_mt(const float *w, const float *X, const uint8_t *site_
         for (int i = 0; i < n_threads; i++) pthread_join(th[i], NULL);
         free(th); free(jobs);
     }
+    free(t);
+}
+
+/* The same pass, also handing out what the reference's own tensors can be compared with: the read representation
+ * (layer 2 after its ReLU; m6anet/model/model.py get_read_representation) and the logit in front of the Sigmoid
+ * (pooling_blocks.py:52).  tests/test_oracle_golden.py holds the first to the reference's bits. */
+void m6a_or_encode_layers(const float *w, const float *X, const uint8_t *site_kmers, const int64_t *off,
+                          int64_t n_sites, float *read_prob, float *hidden, float *logit)
+{
+    enc_tables *t = (enc_tables *)malloc(sizeof(enc_tables));
+    enc_prepare(w, t);
+    enc_range(t, X, site_kmers, off, 0, n_sites, read_prob, hidden, logit);
     free(t);
 }
 

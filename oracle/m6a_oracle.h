@@ -42,6 +42,9 @@ void m6a_or_encode_reads(const float *weights, const float *X, const uint8_t *si
 /* same, site ranges spread over n_threads host threads (results identical) */
 void m6a_or_encode_reads_mt(const float *weights, const float *X, const uint8_t *site_kmers,
                             const int64_t *off, int64_t n_sites, int n_threads, float *read_prob);
+/* as m6a_or_encode_reads, plus hidden[R][32] (the read representation: layer 2 after ReLU) and logit[R] */
+void m6a_or_encode_layers(const float *weights, const float *X, const uint8_t *site_kmers, const int64_t *off,
+                          int64_t n_sites, float *read_prob, float *hidden, float *logit);
 
 /* a10: _calculate_site_proba for one site, consuming `st` (inference_utils.py:74-87). */
 float m6a_or_site_proba(m6a_or_mt *st, const float *p, int64_t n, int n_iters, int n_samples,

@@ -27,8 +27,7 @@ def build(force=False):
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(_SO):
-            build()
+        build()                                   # no-op when the library is newer than its sources
         L = C.CDLL(_SO)
         f32p, i64p, u8p, i32p, u32p, f64p = (C.POINTER(t) for t in
                                              (C.c_float, C.c_int64, C.c_uint8, C.c_int32, C.c_uint32, C.c_double))
@@ -38,6 +37,7 @@ def lib():
         L.m6a_or_pairwise_sum_f32.argtypes = [f32p, C.c_int64]
         L.m6a_or_pairwise_sum_f32.restype = C.c_float
         L.m6a_or_encode_reads_mt.argtypes = [f32p, f32p, u8p, i64p, C.c_int64, C.c_int, f32p]
+        L.m6a_or_encode_layers.argtypes = [f32p, f32p, u8p, i64p, C.c_int64, f32p, f32p, f32p]
         L.m6a_or_flush_groups.argtypes = [C.c_int64, C.c_int64, C.c_int64, i64p]
         L.m6a_or_flush_groups.restype = C.c_int64
         L.m6a_or_site_pool.argtypes = [f32p, i64p, C.c_int64, C.c_int, C.c_int, C.c_float, C.c_uint32,
@@ -94,6 +94,20 @@ def encode_reads(weights, X, site_kmers, off, n_threads=1):
     lib().m6a_or_encode_reads_mt(_p(weights, C.c_float), _p(X, C.c_float), _p(site_kmers, C.c_uint8),
                                  _p(off, C.c_int64), len(off) - 1, n_threads, _p(out, C.c_float))
     return out
+
+
+def encode_layers(weights, X, site_kmers, off):
+    """(read_prob [R], hidden [R][32] = the read representation, logit [R]) -- one thread."""
+    weights = np.ascontiguousarray(weights, np.float32)
+    X = np.ascontiguousarray(X, np.float32)
+    site_kmers = np.ascontiguousarray(site_kmers, np.uint8)
+    off = np.ascontiguousarray(off, np.int64)
+    assert weights.size == 7997 and X.shape[0] == off[-1]
+    R = int(off[-1])
+    p, h, z = np.empty(R, np.float32), np.empty((R, 32), np.float32), np.empty(R, np.float32)
+    lib().m6a_or_encode_layers(_p(weights, C.c_float), _p(X, C.c_float), _p(site_kmers, C.c_uint8), _p(off, C.c_int64),
+                               len(off) - 1, _p(p, C.c_float), _p(h, C.c_float), _p(z, C.c_float))
+    return p, h, z
 
 
 def flush_groups(n_sites, batch_size, save_per_batch):

@@ -118,6 +118,31 @@ def test_encoder_extreme_inputs(eng, orc, weights):
     assert np.allclose(got, want, rtol=1e-5, atol=1e-8)
 
 
+@pytest.mark.parametrize("variant", [1, 2])
+def test_encoder_nan_and_huge_features(eng, orc, weights, variant):
+    """Layer 1's ReLU is the clamp modifier of the batch-norm fma (m6a_kernels.hip bn_relu): a NaN feature must still come
+    out as a NaN probability for THAT read only (the reference propagates it; the hardware's default clamp would have
+    turned it into 0), and features far outside any normalised signal (|x| = 1e6: activations ~1e7, nowhere near the 2^64
+    the clamp saturates at) must match the oracle like any other."""
+    X, km, off = rand_sites(41, [20] * 30)
+    X[7, 3] = np.nan
+    X[300, 0] = np.nan
+    X[100] = 1e6
+    X[101] = -1e6
+    X[102, 4] = 3e5
+    eng.set_encoder_variant(variant)
+    try:
+        got = eng.get_read_probability(X, km, off)
+    finally:
+        eng.set_encoder_variant(0)
+    want = orc.encode_reads(weights["hct116"], X, km, off)
+    bad = np.zeros(got.size, bool)
+    bad[[7, 300]] = True
+    assert np.isnan(got[bad]).all() and np.isnan(want[bad]).all()
+    assert np.isfinite(got[~bad]).all()
+    assert np.allclose(got[~bad], want[~bad], rtol=1e-5, atol=1e-8)
+
+
 @pytest.mark.parametrize("variant,name", [(1, "general16"), (2, "csite12")])
 @pytest.mark.parametrize("bags", [[16] * 50, [20] * 333, [16, 17, 40, 16, 700, 16, 16, 33], list(range(16, 120)),
                                   [32] * 9 + [31] * 9, [1000, 16, 16, 16, 2000]])

@@ -29,6 +29,11 @@ def bar_use(got, want):
     return np.abs(got.astype(np.float64) - want) / (1e-8 + 1e-5 * np.abs(want))
 
 
+# Since round 4 the oracle and the kernels add in the ORDER the reference's float32 arithmetic adds in (DESIGN.md section
+# 2): the distance to its values is a fraction of the bar, and these tighter figures are the regression net for that order
+# (measured on these fixtures: oracle 0.49, general16 0.44, csite12 0.68; rounds 1-3: 0.81 / 0.84 / 0.83).
+ORDER_BAR = {"oracle": 0.60, "general16": 0.55, "csite12": 0.80}
+
 _jobs = {}
 
 
@@ -54,7 +59,24 @@ def test_oracle_read_probabilities_vs_reference_at_scale(golden, weights, tag):
     for name in MODELS:
         got = orc.encode_reads(weights[name], d["X"][:R], d["site_kmers"][:keep_reads], d["off"][:keep_reads + 1], n_threads=4)
         u = bar_use(got, G[f"{tag}_{name}_readprob"])
-        assert u.max() <= 1.0, (tag, name, float(u.max()), int((u > 1).sum()))
+        assert u.max() <= ORDER_BAR["oracle"], (tag, name, float(u.max()), int((u > 1).sum()))
+
+
+@pytest.mark.parametrize("tag", list(SHAPES))
+def test_oracle_layers_are_the_references_bits(golden, weights, tag):
+    """tests/golden/reference_layers.npz: the reference's own read representation (layer 2 after ReLU) -- the oracle's must
+    be the same BITS (Linear = fma chain over k then + bias, batch norm = fma(y, alpha, beta): torch's CPU arithmetic,
+    pinned); the logit (a 32-term MKL gemv of no fixed order) within a few ulp of a 20-ish magnitude sum."""
+    from oracle import m6a_oracle as orc
+    L = golden("reference_layers.npz")
+    n, bag, _, _ = SHAPES[tag]
+    keep = int(L[f"{tag}_sites"])
+    d = synthetic.make_sites(n, bag, seed=20250328, prefix_sites=keep)
+    R = int(d["off"][keep])
+    for name in MODELS:
+        p, h2, z = orc.encode_layers(weights[name], d["X"][:R], d["site_kmers"][:keep], d["off"][:keep + 1])
+        assert np.array_equal(h2.view(np.uint32), L[f"{tag}_{name}_h2"].view(np.uint32)), (tag, name)
+        assert np.abs(z.astype(np.float64) - L[f"{tag}_{name}_logit"]).max() <= 8e-6, (tag, name)
 
 
 @pytest.mark.parametrize("tag", list(SHAPES))
@@ -86,7 +108,8 @@ def engines(weights):
 @pytest.mark.parametrize("variant", [(1, "general16"), (2, "csite12")])
 @pytest.mark.parametrize("tag", list(SHAPES))
 def test_hip_read_probabilities_vs_reference_at_scale(golden, engines, tag, variant):
-    """Every one of the 2.1 M reads x 4 checkpoints x 2 kernels inside rtol 1e-5 / atol 1e-8 of the reference's value."""
+    """Every one of the 2.1 M reads x 4 checkpoints x 2 kernels inside rtol 1e-5 / atol 1e-8 of the reference's value --
+    and, since the kernels add in the reference's order, inside ORDER_BAR of that allowance."""
     d, G, keep_reads, _ = job(golden, tag)
     R = int(d["off"][keep_reads])
     mode, label = variant
@@ -99,7 +122,48 @@ def test_hip_read_probabilities_vs_reference_at_scale(golden, engines, tag, vari
         finally:
             e.set_encoder_variant(0)
         u = bar_use(got, G[f"{tag}_{name}_readprob"])
-        assert u.max() <= 1.0, (tag, name, label, float(u.max()), int((u > 1).sum()))
+        assert u.max() <= ORDER_BAR[label], (tag, name, label, float(u.max()), int((u > 1).sum()))
+
+
+def _layer3_as_the_kernels_sum_it(h2, W3, b3):
+    """Both kernels: each lane half adds its 16 rows of layer 2 (row (q&3) + 8(q>>2) + 4 half for q = 0..15) as one fma
+    chain, the halves are added, then b3; sigmoid as 1 / (1 + exp(-z)) in float32 (here with a correctly rounded exp)."""
+    f64 = np.float64
+    z = []
+    for hf in (0, 1):
+        acc = np.zeros(h2.shape[0], np.float32)
+        for q in range(16):
+            r = (q & 3) + 8 * (q >> 2) + 4 * hf
+            acc = (h2[:, r].astype(f64) * f64(W3[r]) + acc.astype(f64)).astype(np.float32)
+        z.append(acc)
+    zz = (z[0] + z[1]) + np.float32(b3)
+    return (np.float32(1) / (np.float32(1) + np.exp(-zz.astype(f64)).astype(np.float32))).astype(np.float32)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", list(SHAPES))
+def test_hip_general16_follows_the_references_hidden_layer(golden, engines, weights, tag):
+    """enc_kernel's layers 1 and 2 are meant to be the reference's bits.  The C ABI hands out probabilities only, so:
+    take the REFERENCE's read representation (tests/golden/reference_layers.npz), finish it the way the kernel finishes
+    (its own 32 -> 1 order, above) and compare -- all that may differ is the device's expf against a correctly rounded
+    exp: <= 2 ulp of the probability, identical for most reads.  A layer-1/2 sum in any other order moves ~80 % of the
+    probabilities by more than that (tools/emulate_encoder.py)."""
+    L = golden("reference_layers.npz")
+    n, bag, _, _ = SHAPES[tag]
+    keep = int(L[f"{tag}_sites"])
+    d = synthetic.make_sites(n, bag, seed=20250328, prefix_sites=keep)
+    R = int(d["off"][keep])
+    for name in MODELS:
+        e = engines[name]
+        e.set_encoder_variant(1)
+        try:
+            got = e.get_read_probability(d["X"][:R], d["site_kmers"][:keep], d["off"][:keep + 1])
+        finally:
+            e.set_encoder_variant(0)
+        w = weights[name]
+        want = _layer3_as_the_kernels_sum_it(L[f"{tag}_{name}_h2"], w[7964:7996], w[7996])
+        ulp = np.abs(got.view(np.int32).astype(np.int64) - want.view(np.int32).astype(np.int64))
+        assert ulp.max() <= 2 and (ulp == 0).mean() >= 0.85, (tag, name, int(ulp.max()), float((ulp == 0).mean()))
 
 
 @pytest.mark.gpu

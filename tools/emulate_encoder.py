@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""The encoder's float32 arithmetic, operation by operation, in NumPy -- to ask questions the GPU cannot answer cheaply:
+which ORDER of the same multiply-adds lands closest to the reference's values?
+
+torch's CPU path was pinned first (build container, hooks on the reference's modules, 320 reads x hek293t_glori; every
+candidate order compared bit for bit with torch's own intermediate tensors):
+    Linear 15->150   : acc = 0; for k = 0..14: acc = fma(x[k], W1[j][k], acc);  then acc + b1[j]          100.00 % identical
+    BatchNorm (eval) : alpha = g * (1/sqrt(var + eps)); beta = fma(-mean, alpha, bias); fma(y, alpha, beta) 100.00 %
+    Linear 150->32   : acc = 0; for k = 0..149: acc = fma(h[k], W2[j][k], acc); then acc + b2[j]          100.00 %
+    Linear 32->1     : an MKL gemv whose lane order no simple model reproduced (<= 29 %)
+    Sigmoid          : 1 / (1 + exp(-z)) with Sleef's 1-ulp exp (92 % against a correctly rounded exp)
+
+    python tools/emulate_encoder.py [model]      # needs tests/golden/reference_at_scale.npz; gpurun_out/read_probs_<model>.npz if present
+"""
+import os
+import sys
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+from m6anet_amd import synthetic                      # noqa: E402
+from m6anet_amd.constants import asset_path           # noqa: E402
+
+f64, f32 = np.float64, np.float32
+
+
+def fma(a, b, c):
+    # the product of two floats is exact in double; the sum is rounded to double, then to float (double rounding can differ
+    # from a true fma in ~1e-9 of cases: irrelevant here)
+    return (a.astype(f64) * b.astype(f64) + c.astype(f64)).astype(f32)
+
+
+def unpack(w):
+    return dict(E=w[0:132].reshape(66, 2), W1=w[132:2382].reshape(150, 15), b1=w[2382:2532], g=w[2532:2682], be=w[2682:2832],
+                mu=w[2832:2982], var=w[2982:3132], W2=w[3132:7932].reshape(32, 150), b2=w[7932:7964], W3=w[7964:7996], b3=w[7996])
+
+
+def chain(x, W, ks, acc=None):
+    """acc[r][j] = fma(x[r][k], W[j][k], acc[r][j]) for k in ks, in that order."""
+    if acc is None:
+        acc = np.zeros((x.shape[0], W.shape[0]), f32)
+    for k in ks:
+        acc = fma(x[:, k:k + 1], W[None, :, k], acc)
+    return acc
+
+
+def sigmoid(z):
+    return (f32(1) / (f32(1) + np.exp(-z.astype(f64)).astype(f32))).astype(f32)
+
+
+def torch_like(P, inp, upto="p"):
+    y = chain(inp, P["W1"], range(15)) + P["b1"]
+    invstd = (f32(1) / np.sqrt(P["var"] + f32(1e-5))).astype(f32)
+    alpha = (P["g"] * invstd).astype(f32)
+    beta = fma(-P["mu"], alpha, P["be"])
+    h = np.maximum(fma(y, np.broadcast_to(alpha, y.shape), np.broadcast_to(beta, y.shape)), 0)
+    h2 = np.maximum(chain(h, P["W2"], range(150)) + P["b2"], 0)
+    if upto == "h2":
+        return h2
+    z = chain(h2, P["W3"][None, :], range(32)) + P["b3"]
+    return sigmoid(z[:, 0])
+
+
+def bn_pairs(P):
+    invstd = (f32(1) / np.sqrt(P["var"] + f32(1e-5))).astype(f32)
+    alpha = (P["g"] * invstd).astype(f32)
+    return alpha, fma(-P["mu"], alpha, P["be"])
+
+
+def folded(P):
+    """Rounds 1-3: batch norm folded into layer 1's weights in float32."""
+    alpha, _ = bn_pairs(P)
+    shift = (P["be"] - (P["mu"] * alpha).astype(f32)).astype(f32)
+    W1f = np.zeros((150, 16), f32)
+    W1f[:, :15] = (alpha[:, None] * P["W1"]).astype(f32)
+    W1f[:, 15] = ((alpha * P["b1"]).astype(f32) + shift).astype(f32)
+    return W1f
+
+
+def old_unit_order(m):
+    """Rounds 1-3, layer 2: the k pairs of unit tile m in issue order (register q held units (q&3) + 8(q>>2) + 4 half)."""
+    out = []
+    for q in range(12 if m == 4 else 16):
+        u = 32 * m + (q & 3) + 8 * (q >> 2)
+        out += [u, u + 4]
+    return out
+
+
+def layer3_halves(P, h2):
+    """Both kernels: each lane half sums its 16 rows of layer 2 ((q&3) + 8(q>>2) + 4 half, q = 0..15) as one fma chain, the
+    halves are added, then b3."""
+    rows = [[(q & 3) + 8 * (q >> 2) + 4 * hf for q in range(16)] for hf in (0, 1)]
+    z0 = chain(h2[:, rows[0]], P["W3"][None, rows[0]], range(16))
+    z1 = chain(h2[:, rows[1]], P["W3"][None, rows[1]], range(16))
+    return ((z0 + z1) + P["b3"])[:, 0]
+
+
+def layer2(P, h, order):
+    W2a = np.zeros((32, 160), f32)
+    W2a[:, :150] = P["W2"]
+    W2a[:, 150] = P["b2"]
+    ha = np.zeros((h.shape[0], 160), f32)
+    ha[:, :150] = h
+    ha[:, 150] = 1
+    return np.maximum(chain(ha, W2a, order), 0)
+
+
+def kernel_r3(P, inp):
+    """general16 as rounds 1-3 built it: folded layer 1 in slot pairs (st, st+8), layer 2 in accumulator order."""
+    x16 = np.concatenate([inp, np.ones((inp.shape[0], 1), f32)], 1)
+    ks = sum(([st, st + 8] for st in range(8)), [])
+    h = np.maximum(chain(x16, folded(P), ks), 0)
+    return sigmoid(layer3_halves(P, layer2(P, h, sum((old_unit_order(m) for m in range(5)), []))))
+
+
+def kernel_general16(P, inp):
+    """enc_kernel now: the reference's operations through layer 2 (k = 0..14, + b1; fma batch norm; k = 0..149, + b2)."""
+    alpha, beta = bn_pairs(P)
+    y = chain(inp, P["W1"], range(15)) + P["b1"]
+    h = np.maximum(fma(y, np.broadcast_to(alpha, y.shape), np.broadcast_to(beta, y.shape)), 0)
+    return sigmoid(layer3_halves(P, layer2(P, h, range(152))))
+
+
+def kernel_csite12(P, inp):
+    """enc_csite_kernel now: x0..x8 as a chain, then ONE addition of the site's c = b1 + sum_e W1[:, 9+e] * e (a chain that
+    starts at b1), then as enc_kernel."""
+    alpha, beta = bn_pairs(P)
+    c = chain(inp[:, 9:15], P["W1"][:, 9:15], range(6), acc=np.broadcast_to(P["b1"], (inp.shape[0], 150)).astype(f32).copy())
+    y = chain(inp, P["W1"], range(9)) + c
+    h = np.maximum(fma(y, np.broadcast_to(alpha, y.shape), np.broadcast_to(beta, y.shape)), 0)
+    return sigmoid(layer3_halves(P, layer2(P, h, range(152))))
+
+
+def use(got, want):
+    want = want.astype(f64)
+    return np.abs(got.astype(f64) - want) / (1e-8 + 1e-5 * np.abs(want))
+
+
+def line(label, got, ref):
+    u = use(got, ref)
+    print("  %-58s identical %.4f   rms use %.4f   p99.99 %.4f   worst %.4f   beyond %d"
+          % (label, float((got.view(np.uint32) == ref.view(np.uint32)).mean()), float(np.sqrt((u * u).mean())), float(np.quantile(u, 0.9999)),
+             float(u.max()), int((u > 1).sum())), flush=True)
+
+
+def main():
+    name = sys.argv[1] if len(sys.argv) > 1 else "hek293t_glori"
+    S = int(sys.argv[2]) if len(sys.argv) > 2 else 50_000
+    P = unpack(np.fromfile(asset_path("weights_%s.bin" % name), np.float32))
+    d = synthetic.make_sites(1_000_000, 20, seed=20250328, prefix_sites=S)
+    R = int(d["off"][S])
+    emb = P["E"][np.repeat(d["site_kmers"][:S].astype(np.int64), 20, axis=0)].reshape(-1, 6)
+    inp = np.concatenate([d["X"][:R].reshape(-1, 9), emb], 1).astype(f32)
+    ref = np.load(os.path.join(REPO, "tests", "golden", "reference_at_scale.npz"))["uniform_%s_readprob" % name][:R]
+    print(name, R, "reads; against the REFERENCE's read probabilities:")
+    line("torch's order, layer 3 as one chain of 32", torch_like(P, inp), ref)
+    line("rounds 1-3 general16 (emulated)", kernel_r3(P, inp), ref)
+    eg, ec = kernel_general16(P, inp), kernel_csite12(P, inp)
+    line("general16 (emulated)", eg, ref)
+    line("csite12 (emulated)", ec, ref)
+    hip = os.path.join(REPO, "gpurun_out", "read_probs_%s.npz" % name)
+    if os.path.exists(hip):
+        h = np.load(hip)
+        line("general16 on the GPU", h["general16"][:R], ref)
+        line("csite12 on the GPU", h["csite12"][:R], ref)
+        for lab, e, g in (("general16", eg, h["general16"][:R]), ("csite12", ec, h["csite12"][:R])):
+            ulp = np.abs(e.view(np.int32).astype(np.int64) - g.view(np.int32).astype(np.int64))
+            print("  %s emulated vs on the GPU: identical %.4f, within 1 ulp %.4f, worst %d ulp (the GPU's expf against a correctly rounded exp)"
+                  % (lab, float((ulp == 0).mean()), float((ulp <= 1).mean()), int(ulp.max())))
+
+
+if __name__ == "__main__":
+    main()
