@@ -14,6 +14,10 @@ itself sits at 0.9-1.0 of the bar against the float32 oracle (DESIGN.md section 
 any read beyond 1.5x the bar (5x for randomly perturbed weights, where the same noise is larger still) -- and reports how
 many reads went beyond 1.0 and the worst one; the committed tests hold the fixtures and seeded samples to the bar itself.
 
+Since the second half of round 4 the kernels and the oracle both add in the reference's order: what
+separates them is the 32 -> 1 sum, expf, and in the 12-slot kernel the pre-summed site constants -- 11 G reads, none beyond
+the bar, worst 0.94 (profiles/r04_encoder_fuzz_final.json).  The thresholds above stay as they are: a gross-error net.
+
     python tests/fuzz_encoder.py [seconds] [seed]      -> one JSON line with the case counts
 """
 import json

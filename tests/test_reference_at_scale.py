@@ -146,8 +146,8 @@ def test_hip_general16_follows_the_references_hidden_layer(golden, engines, weig
     """enc_kernel's layers 1 and 2 are meant to be the reference's bits.  The C ABI hands out probabilities only, so:
     take the REFERENCE's read representation (tests/golden/reference_layers.npz), finish it the way the kernel finishes
     (its own 32 -> 1 order, above) and compare -- all that may differ is the device's expf against a correctly rounded
-    exp: <= 2 ulp of the probability, identical for most reads.  A layer-1/2 sum in any other order moves ~80 % of the
-    probabilities by more than that (tools/emulate_encoder.py)."""
+    exp: a few ulp of the probability at most (4 seen, on logits near -30), identical for 95 % of the reads.  A layer-1/2
+    sum in any other order leaves ~11-22 % identical (tools/emulate_encoder.py)."""
     L = golden("reference_layers.npz")
     n, bag, _, _ = SHAPES[tag]
     keep = int(L[f"{tag}_sites"])
@@ -163,7 +163,7 @@ def test_hip_general16_follows_the_references_hidden_layer(golden, engines, weig
         w = weights[name]
         want = _layer3_as_the_kernels_sum_it(L[f"{tag}_{name}_h2"], w[7964:7996], w[7996])
         ulp = np.abs(got.view(np.int32).astype(np.int64) - want.view(np.int32).astype(np.int64))
-        assert ulp.max() <= 2 and (ulp == 0).mean() >= 0.85, (tag, name, int(ulp.max()), float((ulp == 0).mean()))
+        assert ulp.max() <= 8 and (ulp == 0).mean() >= 0.85, (tag, name, int(ulp.max()), float((ulp == 0).mean()))
 
 
 @pytest.mark.gpu
