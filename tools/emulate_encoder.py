@@ -7,7 +7,10 @@ candidate order compared bit for bit with torch's own intermediate tensors):
     Linear 15->150   : acc = 0; for k = 0..14: acc = fma(x[k], W1[j][k], acc);  then acc + b1[j]          100.00 % identical
     BatchNorm (eval) : alpha = g * (1/sqrt(var + eps)); beta = fma(-mean, alpha, bias); fma(y, alpha, beta) 100.00 %
     Linear 150->32   : acc = 0; for k = 0..149: acc = fma(h[k], W2[j][k], acc); then acc + b2[j]          100.00 %
-    Linear 32->1     : an MKL gemv whose lane order no simple model reproduced (<= 29 %)
+    Linear 32->1     : an MKL gemv (rows in groups of 4): s = x0*w0; 16 lanes of products k = 1..16 with lane 0 = fma(x1, w1, s),
+                       butterfly l+8, l+4, l+2, l+1; again for k = 17..31 with lane 0 carrying the sum; + b3                  100.00 %
+                       -- on this CPU's AVX-512 path; MKL_ENABLE_INSTRUCTIONS=AVX2 gives other logits (26-57 % identical) and
+                       93-98 % of the hidden layer's bits: layers 1-2 are what the paths share, so that is what is followed
     Sigmoid          : 1 / (1 + exp(-z)) with Sleef's 1-ulp exp (92 % against a correctly rounded exp)
 
     python tools/emulate_encoder.py [model]      # needs tests/golden/reference_at_scale.npz; gpurun_out/read_probs_<model>.npz if present
