@@ -214,16 +214,25 @@ def test_multi_gpu_exchange_plumbing(tmp_path, monkeypatch):
     multi_gpu._wait_for(p, "present", os.getppid())
 
 
-def test_bundled_weights_halve_exactly(weights):
-    """The kernels' ReLU is x + |x| = 2 relu(x); the 0.5 rides in W2 / b2 / W3 (m6a_api.hip::build_fragments).  That is
-    bit-neutral iff halving those weights is exact, i.e. none of them is sub-normal after halving: true for all four
-    bundled checkpoints (and for any float with |w| >= 2^-125)."""
+def test_bundled_weights_scale_exactly(weights):
+    """The encoder's scalings by powers of two (m6a_api.hip::build_fragments) must be exact for the kernels to form the
+    reference's products bit for bit: layer 1's batch norm + ReLU is a clamped fma on (alpha, beta) * 2^-64 with W2 and its
+    bias column * 2^64; layer 2's ReLU is x + |x| = 2 relu(x) with W3 * 0.5.  Exact iff nothing overflows or turns
+    sub-normal: true for the four bundled checkpoints (alpha, beta of a trained batch norm are nowhere near 2^-62)."""
+    f32 = np.float32
     for name, w in weights.items():
-        tail = w[3132:7996]                      # W2 [32,150], b2 [32], W3 [32]  (blob layout: include/m6a.h)
-        half = (tail * np.float32(0.5)).astype(np.float32)
-        assert np.array_equal(half * np.float32(2.0), tail), name
-        nz = np.abs(tail[tail != 0])
-        assert nz.min() > 2.0 ** -100, (name, float(nz.min()))
+        g, be, mu, var = w[2532:2682], w[2682:2832], w[2832:2982], w[2982:3132]       # blob layout: include/m6a.h
+        alpha = (g * (f32(1) / np.sqrt(var + f32(1e-5))).astype(f32)).astype(f32)
+        beta = (be.astype(np.float64) - mu.astype(np.float64) * alpha.astype(np.float64)).astype(f32)   # fma(-mean, alpha, bias)
+        for v in (alpha, beta):
+            s = (v * f32(2.0 ** -64)).astype(f32)
+            assert np.array_equal((s * f32(2.0 ** 64)).astype(f32), v), name
+            assert np.abs(v[v != 0]).min() > 2.0 ** -40, (name, float(np.abs(v[v != 0]).min()))
+        w2b2 = w[3132:7964]                                                               # W2 [32,150], b2 [32]
+        up = (w2b2 * f32(2.0 ** 64)).astype(f32)
+        assert np.isfinite(up).all() and np.array_equal((up * f32(2.0 ** -64)).astype(f32), w2b2), name
+        w3 = w[7964:7996]
+        assert np.array_equal((w3 * f32(0.5)).astype(f32) * f32(2.0), w3), name
 
 
 def test_early_rank_start_helpers(tmp_path, monkeypatch):
