@@ -54,7 +54,8 @@ enum { M6A_RNG_NUMPY = 0 /* exact replay of the reference's NumPy stream */ };
  * Replaces: MILModel(...).load_state_dict(torch.load(...)) at m6anet/scripts/inference.py:88-90.
  * `weights` is a host pointer.  The weights are laid out for the kernels here; BatchNorm (eval, eps 1e-5) becomes the
  * (alpha, beta) = (gamma / sqrt(var + eps), fma(-mean, alpha, bias)) pair torch forms, applied per read in the kernel as
- * torch applies it -- nothing is folded into W1: the encoder's float32 sums run in the reference's order. */
+ * torch applies it -- nothing is folded into W1: the encoder's float32 sums run in the reference's order.
+ * M6A_EUNSUPPORTED for a layer-2 weight or bias of magnitude >= 2^63 (the kernels carry them scaled by 2^64). */
 int m6a_create(m6a_ctx **out, const float *weights, size_t n_floats, int device_id);
 void m6a_destroy(m6a_ctx *ctx);
 const char *m6a_last_error(const m6a_ctx *ctx);   /* ctx may be NULL: last create error */

@@ -1086,6 +1086,11 @@ int m6a_create(m6a_ctx **out, const float *weights, size_t n_floats, int device_
     *out = nullptr;
     if (!weights || n_floats != M6A_N_WEIGHTS)
         return fail(nullptr, M6A_EINVAL, "weights must be %d floats (got %zu)", M6A_N_WEIGHTS, n_floats);
+    // the encoder carries layer 2's weights scaled by 2^64 (build_fragments): a finite weight that would overflow there is
+    // refused here, loudly, not turned into inf inside the kernel (the bundled checkpoints' largest is below 1)
+    for (int i = O_W2; i < O_W3; i++)
+        if (std::isfinite(weights[i]) && std::fabs(weights[i]) >= 0x1p+63f)
+            return fail(nullptr, M6A_EUNSUPPORTED, "layer-2 weight %d is %g: beyond 2^63 in magnitude", i - O_W2, (double)weights[i]);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
         (void)hipGetLastError();

@@ -37,6 +37,9 @@ def test_version_and_errors_without_gpu():
     w = np.zeros(7997, np.float32)
     assert L.m6a_create(C.byref(h), w.ctypes.data, 10, 0) == -1          # M6A_EINVAL: wrong blob size
     assert b"7997" in L.m6a_last_error(None)
+    big = w.copy()
+    big[3132 + 77] = 1e19                                                # a layer-2 weight the 2^64 scaling would overflow
+    assert L.m6a_create(C.byref(h), big.ctypes.data, 7997, 0) == -6 and b"2^63" in L.m6a_last_error(None)   # M6A_EUNSUPPORTED
     import torch
     if not torch.cuda.is_available():
         rc = L.m6a_create(C.byref(h), w.ctypes.data, 7997, 0)
