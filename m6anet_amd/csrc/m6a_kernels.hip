@@ -74,19 +74,15 @@ __device__ __forceinline__ float relu2(float x)
 // exactly 2^-64 * fma(y, alpha, beta), and the instruction's clamp modifier (result to [0, 1]) is the ReLU of every
 // activation below 2^64; layer 2's weights carry the 2^64 back (exact again), so its MFMAs form the very products relu(h)
 // would give.  fma then x + |x| -- two instructions on the datapath the f32 MFMAs use -- cost the 12-slot kernel 3 %
-// (2.202 -> 2.135 ms on the bench shape).  What the trick costs: an activation beyond 2^64 = 1.8e19 saturates there (the
+// (2.202 -> 2.135 ms on the bench shape, before the loads were hidden).  What the trick costs: an activation beyond 2^64 = 1.8e19 saturates there (the
 // reference carries it on towards inf; normalised signal features give |h| < 1e4, tests go to 1e7), and one below 2^-62
 // loses low bits (a contribution under 1e-19).  Both kernels clear MODE.DX10_CLAMP first: with it set (the default for
 // compute kernels) clamp turns NaN into 0, and a NaN feature must come out as a NaN probability, as the reference's does
 // (tests/test_gpu_parity.py::test_encoder_nan_and_huge_features).
 //
 // The (alpha', beta') pairs sit in LDS as [unit tile][lane half][register]: 16 bytes = two hidden units per load, all 32
-// lanes of a half reading the same address (a broadcast, no conflicts).  These 38 loads per tile and their waits are what
-// the reference's order costs: 2.065 -> 2.135 ms for the 12-slot kernel (2.080 with the loads knocked out).  enc_kernel
-// has the 16 registers to run them through a buffer that is always a step ahead -- registers 0..7 of unit tile m are in it
-// when the tile's layer-1 MFMAs have issued; 8..15 are fetched as soon as those are consumed, 0..7 of tile m+1 after that,
-// under the layer-2 MFMAs -- worth 1 %; enc_csite_kernel (245 VGPRs) reads them where it uses them (a two-load head start
-// measured no different).
+// lanes of a half reading the same address (a broadcast, no conflicts) -- 38 ds_read_b128 per tile, whose latency
+// layer2_with_bn (below) hides behind blocks of MFMAs.
 __device__ __forceinline__ void clamp_keeps_nan()
 {
     __builtin_amdgcn_s_setreg(1 | (8 << 6) | (0 << 11), 0);      // hwreg(HW_REG_MODE, offset 8, size 1) = DX10_CLAMP
@@ -97,30 +93,39 @@ __device__ __forceinline__ float bn_relu(float y, float alpha, float beta)
     asm("v_fma_f32 %0, %1, %2, %3 clamp" : "=v"(r) : "v"(y), "v"(alpha), "v"(beta));
     return r;
 }
-struct BnBuf { float4 ab[4]; };
-__device__ __forceinline__ void bn_fetch(BnBuf &b, const float *bn, int q0)
+// Layer 2 of one unit tile, with the batch norm of its inputs woven in: blocks of BN_BLOCK hidden units -- clamp-fma them
+// from the pairs in `pq`, fetch the NEXT block's pairs into `pq` (this tile's, or the first block of unit tile `m_next`),
+// issue the block's MFMAs.  The loads are issued with a block of MFMAs (4 x 64 cycles of matrix pipe) in front of their
+// use, so the wave never waits for LDS; 8 registers hold the pairs.  (All 16 units first and then 16 MFMAs back to back --
+// how rounds 1-3 ran the plain ReLU, a VALU instruction between EVERY two dependent MFMAs costing the pipe 6 % then -- left
+// the 38 loads' latency exposed: 2.135-2.15 ms for the 12-slot kernel against 2.07-2.09 this way, which is what the kernel
+// took with the batch norm folded into the weights; blocks of 8 need 16 registers the 12-slot kernel does not have (spills:
+// 2.25), blocks of 2 measure 2.10.  profiles/r04_encoder_order_timing.txt.)
+#define BN_BLOCK 4
+struct BnPairs { float4 v[BN_BLOCK / 2]; };
+__device__ __forceinline__ void bn_pairs_load(BnPairs &pq, const float *p)
 {
 #pragma unroll
-    for (int i = 0; i < 4; i++) b.ab[i] = *(const float4 *)(bn + 2 * q0 + 4 * i);
+    for (int i = 0; i < BN_BLOCK / 2; i++) pq.v[i] = *(const float4 *)(p + 4 * i);
 }
-__device__ __forceinline__ void bn_relu_buf(f32x16 &t, const BnBuf &b, int q0, int n)
+template <int M>
+__device__ __forceinline__ void layer2_with_bn(f32x16 &acc2, f32x16 &cur, const float (&w2)[80], BnPairs &pq, const float *bn_half)
 {
+    constexpr int n = L2_REGS(M), m_next = M < 4 ? M + 1 : 0;
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int q = q0 + 2 * i;
-        if (q >= n) break;
-        t[q] = bn_relu(t[q], b.ab[i].x, b.ab[i].y);
-        t[q + 1] = bn_relu(t[q + 1], b.ab[i].z, b.ab[i].w);
-    }
-}
-__device__ __forceinline__ void bn_relu_lds(f32x16 &t, const float *bn, int n)
-{
+    for (int b = 0; b * BN_BLOCK < n; b++) {
 #pragma unroll
-    for (int q = 0; q < 16; q += 2) {
-        if (q >= n) break;
-        const float4 ab = *(const float4 *)(bn + 2 * q);
-        t[q] = bn_relu(t[q], ab.x, ab.y);
-        t[q + 1] = bn_relu(t[q + 1], ab.z, ab.w);
+        for (int i = 0; i < BN_BLOCK / 2; i++) {
+            const int q = b * BN_BLOCK + 2 * i;
+            cur[q] = bn_relu(cur[q], pq.v[i].x, pq.v[i].y);
+            cur[q + 1] = bn_relu(cur[q + 1], pq.v[i].z, pq.v[i].w);
+        }
+        bn_pairs_load(pq, (b + 1) * BN_BLOCK < n ? bn_half + M * 64 + 2 * (b + 1) * BN_BLOCK : bn_half + m_next * 64);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = b * BN_BLOCK; q < (b + 1) * BN_BLOCK; q++)
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(w2[M * 16 + q], cur[q], acc2, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -267,8 +272,8 @@ __global__ __launch_bounds__(256, 2) void enc_kernel(EncArgs a)
         s_base = uniform_i64(__shfl(s, 31, 64));
     }
 
-    BnBuf bnb;
-    bn_fetch(bnb, bn_half, 0);
+    BnPairs bnq;
+    bn_pairs_load(bnq, bn_half);
     for (int64_t tile = tile0; tile < tile1; ++tile) {
         // the chain always runs (for the last tile it refetches that tile): no guard, no merge
         const int64_t tn = tile + 1 < tile1 ? tile + 1 : tile;
@@ -278,9 +283,8 @@ __global__ __launch_bounds__(256, 2) void enc_kernel(EncArgs a)
         link0(s_base, o);
 
         // Layer 1 of unit-tile m+1 is issued ahead of layer 2 of unit-tile m (ping-pong
-        // accumulators).  ReLU is applied to a finished tile as one batch of 16 v_add_f32 (x + |x|, see relu2) and
-        // the 16 layer-2 MFMAs that consume it then issue back to back: a VALU op wedged between
-        // two MFMAs on the same accumulator costs ~6% of the matrix pipe (tools/mfma_chain_bench).
+        // accumulators).  Batch norm + ReLU of the finished tile and the layer-2 MFMAs that consume it go in blocks
+        // of four hidden units (layer2_with_bn): four clamped fmas, the next block's pairs fetched from LDS, four MFMAs.
         f32x16 acc2, h1a, h1b;
 #pragma unroll
         for (int q = 0; q < 16; q++) { acc2[q] = 0.0f; h1a[q] = 0.0f; }
@@ -301,16 +305,11 @@ __global__ __launch_bounds__(256, 2) void enc_kernel(EncArgs a)
             __builtin_amdgcn_sched_barrier(0);
             if (m == 0) link1(tn, s_base, o, sn, km, fn);
             if (m == 2) link2(km, fn);
-            bn_relu_buf(cur, bnb, 0, L2_REGS(m));
-            bn_fetch(bnb, bn_half + m * 64, 8);
-            __builtin_amdgcn_sched_barrier(0);
-            bn_relu_buf(cur, bnb, 8, L2_REGS(m));
-            bn_fetch(bnb, bn_half + (m < 4 ? m + 1 : 0) * 64, 0);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int q = 0; q < L2_REGS(m); q++)
-                acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(w2[m * 16 + q], cur[q], acc2, 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
+            if (m == 0) layer2_with_bn<0>(acc2, cur, w2, bnq, bn_half);
+            if (m == 1) layer2_with_bn<1>(acc2, cur, w2, bnq, bn_half);
+            if (m == 2) layer2_with_bn<2>(acc2, cur, w2, bnq, bn_half);
+            if (m == 3) layer2_with_bn<3>(acc2, cur, w2, bnq, bn_half);
+            if (m == 4) layer2_with_bn<4>(acc2, cur, w2, bnq, bn_half);
         }
         float z = 0.0f;
 #pragma unroll
@@ -495,6 +494,8 @@ __global__ __launch_bounds__(256, 2) void enc_csite_kernel(EncArgs a)
         s_base += __builtin_amdgcn_readfirstlane(__shfl(rel, 31, 64));
     }
 
+    BnPairs bnq;
+    bn_pairs_load(bnq, bn_half);
     for (int tile = tile0; tile < tile1; ++tile) {
         // the chain always runs (for the last tile it refetches that tile): no guard, no merge
         const int tn = tile + 1 < tile1 ? tile + 1 : tile;
@@ -526,12 +527,11 @@ __global__ __launch_bounds__(256, 2) void enc_csite_kernel(EncArgs a)
             if (m == 0) link1(tn, s_base, o, reln, kidn, fn);
             if (m == 1) link2(kidn, evn);
             if (m == 3) link3(evn, reln, fn[4], f, a4, a5);             // layer1(4) has issued: in place
-            bn_relu_lds(cur, bn_half + m * 64, L2_REGS(m));
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int q = 0; q < L2_REGS(m); q++)
-                acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(w2[m * 16 + q], cur[q], acc2, 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
+            if (m == 0) layer2_with_bn<0>(acc2, cur, w2, bnq, bn_half);
+            if (m == 1) layer2_with_bn<1>(acc2, cur, w2, bnq, bn_half);
+            if (m == 2) layer2_with_bn<2>(acc2, cur, w2, bnq, bn_half);
+            if (m == 3) layer2_with_bn<3>(acc2, cur, w2, bnq, bn_half);
+            if (m == 4) layer2_with_bn<4>(acc2, cur, w2, bnq, bn_half);
         }
         float z = 0.0f;
 #pragma unroll
