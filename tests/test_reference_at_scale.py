@@ -79,6 +79,29 @@ def test_oracle_layers_are_the_references_bits(golden, weights, tag):
         assert np.abs(z.astype(np.float64) - L[f"{tag}_{name}_logit"]).max() <= 8e-6, (tag, name)
 
 
+def test_numpy_emulation_of_the_order_reproduces_the_references_hidden_layer(golden, weights):
+    """tools/emulate_encoder.py is where the order of operations was worked out and where DESIGN.md's noise-budget figures come
+    from; this keeps it honest: its restatement of torch's order (fma chains in float64-exact NumPy steps) gives the reference's
+    read representation bit for bit, and its 32 -> 1 model (the AVX-512 gemv: a one-element head, two 16-lane butterflies) the
+    reference's logits."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import emulate_encoder as E
+    L = golden("reference_layers.npz")
+    keep = int(L["uniform_sites"])
+    d = synthetic.make_sites(1_000_000, 20, seed=20250328, prefix_sites=keep)
+    R = int(d["off"][keep])
+    for name in ("hct116", "hek293t_glori"):
+        P = E.unpack(weights[name])
+        emb = P["E"][np.repeat(d["site_kmers"][:keep].astype(np.int64), 20, axis=0)].reshape(-1, 6)
+        inp = np.concatenate([d["X"][:R].reshape(-1, 9), emb], 1).astype(np.float32)
+        h2 = E.torch_like(P, inp, upto="h2")
+        assert np.array_equal(h2.view(np.uint32), L[f"uniform_{name}_h2"].view(np.uint32)), name
+        z = E.mkl_avx512_gemv_32(h2, P["W3"], P["b3"])
+        assert np.array_equal(z.view(np.uint32), L[f"uniform_{name}_logit"].view(np.uint32)), name
+
+
 @pytest.mark.parametrize("tag", list(SHAPES))
 def test_oracle_site_probabilities_vs_reference_at_scale(golden, weights, tag):
     """From the REFERENCE's read probabilities the oracle's sampling must be the reference's, bit for bit (2 000 sites:

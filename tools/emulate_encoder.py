@@ -65,6 +65,23 @@ def torch_like(P, inp, upto="p"):
     return sigmoid(z[:, 0])
 
 
+def mkl_avx512_gemv_32(h2, W3, b3):
+    """Linear(32, 1) as MKL's AVX-512 sgemv computes it for rows in groups of 4 (found with cancellation triples, see the module
+    docstring): s = x0*w0; lanes l = 0..15 hold the products of k = 1 + l, lane 0 = fma(x1, w1, s); butterfly l+8, l+4, l+2, l+1;
+    the same again for k = 17 + l (lane 15 empty) with lane 0 carrying the sum so far; + b3."""
+    def butterfly(v):
+        for step in (8, 4, 2, 1):
+            v = [v[l] + v[l + step] for l in range(step)]
+        return v[0]
+    p = [(h2[:, k] * W3[k]).astype(f32) for k in range(32)]
+    v = [p[1 + l] for l in range(16)]
+    v[0] = fma(h2[:, 1], np.broadcast_to(W3[1], h2[:, 1].shape), p[0])
+    s = butterfly(v)
+    v = [p[17 + l] if 17 + l < 32 else np.zeros_like(s) for l in range(16)]
+    v[0] = fma(h2[:, 17], np.broadcast_to(W3[17], h2[:, 17].shape), s)
+    return (butterfly(v) + f32(b3)).astype(f32)
+
+
 def bn_pairs(P):
     invstd = (f32(1) / np.sqrt(P["var"] + f32(1e-5))).astype(f32)
     alpha = (P["g"] * invstd).astype(f32)
