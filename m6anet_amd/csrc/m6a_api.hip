@@ -1147,6 +1147,12 @@ int m6a_create(m6a_ctx **out, const float *weights, size_t n_floats, int device_
     CRCHK(hipHostMalloc((void **)&c->h_ctl, kCtlWords * 4, hipHostMallocDefault));
     for (int n = 0; n <= M6A_RTAB_MAX_N; n++) c->rt.slot_of_n[n] = -1;
 #undef CRCHK
+    // M6A_ENCODER=general16 | csite12: the context starts with that encoder kernel selected (m6a_set_encoder_variant 1 / 2)
+    // -- for callers that cannot be changed, e.g. to run the CLI on the 16-slot kernel, whose layers 1-2 are the reference's bits
+    if (const char *ev = getenv("M6A_ENCODER")) {
+        if (!strcmp(ev, "general16")) c->enc_variant = 1;
+        else if (!strcmp(ev, "csite12")) c->enc_variant = 2;
+    }
     const char *w = getenv("M6A_WARMUP");
     if (!(w && w[0] == '0')) {
         try { c->warm = std::thread(warm_default, c); } catch (...) { /* no thread: the first call sets up what it needs */ }

@@ -162,6 +162,20 @@ def test_encoder_variants_vs_oracle(engines, orc, weights, variant, name, bags):
         assert np.allclose(got, want, rtol=1e-5, atol=1e-8), (model, name)
 
 
+def test_encoder_variant_from_the_environment(weights, monkeypatch):
+    """M6A_ENCODER preselects the kernel for callers that cannot call m6a_set_encoder_variant (the CLI)."""
+    from m6anet_amd.engine import M6ANetEngine
+    X, km, off = rand_sites(5, [20] * 40)
+    for value, want in (("general16", "general16"), ("csite12", "csite12"), ("nonsense", "csite12")):
+        monkeypatch.setenv("M6A_ENCODER", value)
+        e = M6ANetEngine(weights=weights["hct116"])
+        try:
+            e.get_read_probability(X, km, off)
+            assert e.last_encoder_variant == want, value
+        finally:
+            e.close()
+
+
 def test_encoder_variant_selection_and_precondition(eng):
     from m6anet_amd._lib import M6AError
     X, km, off = rand_sites(1, [20] * 40)
