@@ -175,6 +175,7 @@ def main():
     ref = np.load(os.path.join(REPO, "tests", "golden", "reference_at_scale.npz"))["uniform_%s_readprob" % name][:R]
     print(name, R, "reads; against the REFERENCE's read probabilities:")
     line("torch's order, layer 3 as one chain of 32", torch_like(P, inp), ref)
+    line("torch's order, layer 3 as MKL's AVX-512 gemv", sigmoid(mkl_avx512_gemv_32(torch_like(P, inp, upto="h2"), P["W3"], P["b3"])), ref)
     line("rounds 1-3 general16 (emulated)", kernel_r3(P, inp), ref)
     eg, ec = kernel_general16(P, inp), kernel_csite12(P, inp)
     line("general16 (emulated)", eg, ref)
