@@ -14,9 +14,8 @@
  *     intermediate tensors, every candidate order compared bit for bit (tools/emulate_encoder.py):
  *       Linear      : acc = 0; acc = fma(x[k], W[j][k], acc) for k = 0, 1, 2, ...; then acc + b[j]   (MKL sgemm, any batch >= 7 rows)
  *       BatchNorm1d : alpha = gamma * (1 / sqrt(var + eps)); beta = fma(-mean, alpha, bias); y -> fma(y, alpha, beta)
- *     Layers 1 and 2 below reproduce torch's values bit for bit; the 32 -> 1 layer is an MKL gemv whose lane order
- *     depends on row count and alignment (no fixed order to restate: summed left to right here), and the sigmoid's exp
- *     is Sleef's in torch, libm's here (1 ulp apart on a few percent of the reads).
+ *     Layers 1 and 2 below reproduce torch's values bit for bit; the 32 -> 1 layer follows the AVX-512 sgemv of the
+ *     machine the captures were made on (gemv32 below), and the sigmoid's exp is Sleef's, restated (sleef_expf_u10 below).
  */
 #include "m6a_oracle.h"
 
@@ -139,6 +138,60 @@ static void enc_prepare(const float *w, enc_tables *t)
     t->emb = w + O_E;
 }
 
+/* Linear(32, 1) as the sgemv behind torch's addmm computes it in the build container (MKL 2024.2, AVX-512; rows in groups of
+ * four -- every row of a batch of 20-read bags, all but the last 0..3 rows of any other batch, which take a path this does not
+ * restate): found by probing the module itself with cancellation triples (2^24, 1, -2^24 on every triple of inputs) and then
+ * checked bit for bit against the reference's logits (tests/golden/reference_layers.npz):
+ *     s = x0*w0;   16 lanes of products k = 1 + l, lane 0 = fma(x1, w1, s);   butterfly l+8, l+4, l+2, l+1;
+ *     the same for k = 17 + l (lane 15 empty), lane 0 = fma(x17, w17, sum so far).
+ * This is one MKL kernel on one ISA, not m6anet's algorithm: the HIP kernels do NOT follow it.  The
+ * oracle does, because it is pinned to captures made on that machine and stands in for the reference on the GPU box -- with
+ * it (and Sleef's exp), the oracle's read probabilities ARE the capture's, bit for bit, on every read of a 20-read-bag job. */
+static inline float butterfly16(float *v)
+{
+    for (int step = 8; step >= 1; step >>= 1)
+        for (int l = 0; l < step; l++) v[l] = v[l] + v[l + step];
+    return v[0];
+}
+
+static inline float gemv32(const float *x, const float *w)
+{
+    float v[16];
+    const float s0 = x[0] * w[0];
+    for (int l = 0; l < 16; l++) v[l] = x[1 + l] * w[1 + l];
+    v[0] = fmaf(x[1], w[1], s0);
+    const float s1 = butterfly16(v);
+    for (int l = 0; l < 15; l++) v[l] = x[17 + l] * w[17 + l];
+    v[15] = 0.0f;
+    v[0] = fmaf(x[17], w[17], s1);
+    return butterfly16(v);
+}
+
+/* exp as torch's vectorised sigmoid computes it: Sleef's expf with 1.0-ulp bound (Sleef_expf16_u10 / Sleef_expf8_u10,
+ * sleefsimdsp.c `xexpf`, Boost licence; restated from the published algorithm: Cody-Waite reduction by ln 2 in two parts, a
+ * degree-6 polynomial in fma form, scaling by 2^q in two factors).  Checked in the build container against torch.sigmoid on
+ * 2 M random floats in [-40, 40]: 99.9997 % identical. */
+static inline float sleef_expf_u10(float d)
+{
+    const float R_LN2f = 1.442695040888963407359924681001892137426645954152985934135449406931f;
+    const float L2Uf = 0.693145751953125f, L2Lf = 1.428606765330187045e-06f;
+    const int q = (int)rintf(d * R_LN2f);
+    float s = fmaf((float)q, -L2Uf, d);
+    s = fmaf((float)q, -L2Lf, s);
+    float u = 0.000198527617612853646278381f;
+    u = fmaf(u, s, 0.00139304355252534151077271f);
+    u = fmaf(u, s, 0.00833336077630519866943359f);
+    u = fmaf(u, s, 0.0416664853692054748535156f);
+    u = fmaf(u, s, 0.166666671633720397949219f);
+    u = fmaf(u, s, 0.5f);
+    u = 1.0f + fmaf(s * s, u, s);
+    const int q1 = q >> 1, q2 = q - q1;
+    u = u * ldexpf(1.0f, q1) * ldexpf(1.0f, q2);
+    if (d < -104.0f) u = 0.0f;
+    if (d > 104.0f) u = INFINITY;
+    return u;
+}
+
 /* fmaf is one instruction in the first two clones (any x86 with FMA3: the GPU boxes and the build container have it) and
  * libm's correctly rounded software fma in the last: same bits, ~35x slower */
 __attribute__((target_clones("avx512f", "fma", "default")))
@@ -168,17 +221,14 @@ static void enc_range(const enc_tables *t, const float *X, const uint8_t *site_k
                 const float hk = h1[k];
                 for (int j = 0; j < 32; j++) h2[j] = fmaf(hk, t->w2t[k][j], h2[j]);
             }
-            float z = 0.0f;
             for (int j = 0; j < 32; j++) {
                 float a = h2[j] + t->b2[j];
-                a = a < 0.0f ? 0.0f : a;
-                z = fmaf(a, t->w3[j], z);
+                h2[j] = a < 0.0f ? 0.0f : a;
             }
-            z += t->b3;
-            if (hidden)
-                for (int j = 0; j < 32; j++) { float a = h2[j] + t->b2[j]; hidden[32 * r + j] = a < 0.0f ? 0.0f : a; }
+            const float z = gemv32(h2, t->w3) + t->b3;
+            if (hidden) memcpy(hidden + 32 * r, h2, 32 * sizeof(float));
             if (logit) logit[r] = z;
-            read_prob[r] = 1.0f / (1.0f + expf(-z));
+            read_prob[r] = 1.0f / (1.0f + sleef_expf_u10(-z));
         }
     }
 }

@@ -2,7 +2,8 @@
 
 Only tests/, __graft_entry__.smoke() and bench.py's `cpu_baseline` leg may import this
 module; the product (m6anet_amd/) never does.  Parity status: pinned -- see
-tests/test_oracle_golden.py.
+tests/test_oracle_golden.py and tests/test_reference_at_scale.py (read and site probabilities of the 20-read-bag capture
+reproduced bit for bit).
 """
 import ctypes as C
 import os

@@ -31,8 +31,11 @@ def bar_use(got, want):
 
 # Since round 4 the oracle and the kernels add in the ORDER the reference's float32 arithmetic adds in (DESIGN.md section
 # 2): the distance to its values is a fraction of the bar, and these tighter figures are the regression net for that order
-# (measured on these fixtures: oracle 0.49, general16 0.44, csite12 0.68; rounds 1-3: 0.81 / 0.84 / 0.83).
-ORDER_BAR = {"oracle": 0.60, "general16": 0.55, "csite12": 0.80}
+# (measured on these fixtures: general16 0.44, csite12 0.68; rounds 1-3: 0.84 / 0.83).  The ORACLE goes further -- it also
+# follows the 32 -> 1 gemv and the exp of the machine the captures were made on -- and must reproduce the capture's read
+# probabilities BIT FOR BIT on the 20-read-bag job (1 M reads x 4 checkpoints); on the ragged job all but the rows MKL's
+# thread partition leaves outside its groups of four (0.05 % of them, each within 0.21 of the bar).
+ORDER_BAR = {"general16": 0.55, "csite12": 0.80}
 
 _jobs = {}
 
@@ -58,15 +61,19 @@ def test_oracle_read_probabilities_vs_reference_at_scale(golden, weights, tag):
     R = int(d["off"][keep_reads])
     for name in MODELS:
         got = orc.encode_reads(weights[name], d["X"][:R], d["site_kmers"][:keep_reads], d["off"][:keep_reads + 1], n_threads=4)
-        u = bar_use(got, G[f"{tag}_{name}_readprob"])
-        assert u.max() <= ORDER_BAR["oracle"], (tag, name, float(u.max()), int((u > 1).sum()))
+        want = G[f"{tag}_{name}_readprob"]
+        differing = int((got.view(np.uint32) != want.view(np.uint32)).sum())
+        if tag == "uniform":
+            assert differing == 0, (tag, name, differing)
+        else:
+            assert differing <= 1e-3 * got.size and bar_use(got, want).max() <= 0.3, (tag, name, differing, float(bar_use(got, want).max()))
 
 
 @pytest.mark.parametrize("tag", list(SHAPES))
 def test_oracle_layers_are_the_references_bits(golden, weights, tag):
     """tests/golden/reference_layers.npz: the reference's own read representation (layer 2 after ReLU) -- the oracle's must
     be the same BITS (Linear = fma chain over k then + bias, batch norm = fma(y, alpha, beta): torch's CPU arithmetic,
-    pinned); the logit (a 32-term MKL gemv of no fixed order) within a few ulp of a 20-ish magnitude sum."""
+    pinned), and so must its logit (the AVX-512 sgemv's order, oracle/m6a_oracle.c gemv32)."""
     from oracle import m6a_oracle as orc
     L = golden("reference_layers.npz")
     n, bag, _, _ = SHAPES[tag]
@@ -76,7 +83,7 @@ def test_oracle_layers_are_the_references_bits(golden, weights, tag):
     for name in MODELS:
         p, h2, z = orc.encode_layers(weights[name], d["X"][:R], d["site_kmers"][:keep], d["off"][:keep + 1])
         assert np.array_equal(h2.view(np.uint32), L[f"{tag}_{name}_h2"].view(np.uint32)), (tag, name)
-        assert np.abs(z.astype(np.float64) - L[f"{tag}_{name}_logit"]).max() <= 8e-6, (tag, name)
+        assert np.array_equal(z.view(np.uint32), L[f"{tag}_{name}_logit"].view(np.uint32)), (tag, name)
 
 
 def test_numpy_emulation_of_the_order_reproduces_the_references_hidden_layer(golden, weights):
@@ -116,7 +123,9 @@ def test_oracle_site_probabilities_vs_reference_at_scale(golden, weights, tag):
         assert np.array_equal(site, G[f"{tag}_{name}_site_T1000"][:S]), (tag, name)
         assert np.array_equal(mod, G[f"{tag}_{name}_mod"][:S]), (tag, name)
         p_own = orc.encode_reads(weights[name], d["X"][:int(off[-1])], d["site_kmers"][:S], off, n_threads=4)
-        site2, _ = orc.site_pool(p_own, off, 1000, THR)
+        site2, mod2 = orc.site_pool(p_own, off, 1000, THR)
+        if tag == "uniform":                     # identical read probabilities -> the reference's site rows, bit for bit
+            assert np.array_equal(site2, G[f"{tag}_{name}_site_T1000"][:S]) and np.array_equal(mod2, G[f"{tag}_{name}_mod"][:S]), (tag, name)
         assert np.abs(site2.astype(np.float64) - G[f"{tag}_{name}_site_T1000"][:S]).max() <= 1e-5, (tag, name)
 
 
