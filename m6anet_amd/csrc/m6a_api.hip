@@ -107,6 +107,14 @@ void build_fragments(const float *w, std::vector<float> &frag, std::vector<float
     // register q of the two halves -- adds units 32m + 2q and 32m + 2q + 1, in that order: k = 0, 1, 2, ... 149, then the
     // constant-one unit 150 (b2, added last as the reference adds it) and the zero unit 151.
     auto unit_of_row = [](int m, int i) { return 32 * m + 2 * ((i & 3) + 4 * (i >> 3)) + ((i >> 2) & 1); };
+    // Layer 2's OUTPUT units on the accumulator rows: register q of lane half h holds output unit out_unit(q, h) -- the
+    // even lanes of the reference's two 16-lane gemv vectors in half 0, the odd lanes and k = 0 in half 1 (m6a_kernels.hip,
+    // gemv32_as_mkl); the 12-slot kernel sums its half's 16 registers in register order, whatever units they are.
+    auto out_unit = [](int q, int half) {
+        if (half == 0) return q < 8 ? 2 * q + 1 : 2 * (q - 8) + 17;
+        return q < 8 ? 2 * q + 2 : (q < 15 ? 2 * (q - 8) + 18 : 0);
+    };
+    auto out_unit_of_row = [&](int i) { return out_unit((i & 3) + 4 * (i >> 3), (i >> 2) & 1); };
     frag.assign(M6A_WFRAG_FLOATS, 0.f);
     for (int lane = 0; lane < 64; lane++) {
         const int col = lane & 31, half = lane >> 5;
@@ -114,10 +122,10 @@ void build_fragments(const float *w, std::vector<float> &frag, std::vector<float
             for (int st = 0; st < 8; st++)      // A[i=col][k=half] of step st <-> feature 2st + half
                 frag[(m * 8 + st) * 64 + lane] = w1[unit_of_row(m, col) * 16 + 2 * st + half];
             for (int q = 0; q < 16; q++)        // A[o=col][k=half] of step q <-> hidden unit 32m + 2q + half
-                frag[(40 + m * 16 + q) * 64 + lane] = w2[col * 160 + 32 * m + 2 * q + half];
+                frag[(40 + m * 16 + q) * 64 + lane] = w2[out_unit_of_row(col) * 160 + 32 * m + 2 * q + half];
         }
-        for (int q = 0; q < 16; q++)            // layer 2's output rows stay in register order (layer 3's sum has no pinned order)
-            frag[(120 + q) * 64 + lane] = w3_scale * w[O_W3 + (q & 3) + 8 * (q >> 2) + 4 * half];
+        for (int q = 0; q < 16; q++)
+            frag[(120 + q) * 64 + lane] = w3_scale * w[O_W3 + out_unit(q, half)];
     }
     // 12-slot kernel: x-slot fragments W1[u][2st+half] (st<4), W1[u][8]; and the per-unit rows the per-site c vectors are
     // formed from: W1[u][9..14], b1[u]

@@ -129,6 +129,65 @@ __device__ __forceinline__ void layer2_with_bn(f32x16 &acc2, f32x16 &cur, const 
     }
 }
 
+// exp as torch's vectorised sigmoid computes it -- Sleef's expf with the 1.0-ulp bound (sleefsimdsp.c `xexpf`; restated from the
+// published algorithm, as in oracle/m6a_oracle.c): Cody-Waite reduction by ln 2 in two parts, a degree-6 polynomial in fma form,
+// 2^q applied as two factors.  Only the 16-slot kernel uses it (its read probabilities are the reference's bits, below).
+__device__ __forceinline__ float sleef_expf_u10(float d)
+{
+    const float qf = __builtin_rintf(d * 1.442695040888963407359924681001892137426645954152985934135449406931f);
+    const int q = (int)qf;
+    float s = __builtin_fmaf(qf, -0.693145751953125f, d);
+    s = __builtin_fmaf(qf, -1.428606765330187045e-06f, s);
+    float u = 0.000198527617612853646278381f;
+    u = __builtin_fmaf(u, s, 0.00139304355252534151077271f);
+    u = __builtin_fmaf(u, s, 0.00833336077630519866943359f);
+    u = __builtin_fmaf(u, s, 0.0416664853692054748535156f);
+    u = __builtin_fmaf(u, s, 0.166666671633720397949219f);
+    u = __builtin_fmaf(u, s, 0.5f);
+    u = 1.0f + __builtin_fmaf(s * s, u, s);
+    const int q1 = q >> 1;
+    u = u * ldexpf(1.0f, q1) * ldexpf(1.0f, q - q1);
+    u = d < -104.0f ? 0.0f : u;
+    return d > 104.0f ? __builtin_inff() : u;
+}
+
+// Linear(32, 1) in the order of the sgemv behind torch's addmm on the machine the reference captures were made on (MKL,
+// AVX-512; rows of a batch in groups of four -- every row of a job of 20-read bags; found by probing the module with
+// cancellation triples): s = x0*w0; 16 lanes of products k = 1 + l with lane 0 = fma(x1, w1, s),
+// reduced by a butterfly l+8, l+4, l+2, l+1; the same for k = 17 + l (lane 15 empty) with lane 0 = fma(x17, w17, sum so far).
+// The host wires layer 2's output units to the accumulator rows so that lane half 0 holds the EVEN lanes of both vectors
+// (k = 1, 3, .., 15 in registers 0..7; 17, 19, .., 31 in 8..15) and half 1 the odd lanes (k = 2, 4, .., 16; 18, .., 30) plus
+// k = 0 in register 15: every butterfly level but the last stays inside a half (lane l <-> register l >> 1), the last is the
+// exchange between the halves.  t[q] = 2 relu(acc2[q]), w[q] = 0.5 W3[unit]: the products are relu * W3 exactly.
+__device__ __forceinline__ float gemv32_as_mkl(const f32x16 &acc2, const float (&w)[16], int half)
+{
+    float r[16];
+#pragma unroll
+    for (int q = 0; q < 16; q++) r[q] = relu2(acc2[q]);
+    const float k0 = r[15] * w[15];                                   // half 1: x0*w0; half 0: the product of k = 31
+    // every exchange is executed by ALL lanes and selected afterwards (a shuffle under a divergent branch reads zeros from
+    // the lanes that did not take it; the empty asm keeps the compiler from sinking it into the select)
+    float k0_other = __shfl_xor(k0, 32, 64);
+    asm volatile("" : "+v"(k0_other));
+    const float s0 = half ? 0.0f : k0_other;                          // fma(x, w, +0) is the rounded product itself
+    float v[8];
+    v[0] = __builtin_fmaf(r[0], w[0], s0);
+#pragma unroll
+    for (int q = 1; q < 8; q++) v[q] = r[q] * w[q];
+    float c = ((v[0] + v[4]) + (v[2] + v[6])) + ((v[1] + v[5]) + (v[3] + v[7]));
+    float c_other = __shfl_xor(c, 32, 64);
+    asm volatile("" : "+v"(c_other));
+    const float t1 = c + c_other;
+    v[0] = __builtin_fmaf(r[8], w[8], half ? 0.0f : t1);
+#pragma unroll
+    for (int q = 1; q < 7; q++) v[q] = r[8 + q] * w[8 + q];
+    v[7] = half ? 0.0f : k0;
+    c = ((v[0] + v[4]) + (v[2] + v[6])) + ((v[1] + v[5]) + (v[3] + v[7]));
+    c_other = __shfl_xor(c, 32, 64);
+    asm volatile("" : "+v"(c_other));
+    return c + c_other;
+}
+
 // A value the program knows to be wave-uniform, made provably so: addresses built from it use
 // scalar loads (s_load, counted by lgkmcnt) instead of vector loads (in-order vmcnt queue).
 __device__ __forceinline__ int64_t uniform_i64(int64_t v)
@@ -311,12 +370,8 @@ __global__ __launch_bounds__(256, 2) void enc_kernel(EncArgs a)
             if (m == 3) layer2_with_bn<3>(acc2, cur, w2, bnq, bn_half);
             if (m == 4) layer2_with_bn<4>(acc2, cur, w2, bnq, bn_half);
         }
-        float z = 0.0f;
-#pragma unroll
-        for (int q = 0; q < 16; q++) z = fmaf(relu2(acc2[q]), w3[q], z);
-        z += __shfl_xor(z, 32, 64);
-        z += a.b3;
-        const float p = 1.0f / (1.0f + expf(-z));
+        const float z = gemv32_as_mkl(acc2, w3, half) + a.b3;
+        const float p = 1.0f / (1.0f + sleef_expf_u10(-z));
         const int64_t r = tile * 32 + col;
         if (half == 0 && r < a.n_reads) a.read_prob[r] = p;
         if (tn != tile) s_base = uniform_i64(__shfl(sn, 31, 64));

@@ -153,49 +153,32 @@ def test_hip_read_probabilities_vs_reference_at_scale(golden, engines, tag, vari
             assert e.last_encoder_variant == label
         finally:
             e.set_encoder_variant(0)
-        u = bar_use(got, G[f"{tag}_{name}_readprob"])
+        want = G[f"{tag}_{name}_readprob"]
+        u = bar_use(got, want)
         assert u.max() <= ORDER_BAR[label], (tag, name, label, float(u.max()), int((u > 1).sum()))
-
-
-def _layer3_as_the_kernels_sum_it(h2, W3, b3):
-    """Both kernels: each lane half adds its 16 rows of layer 2 (row (q&3) + 8(q>>2) + 4 half for q = 0..15) as one fma
-    chain, the halves are added, then b3; sigmoid as 1 / (1 + exp(-z)) in float32 (here with a correctly rounded exp)."""
-    f64 = np.float64
-    z = []
-    for hf in (0, 1):
-        acc = np.zeros(h2.shape[0], np.float32)
-        for q in range(16):
-            r = (q & 3) + 8 * (q >> 2) + 4 * hf
-            acc = (h2[:, r].astype(f64) * f64(W3[r]) + acc.astype(f64)).astype(np.float32)
-        z.append(acc)
-    zz = (z[0] + z[1]) + np.float32(b3)
-    return (np.float32(1) / (np.float32(1) + np.exp(-zz.astype(f64)).astype(np.float32))).astype(np.float32)
+        if label == "general16":
+            # the 16-slot kernel follows the reference all the way (layers 1-2, the capture machine's gemv order, Sleef's
+            # exp): on the 20-read-bag job its read probabilities ARE the reference's; on the ragged job all but the rows
+            # MKL's thread partition leaves outside its groups of four
+            differing = int((got.view(np.uint32) != want.view(np.uint32)).sum())
+            assert differing == 0 if tag == "uniform" else differing <= 1e-3 * got.size, (tag, name, differing)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("tag", list(SHAPES))
-def test_hip_general16_follows_the_references_hidden_layer(golden, engines, weights, tag):
-    """enc_kernel's layers 1 and 2 are meant to be the reference's bits.  The C ABI hands out probabilities only, so:
-    take the REFERENCE's read representation (tests/golden/reference_layers.npz), finish it the way the kernel finishes
-    (its own 32 -> 1 order, above) and compare -- all that may differ is the device's expf against a correctly rounded
-    exp: a few ulp of the probability at most (4 seen, on logits near -30), identical for 95 % of the reads.  A layer-1/2
-    sum in any other order leaves ~11-22 % identical (tools/emulate_encoder.py)."""
-    L = golden("reference_layers.npz")
-    n, bag, _, _ = SHAPES[tag]
-    keep = int(L[f"{tag}_sites"])
-    d = synthetic.make_sites(n, bag, seed=20250328, prefix_sites=keep)
-    R = int(d["off"][keep])
+def test_hip_general16_site_rows_are_the_references(golden, engines):
+    """With the 16-slot kernel the whole path is the reference's arithmetic: on the 20-read-bag job probability_modified and
+    mod_ratio of every site come out bit-identical to the reference's (10 000 sites x 4 checkpoints, T = 1000)."""
+    d, G, _, keep_sites = job(golden, "uniform")
+    off = d["off"][:keep_sites + 1]
+    R = int(off[-1])
     for name in MODELS:
         e = engines[name]
         e.set_encoder_variant(1)
         try:
-            got = e.get_read_probability(d["X"][:R], d["site_kmers"][:keep], d["off"][:keep + 1])
+            rp, site, mod = e.infer(d["X"][:R], d["site_kmers"][:keep_sites], off, 1000)
         finally:
             e.set_encoder_variant(0)
-        w = weights[name]
-        want = _layer3_as_the_kernels_sum_it(L[f"{tag}_{name}_h2"], w[7964:7996], w[7996])
-        ulp = np.abs(got.view(np.int32).astype(np.int64) - want.view(np.int32).astype(np.int64))
-        assert ulp.max() <= 8 and (ulp == 0).mean() >= 0.85, (tag, name, int(ulp.max()), float((ulp == 0).mean()))
+        assert np.array_equal(site, G[f"uniform_{name}_site_T1000"]) and np.array_equal(mod, G[f"uniform_{name}_mod"]), name
 
 
 @pytest.mark.gpu

@@ -52,6 +52,28 @@ def sigmoid(z):
     return (f32(1) / (f32(1) + np.exp(-z.astype(f64)).astype(f32))).astype(f32)
 
 
+def sleef_expf(d):
+    """Sleef's expf (u10) as torch's vectorised sigmoid calls it: 99.9997 % identical to torch.sigmoid's over 2 M random floats."""
+    d = d.astype(f32)
+    sh = d.shape
+    c = lambda x: np.broadcast_to(f32(x), sh)                                      # noqa: E731
+    qf = np.rint((d * f32(1.442695040888963407359924681001892137426645954152985934135449406931)).astype(f32)).astype(f32)
+    q = qf.astype(np.int32)
+    s_ = fma(qf, c(-0.693145751953125), d)
+    s_ = fma(qf, c(-1.428606765330187045e-06), s_)
+    u = c(0.000198527617612853646278381).copy()
+    for k in (0.00139304355252534151077271, 0.00833336077630519866943359, 0.0416664853692054748535156, 0.166666671633720397949219, 0.5):
+        u = fma(u, s_, c(k))
+    u = (f32(1.0) + fma((s_ * s_).astype(f32), u, s_)).astype(f32)
+    q1 = q >> 1
+    u = ((u * np.ldexp(f32(1), q1).astype(f32)).astype(f32) * np.ldexp(f32(1), q - q1).astype(f32)).astype(f32)
+    return np.where(d < -104, f32(0), u).astype(f32)
+
+
+def sigmoid_sleef(z):
+    return (f32(1) / (f32(1) + sleef_expf(-z))).astype(f32)
+
+
 def torch_like(P, inp, upto="p"):
     y = chain(inp, P["W1"], range(15)) + P["b1"]
     invstd = (f32(1) / np.sqrt(P["var"] + f32(1e-5))).astype(f32)
@@ -107,10 +129,17 @@ def old_unit_order(m):
     return out
 
 
+def out_unit(q, half):
+    """Layer 2's output unit in accumulator register q of lane half `half` (m6a_api.hip build_fragments)."""
+    if half == 0:
+        return 2 * q + 1 if q < 8 else 2 * (q - 8) + 17
+    return 2 * q + 2 if q < 8 else (2 * (q - 8) + 18 if q < 15 else 0)
+
+
 def layer3_halves(P, h2):
-    """Both kernels: each lane half sums its 16 rows of layer 2 ((q&3) + 8(q>>2) + 4 half, q = 0..15) as one fma chain, the
-    halves are added, then b3."""
-    rows = [[(q & 3) + 8 * (q >> 2) + 4 * hf for q in range(16)] for hf in (0, 1)]
+    """The 12-slot kernel: each lane half sums the 16 output units in its registers (out_unit) as one fma chain in register
+    order, the halves are added, then b3.  (Rounds 1-3 and the first half of round 4: rows (q&3) + 8(q>>2) + 4 half.)"""
+    rows = [[out_unit(q, hf) for q in range(16)] for hf in (0, 1)]
     z0 = chain(h2[:, rows[0]], P["W3"][None, rows[0]], range(16))
     z1 = chain(h2[:, rows[1]], P["W3"][None, rows[1]], range(16))
     return ((z0 + z1) + P["b3"])[:, 0]
@@ -131,15 +160,20 @@ def kernel_r3(P, inp):
     x16 = np.concatenate([inp, np.ones((inp.shape[0], 1), f32)], 1)
     ks = sum(([st, st + 8] for st in range(8)), [])
     h = np.maximum(chain(x16, folded(P), ks), 0)
-    return sigmoid(layer3_halves(P, layer2(P, h, sum((old_unit_order(m) for m in range(5)), []))))
+    h2 = layer2(P, h, sum((old_unit_order(m) for m in range(5)), []))
+    rows = [[(q & 3) + 8 * (q >> 2) + 4 * hf for q in range(16)] for hf in (0, 1)]
+    z0 = chain(h2[:, rows[0]], P["W3"][None, rows[0]], range(16))
+    z1 = chain(h2[:, rows[1]], P["W3"][None, rows[1]], range(16))
+    return sigmoid(((z0 + z1) + P["b3"])[:, 0])
 
 
 def kernel_general16(P, inp):
-    """enc_kernel now: the reference's operations through layer 2 (k = 0..14, + b1; fma batch norm; k = 0..149, + b2)."""
+    """enc_kernel now: the reference's operations all the way (k = 0..14, + b1; fma batch norm; k = 0..149, + b2; the AVX-512
+    gemv's order; Sleef's exp)."""
     alpha, beta = bn_pairs(P)
     y = chain(inp, P["W1"], range(15)) + P["b1"]
     h = np.maximum(fma(y, np.broadcast_to(alpha, y.shape), np.broadcast_to(beta, y.shape)), 0)
-    return sigmoid(layer3_halves(P, layer2(P, h, range(152))))
+    return sigmoid_sleef(mkl_avx512_gemv_32(layer2(P, h, range(152)), P["W3"], P["b3"]))
 
 
 def kernel_csite12(P, inp):
@@ -175,7 +209,7 @@ def main():
     ref = np.load(os.path.join(REPO, "tests", "golden", "reference_at_scale.npz"))["uniform_%s_readprob" % name][:R]
     print(name, R, "reads; against the REFERENCE's read probabilities:")
     line("torch's order, layer 3 as one chain of 32", torch_like(P, inp), ref)
-    line("torch's order, layer 3 as MKL's AVX-512 gemv", sigmoid(mkl_avx512_gemv_32(torch_like(P, inp, upto="h2"), P["W3"], P["b3"])), ref)
+    line("torch's order, layer 3 as MKL's AVX-512 gemv, Sleef's exp", sigmoid_sleef(mkl_avx512_gemv_32(torch_like(P, inp, upto="h2"), P["W3"], P["b3"])), ref)
     line("rounds 1-3 general16 (emulated)", kernel_r3(P, inp), ref)
     eg, ec = kernel_general16(P, inp), kernel_csite12(P, inp)
     line("general16 (emulated)", eg, ref)
