@@ -84,7 +84,7 @@ def rank_argv(args):
     """The command line of a rank: the launcher's own options (the pretrained-model defaults are resolved again there)."""
     argv = ["--input_dir"] + [str(d) for d in args.input_dir] + ["--out_dir", str(args.out_dir)]
     for name in ("pretrained_model", "model_config", "model_state_dict", "norm_path", "batch_size", "save_per_batch", "n_processes",
-                 "num_iterations", "device", "seed", "read_proba_threshold", "gpus"):
+                 "num_iterations", "device", "seed", "read_proba_threshold", "gpus", "encoder"):
         v = getattr(args, name)
         if v is not None:
             argv += ["--" + name, str(v)]

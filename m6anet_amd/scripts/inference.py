@@ -40,6 +40,13 @@ def argparser():
     parser.add_argument("--gpus", default=1, type=int,
                         help="GPUs of this node to split the job's sites over: one process per GPU, flush-group-aligned shards, "
                              "one RCCL gather to the rank that writes the CSVs; the output does not depend on it.")
+    parser.add_argument("--encoder", default="reference", choices=["reference", "fast"],
+                        help="read encoder kernel.  reference (default): the 16-slot kernel, which performs the reference's float32 "
+                             "operations in the reference's order all the way to the sigmoid -- read probabilities bit-identical "
+                             "to `m6anet inference` on an AVX-512 host wherever MKL groups a batch's rows in fours (every read of "
+                             "20-read bags, > 99.9 %% of ragged ones); fast: the automatic choice, for bags of >= 16 reads a 12-slot "
+                             "kernel 10 %% faster and within 1e-5 relative of the reference.  The encoder is under 1 %% of this "
+                             "command's wall time either way.  The environment variable M6A_ENCODER overrides both.")
     parser.add_argument("--drop_unflushed_tail", action="store_true",
                         help="reference-compatible output: omit the batches after the reference's last flush, which "
                              "`m6anet inference` never writes (its flush test is inverted); default: write every site.")
@@ -92,6 +99,8 @@ def main(args):
 
     if args.gpus < 1:
         raise ValueError("--gpus must be >= 1")
+    if args.encoder == "reference":
+        os.environ.setdefault("M6A_ENCODER", "general16")     # read by m6a_create; inherited by the ranks of a --gpus N job
     if "M6A_RANK" in os.environ:                         # one rank of a --gpus N job (started by multi_gpu.launch)
         from .. import multi_gpu
         multi_gpu.run_rank(args, weights)
