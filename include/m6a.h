@@ -250,9 +250,11 @@ int m6a_profile_enable(m6a_ctx *ctx, int on);
 int m6a_profile_read(m6a_ctx *ctx, int kind, double *total_ms, int64_t *n_launches);
 /* Tuning knob for the read encoder: 0 = auto (default), 1 = general kernel (16 K-slots, any bags),
  * 2 = 12-slot kernel (per-site constants folded; requires every bag >= 16 reads -- a call that
- * violates this reports M6A_EINVAL at the next sync).  Results agree to float32 rounding: the general kernel's layers 1-2
- * are the reference's bits, the 12-slot kernel adds a site's six embedding terms and b1 pre-summed.  The
- * environment variable M6A_ENCODER=general16|csite12 preselects 1 / 2 in every context the process creates. */
+ * violates this reports M6A_EINVAL at the next sync).  Results agree to float32 rounding: the general kernel performs the
+ * reference's float32 operations in the reference's order all the way (its read probabilities are those of torch on an
+ * AVX-512 host, bit for bit, for every read of a 20-read-bag job); the 12-slot kernel, 10 % faster, adds a site's six
+ * embedding terms and b1 pre-summed and sums the 32 -> 1 layer in register order.  The environment variable
+ * M6A_ENCODER=general16|csite12 preselects 1 / 2 in every context the process creates. */
 int m6a_set_encoder_variant(m6a_ctx *ctx, int mode);
 const char *m6a_last_encoder_variant(const m6a_ctx *ctx);   /* "general16" | "csite12" */
 /* Tuning knob for ragged bags: 0 = auto (default: per-bag-size index tables once the work seen pays for them, else
