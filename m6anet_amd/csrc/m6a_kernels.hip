@@ -4,7 +4,8 @@
 //                      read encoder: [x(9) | emb(6) | 1] -> 150 -> batch norm -> ReLU -> 32 -> ReLU
 //                      -> 1 -> sigmoid, all in registers on v_mfma_f32_32x32x2_f32 (two IEEE fmas per output, k = the
 //                      half-0 operand first), every sum through layer 2 in the order the reference's float32 arithmetic
-//                      runs it; the csite variant folds the per-site constants (12 K-slots, bags >= 16 reads).
+//                      runs it -- enc_kernel all the way to the probability (the reference's bits); the csite variant
+//                      folds the per-site constants (12 K-slots, bags >= 16 reads) and keeps a plain 32 -> 1 sum.
 //   pool_scan_start_kernel + pool_scan_site_kernel, pool_scan_group_kernel
 //                      site pooling, exact NumPy-stream replay, any bag sizes: a counting pass per
 //                      flush group finds where each site starts in the shared MT19937 word stream
@@ -223,9 +224,8 @@ __device__ __forceinline__ void wave_lds_fence()
 //   hidden unit 150 is wired to the constant 1.0 (alpha 1, beta 0) and adds b2 through W2aug[:,150];
 //   units 151..159 are zero padding.
 // K slot 2s + h holds feature 2s + h: half 0 lanes load x0, x2, x4, x6, x8, e1, e3, e5; half 1 lanes x1, x3,
-// x5, x7, e0, e2, e4, 1.  With that, layers 1 and 2 of this kernel are the reference's bits; what is left
-// between its read probabilities and the reference's is the 32 -> 1 sum (an MKL gemv there, whose lane order
-// depends on row count and alignment) and the exp.
+// x5, x7, e0, e2, e4, 1.  With that, layers 1 and 2 of this kernel are the reference's bits; the epilogue
+// (gemv32_as_mkl, sleef_expf_u10 above) carries that on to the probability.
 // =====================================================================================
 // Input pipeline: the features of tile t+1 are fetched while tile t is on the matrix pipe.  The
 // site lookup is a dependent chain (CSR offsets -> k-mer ids -> embedding rows); its three links
