@@ -48,11 +48,13 @@ def main():
                 got = e.get_read_probability(d["X"][:R], d["site_kmers"][:keep_reads], d["off"][:keep_reads + 1])
                 u = use(got, ref)
                 r[label] = {"worst_use": float(u.max()), "reads_beyond_bar": int((u > 1).sum()), "p99.99_use": float(np.quantile(u, 0.9999)),
-                            "ref_p_at_worst": float(ref[int(u.argmax())])}
+                            "ref_p_at_worst": float(ref[int(u.argmax())]),
+                            "bit_identical_fraction": float((got.view(np.uint32) == ref.view(np.uint32)).mean())}
             e.set_encoder_variant(0)
             po = orc.encode_reads(w, d["X"][:R], d["site_kmers"][:keep_reads], d["off"][:keep_reads + 1], n_threads=8)
             u = use(po, ref)
-            r["oracle"] = {"worst_use": float(u.max()), "reads_beyond_bar": int((u > 1).sum()), "p99.99_use": float(np.quantile(u, 0.9999))}
+            r["oracle"] = {"worst_use": float(u.max()), "reads_beyond_bar": int((u > 1).sum()), "p99.99_use": float(np.quantile(u, 0.9999)),
+                           "bit_identical_fraction": float((po.view(np.uint32) == ref.view(np.uint32)).mean())}
             rp, site, mod = e.infer(d["X"][:Rs], d["site_kmers"][:keep_sites], d["off"][:keep_sites + 1], 1000)
             r["site_prob_T1000_max_abs_diff"] = float(np.abs(site.astype(np.float64) - G["%s_%s_site_T1000" % (tag, name)]).max())
             r["site_prob_encoder"] = e.last_encoder_variant
