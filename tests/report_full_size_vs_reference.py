@@ -38,7 +38,8 @@ def main():
         for mode, label in ((1, "general16"), (2, "csite12")):
             e.set_encoder_variant(mode)
             u = use(e.get_read_probability(d["X"], d["site_kmers"], d["off"]), ref)
-            row[label] = {"worst_use": float(u.max()), "reads_beyond_bar": int((u > 1).sum()), "p99.9999_use": float(np.quantile(u, 0.999999))}
+            row[label] = {"worst_use": float(u.max()), "reads_beyond_bar": int((u > 1).sum()), "p99.9999_use": float(np.quantile(u, 0.999999)),
+                          "reads_not_bit_identical": int((u > 0).sum())}
         u = use(orc.encode_reads(w, d["X"], d["site_kmers"], d["off"], n_threads=16), ref)
         row["oracle"] = {"worst_use": float(u.max()), "reads_beyond_bar": int((u > 1).sum())}
         exact = os.path.join(REPO, "tests", "golden", "_big", "%s_%s_f64.npy" % (tag, name))
