@@ -888,6 +888,23 @@ def run(args, line, rank, world, local_rank, S, bag, T):
         default_run = (world == 1 and args.workload == "uniform" and S == WORKLOADS["uniform"]["sites"] and T == 1000 and
                        bag == WORKLOADS["uniform"]["bag"])
         if default_run and not args.no_ragged_extra:
+            # the same workload on the 16-slot encoder -- the kernel whose read probabilities are the reference's bit for bit
+            # (what `m6anet_amd inference` runs by default; the timed region above used the library's automatic choice)
+            b.eng.set_encoder_variant(1)
+            for _ in range(3):
+                b.compute()
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(10):
+                b.compute()
+            torch.cuda.synchronize(dev)
+            ms = (time.perf_counter() - t0) / 10 * 1e3
+            line["reference_order_encoder"] = {
+                "encoder_kernel": b.eng.last_encoder_variant, "ms_per_step": ms, "value": b.Sr / (ms * 1e-3), "steps": 10, "warmup": 3,
+                "note": "same workload, m6a_set_encoder_variant(1): every float32 operation of the reference's encoder in the "
+                        "reference's order (DESIGN.md section 2) -- read and site probabilities bit-identical to the reference's on "
+                        "this workload's bags; the headline above runs the 12-slot kernel (within 1e-5 relative)"}
+            b.eng.set_encoder_variant(0)
             # the path real data takes (bags are never uniform), in the same record: configs[4]'s per-GPU shape
             del b.X, b.rp
             b.eng.close()
