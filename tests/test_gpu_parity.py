@@ -118,6 +118,29 @@ def test_encoder_extreme_inputs(eng, orc, weights):
     assert np.allclose(got, want, rtol=1e-5, atol=1e-8)
 
 
+@pytest.mark.parametrize("bags", [[1], [20] * 64, [3] * 100, list(range(1, 70)), [662, 20, 21, 500, 33], [0, 5, 0, 0, 7, 0],
+                                  [16, 17, 40, 16, 700, 16, 16, 33]])
+def test_encoder_general16_is_the_oracle_bit_for_bit(engines, orc, weights, bags):
+    """The 16-slot kernel and the oracle perform the same float32 operations in the same order from the first feature to
+    the division of the sigmoid (both restate the reference: DESIGN.md section 2): whatever the bags, the read
+    probabilities must be the same BITS -- ordinary features, features at the clip, and far outside it."""
+    X, km, off = rand_sites(len(bags) * 3 + 2, bags)
+    if X.shape[0] > 40:
+        X[5] = 6.0
+        X[6] = -6.0
+        X[7] = 0.0
+        X[8, :] = [40.0, -35.0, 12.0, 0.5, -0.25, 3.0, -60.0, 1e-3, 9.0]
+    for model in ("hct116", "hek293t_glori", "arabidopsis", "hek293t_m6ace"):
+        e = engines[model]
+        e.set_encoder_variant(1)
+        try:
+            got = e.get_read_probability(X, km, off)
+        finally:
+            e.set_encoder_variant(0)
+        want = orc.encode_reads(weights[model], X, km, off)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (model, int((got.view(np.uint32) != want.view(np.uint32)).sum()))
+
+
 @pytest.mark.parametrize("variant", [1, 2])
 def test_encoder_nan_and_huge_features(eng, orc, weights, variant):
     """Layer 1's ReLU is the clamp modifier of the batch-norm fma (m6a_kernels.hip bn_relu): a NaN feature must still come
