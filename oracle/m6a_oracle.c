@@ -175,7 +175,10 @@ static inline float sleef_expf_u10(float d)
 {
     const float R_LN2f = 1.442695040888963407359924681001892137426645954152985934135449406931f;
     const float L2Uf = 0.693145751953125f, L2Lf = 1.428606765330187045e-06f;
-    const int q = (int)rintf(d * R_LN2f);
+    if (d != d) return d;                                    /* NaN in, NaN out (and no float -> int conversion of a NaN) */
+    if (d < -104.0f) return 0.0f;                            /* Sleef's own clips, taken first: they also bound q */
+    if (d > 104.0f) return INFINITY;
+    const int q = (int)rintf(d * R_LN2f);                    /* |d| is clipped below: q stays far inside int */
     float s = fmaf((float)q, -L2Uf, d);
     s = fmaf((float)q, -L2Lf, s);
     float u = 0.000198527617612853646278381f;
@@ -187,8 +190,6 @@ static inline float sleef_expf_u10(float d)
     u = 1.0f + fmaf(s * s, u, s);
     const int q1 = q >> 1, q2 = q - q1;
     u = u * ldexpf(1.0f, q1) * ldexpf(1.0f, q2);
-    if (d < -104.0f) u = 0.0f;
-    if (d > 104.0f) u = INFINITY;
     return u;
 }
 
