@@ -486,11 +486,11 @@ def test_bench_prints_its_line_when_a_rank_dies():
 # ------------------------------------------------------------------ the read-probability bar, statistically --------
 def test_read_probability_tail_at_full_size(engines, orc, weights):
     """BASELINE configs[2] at full size: ALL 20 M read probabilities of both encoder kernels and all four checkpoints
-    against the multi-threaded oracle.  The bar is the reference's (m6anet/tests/test_inference.py:32: rtol 1e-5, atol
-    1e-8); at this scale float32 rounding noise between two summation orders puts a handful of reads in 10^8 just beyond
-    it (even exact float64 arithmetic sits AT the bar against the float32 oracle), so the guard is
-    statistical: at most 1e-6 of the reads beyond the bar, the worst below 1.5x, nothing grossly wrong.  A kernel change
-    that moved the tail from 5e-8 to 1e-4 of the reads -- invisible to the small committed vectors -- fails here."""
+    against the multi-threaded oracle -- which reproduces the reference's capture of this shape bit for bit
+    (tests/test_reference_at_scale.py), so this is the reference's bar (m6anet/tests/test_inference.py:32: rtol 1e-5, atol
+    1e-8) held against the reference's values at a size no fixture can carry.  The 16-slot kernel restates the same
+    operations as the oracle: every one of its 80 M probabilities must be the oracle's BITS.  The 12-slot kernel sums a
+    site's constants first and the 32 -> 1 layer in register order: no read beyond the bar (0.75 of it at worst, measured)."""
     import json
     d = synthetic.make_sites(1_000_000, 20, seed=20250328)
     X, km, off = d["X"], d["site_kmers"], d["off"]
@@ -519,8 +519,10 @@ def test_read_probability_tail_at_full_size(engines, orc, weights):
     except OSError:
         pass
     for key, s in seen.items():
-        assert s["fraction"] <= 1e-6, (key, s)
-        assert s["worst_use_of_bar"] < 1.5, (key, s)
+        if key.endswith("general16"):
+            assert s["worst_use_of_bar"] == 0.0, (key, s)        # |got - want| == 0 on every read: the same bits
+        else:
+            assert s["beyond_bar"] == 0 and s["worst_use_of_bar"] <= 0.9, (key, s)
 
 
 def test_c_abi_from_plain_c():
