@@ -131,7 +131,7 @@ __device__ __forceinline__ void layer2_with_bn(f32x16 &acc2, f32x16 &cur, const 
 }
 
 // exp as torch's vectorised sigmoid computes it -- Sleef's expf with the 1.0-ulp bound (sleefsimdsp.c `xexpf`; restated from the
-// published algorithm, as in oracle/m6a_oracle.c): Cody-Waite reduction by ln 2 in two parts, a degree-6 polynomial in fma form,
+// published algorithm): Cody-Waite reduction by ln 2 in two parts, a degree-6 polynomial in fma form,
 // 2^q applied as two factors.  Only the 16-slot kernel uses it (its read probabilities are the reference's bits, below).
 __device__ __forceinline__ float sleef_expf_u10(float d)
 {
