@@ -2,8 +2,9 @@
 """One-off, BUILD CONTAINER ONLY (imports the reference like make_golden.py): the reference's read probabilities for ALL
 20 000 000 reads of BASELINE.json configs[2] -- or, with --ragged, all 34 357 966 reads of configs[4]'s per-GPU shape (125 000
 sites x 50..500 reads, what `bench.py --workload ragged` runs) -- from this repository's generator, four checkpoints, encoder per 16-site batch
-(m6anet/utils/inference_utils.py:33-37) -> tests/golden/_big/configs2_<model>.npy (80 MB each: git-ignored, but they travel
-to the GPU box with the snapshot).  tests/report_full_size_vs_reference.py compares both HIP encoder kernels with them there
+(m6anet/utils/inference_utils.py:33-37) -> tests/golden/_big/configs2_<model>.npy (80 MB each: git-ignored, and listed in
+.gpurunignore so that ordinary snapshots stay small -- take that line out for the one call that runs the report; a snapshot
+carries at most 512 MiB, so the ragged shape goes three checkpoints at a time).  tests/report_full_size_vs_reference.py compares both HIP encoder kernels with them there
 and writes the summary that IS committed (profiles/r04_full_size_vs_reference.json)."""
 import os
 import sys

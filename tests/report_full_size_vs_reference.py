@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """GPU box: both HIP encoder kernels (and the oracle) against the REFERENCE's read probabilities on ALL 20 000 000 reads of
 BASELINE.json configs[2] -- with --ragged: all 34 357 966 reads of configs[4]'s per-GPU shape --, four checkpoints (tests/golden/_big/*.npy from tests/golden/make_full_size_reference.py; 80 MB each,
-not committed).  Bar: rtol 1e-5 / atol 1e-8 (m6anet/tests/test_inference.py:32).
+not committed; .gpurunignore lists that directory -- take the line out for this call).  Bar: rtol 1e-5 / atol 1e-8 (m6anet/tests/test_inference.py:32).
     python tests/report_full_size_vs_reference.py > gpurun_out/r04_full_size_vs_reference.json"""
 import json
 import os
