@@ -257,6 +257,10 @@ int m6a_profile_read(m6a_ctx *ctx, int kind, double *total_ms, int64_t *n_launch
  * M6A_ENCODER=general16|csite12 preselects 1 / 2 in every context the process creates. */
 int m6a_set_encoder_variant(m6a_ctx *ctx, int mode);
 const char *m6a_last_encoder_variant(const m6a_ctx *ctx);   /* "general16" | "csite12" */
+/* The __global__ function the last encode launched: "enc_site16_kernel" (16 slots, scalar 32-bit site chain: every bag
+ * >= 16 reads), "enc_kernel" (16 slots, per-lane 64-bit walk: any bags; mode 3 forces it), "enc_csite_kernel" (12 slots).
+ * The two 16-slot kernels perform the same float32 operations: same bits. */
+const char *m6a_last_encoder_kernel(const m6a_ctx *ctx);
 /* Tuning knob for ragged bags: 0 = auto (default: per-bag-size index tables once the work seen pays for them, else
  * the stream-replaying scan kernels, their driver chosen by the parallelism on offer), 1 = scan, one wavefront per
  * flush group, 2 = scan, counting pass + one wavefront per site, 3 = index tables always (M6A_EUNSUPPORTED if a bag

@@ -686,15 +686,19 @@ int launch_encode(m6a_ctx *c, const float *X, const uint8_t *km, const int64_t *
     a.tiles_per_wave = (a.n_tiles + max_waves - 1) / max_waves;
     const int64_t waves = (a.n_tiles + a.tiles_per_wave - 1) / a.tiles_per_wave;
     const unsigned blocks = (unsigned)((waves + 3) / 4);
-    // every bag >= 16 reads: a 32-read tile spans <= 3 sites -> 12-slot layer 1 (106 MFMAs per tile);
-    // otherwise the general 16-slot kernel (116)
-    // the 12-slot kernel keeps tile and site indices in 32 bits (wave-uniform SALU arithmetic)
+    // every bag >= 16 reads: a 32-read tile spans <= 3 sites, and the site lookup is the scalar 32-bit chain of
+    // enc_csite_kernel (12-slot layer 1, 106 MFMAs per tile) / enc_site16_kernel (the reference's 16 slots, 116);
+    // otherwise enc_kernel: the same 16-slot arithmetic behind a per-lane 64-bit walk of off[]
     const bool fits32 = S < 0x7ffffff0LL && a.n_tiles < 0x7ffffff0LL;
     if (c->enc_variant == 2 && !fits32) return fail(c, M6A_EUNSUPPORTED, "12-slot encoder: more than 2^31 sites or tiles");
-    const bool csite = c->enc_variant ? c->enc_variant == 2 : (c->bag_min >= M6A_CSITE_MIN_BAG && fits32);
+    const bool scalar_chain = c->bag_min >= M6A_CSITE_MIN_BAG && fits32;
+    const bool csite = c->enc_variant ? c->enc_variant == 2 : scalar_chain;
+    const bool site16 = !csite && c->enc_variant != 3 && scalar_chain;
     c->enc_variant_used = csite ? "csite12" : "general16";
+    c->enc_kernel_used = csite ? "enc_csite_kernel" : site16 ? "enc_site16_kernel" : "enc_kernel";
     prof_begin(c, 0);
     if (csite) hipLaunchKernelGGL(enc_csite_kernel, dim3(blocks), dim3(256), 0, c->stream, a);
+    else if (site16) hipLaunchKernelGGL(enc_site16_kernel, dim3(blocks), dim3(256), 0, c->stream, a);
     else hipLaunchKernelGGL(enc_kernel, dim3(blocks), dim3(256), 0, c->stream, a);
     prof_end(c, 0);
     HIPCHK(c, hipGetLastError());
@@ -1160,6 +1164,7 @@ int m6a_create(m6a_ctx **out, const float *weights, size_t n_floats, int device_
     if (const char *ev = getenv("M6A_ENCODER")) {
         if (!strcmp(ev, "general16")) c->enc_variant = 1;
         else if (!strcmp(ev, "csite12")) c->enc_variant = 2;
+        else if (!strcmp(ev, "walk16")) c->enc_variant = 3;
     }
     const char *w = getenv("M6A_WARMUP");
     if (!(w && w[0] == '0')) {
@@ -1248,12 +1253,14 @@ int m6a_set_job_offset(m6a_ctx *c, int64_t first_site)
 int m6a_set_encoder_variant(m6a_ctx *c, int mode)
 {
     if (!c) return M6A_EINVAL;
-    if (mode < 0 || mode > 2) return fail(c, M6A_EINVAL, "encoder variant must be 0 (auto), 1 (16-slot) or 2 (12-slot)");
+    if (mode < 0 || mode > 3)
+        return fail(c, M6A_EINVAL, "encoder variant must be 0 (auto), 1 (16-slot), 2 (12-slot) or 3 (16-slot, per-lane walk)");
     c->enc_variant = mode;
     return M6A_OK;
 }
 
 const char *m6a_last_encoder_variant(const m6a_ctx *c) { return c ? c->enc_variant_used : "none"; }
+const char *m6a_last_encoder_kernel(const m6a_ctx *c) { return c ? c->enc_kernel_used : "none"; }
 
 int m6a_set_scan_driver(m6a_ctx *c, int mode)
 {

@@ -208,8 +208,9 @@ struct m6a_ctx {
     struct { int64_t S, bs, spb, base, G, gmax; bool valid; } goff_key = {0, 0, 0, 0, 0, 0, false};
     int64_t job_offset = 0;
     int64_t bag_min = 0, bag_max = 0, n_reads = 0;   // last query_bags()
-    int enc_variant = 0;                              // 0 auto, 1 general 16-slot, 2 12-slot (bags >= 16)
+    int enc_variant = 0;                              // 0 auto, 1 16-slot, 2 12-slot (bags >= 16), 3 16-slot per-lane walk
     const char *enc_variant_used = "none";
+    const char *enc_kernel_used = "none";             // the __global__ function the last encode launched
     int scan_driver = 0;                              // 0 auto, 1 per group, 2 counting pass + per site
     int *d_err = nullptr;
     unsigned long long *d_minmax = nullptr;

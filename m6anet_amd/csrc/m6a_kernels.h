@@ -97,6 +97,7 @@ struct RtabUse {
 };
 
 __global__ void enc_kernel(EncArgs a);
+__global__ void enc_site16_kernel(EncArgs a);
 __global__ void enc_csite_kernel(EncArgs a);
 __global__ void pool_scan_start_kernel(PoolArgs a);
 template <int KT> __global__ void pool_scan_group_kernel(PoolArgs a);

@@ -381,6 +381,166 @@ __global__ __launch_bounds__(256, 2) void enc_kernel(EncArgs a)
 }
 
 // =====================================================================================
+// Read encoder, 16 slots, bags >= 16 reads: enc_kernel's arithmetic behind enc_csite_kernel's input chain.
+//
+// Every float32 operation is enc_kernel's (same fragments, same K-slot wiring, same epilogue: the reference's bits); what
+// differs is how a lane finds its site and its six embedding floats.  enc_kernel walks the CSR array per lane with 64-bit
+// indices (vector loads of off[], three k-mer byte loads and three LDS reads per lane, 64-bit clamps on the VALU -- the
+// datapath the f32 MFMAs use); here, as in the 12-slot kernel below, a 32-read tile spans at most three sites, so
+//   link0  off[a+1..a+3] come through scalar loads (constant address space), tile and site indices are 32-bit SALU values;
+//   link1  the lane's site is `rel` = 0, 1, 2 relative to the wave-uniform base, by two 32-bit compares; lanes 0..17 fetch
+//          ONE k-mer id byte each (float q of site a + q/6), then the x loads;
+//   link2  the embedding float, one LDS read per lane;
+//   link3  three ds_bpermute (LDS crossbar, not the VALU) hand every lane its site's floats: half 0 the odd ones
+//          (e1, e3, e5: K slots 5..7), half 1 the even ones (e0, e2, e4: slots 4..6) and the constant 1.
+// A tile that would need a fourth site raises the error flag (the host launches this kernel only when the smallest bag
+// has >= 16 reads and the job fits 32-bit indices; enc_kernel stays the path for everything else).
+// =====================================================================================
+__global__ __launch_bounds__(256, 2) void enc_site16_kernel(EncArgs a)
+{
+    clamp_keeps_nan();
+    __shared__ float s_emb[132];
+    __shared__ __attribute__((aligned(16))) float s_bn[M6A_BN_FLOATS];
+    for (int i = threadIdx.x; i < 132; i += 256) s_emb[i] = a.emb[i];
+    for (int i = threadIdx.x; i < M6A_BN_FLOATS; i += 256) s_bn[i] = a.bn[i];
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int col = lane & 31;
+    const int half = lane >> 5;
+    const float *bn_half = s_bn + half * 32;
+    const int wave = (int)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int n_tiles = (int)a.n_tiles, tpw = (int)a.tiles_per_wave;
+    const int tile0 = wave * tpw;
+    if (tile0 >= n_tiles) return;
+    const int tile1 = (tile0 + tpw < n_tiles) ? tile0 + tpw : n_tiles;
+    const int n_sites = (int)a.n_sites;
+    const int last_lim = (int)(a.n_reads - 1 - (int64_t)(n_tiles - 1) * 32);   // last valid column of the last tile
+
+    float w1[40], w2[80], w3[16];
+#pragma unroll
+    for (int i = 0; i < 40; i++) w1[i] = a.wfrag[i * 64 + lane];
+#pragma unroll
+    for (int i = 0; i < 80; i++) w2[i] = a.wfrag[(40 + i) * 64 + lane];
+#pragma unroll
+    for (int i = 0; i < 16; i++) w3[i] = a.wfrag[(120 + i) * 64 + lane];
+
+    int s_base;
+    {
+        const int64_t r = (int64_t)tile0 * 32;
+        int lo = 0, hi = n_sites;                // invariant: off[lo] <= r < off[hi]
+        while (hi - lo > 1) {
+            const int mid = (int)(((int64_t)lo + hi) >> 1);
+            if (a.off[mid] <= r) lo = mid; else hi = mid;
+        }
+        s_base = lo;
+    }
+    const int last_site = n_sites - 1;
+
+    const __attribute__((address_space(4))) int64_t *off_c = (const __attribute__((address_space(4))) int64_t *)a.off;
+    auto link0 = [&](int base, int64_t (&o)[3]) {
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            const int si = base + 1 + i;
+            o[i] = off_c[si <= n_sites ? si : n_sites];
+        }
+    };
+    const int kq = lane < 18 ? lane : 17;                    // every lane loads a valid byte: no merge
+    const int kq_site = kq / 6, kq_byte = (kq % 6) / 2;
+    int too_small = 0;                                       // wave-uniform
+    auto link1 = [&](int tile, int base, const int64_t (&o)[3], int &rel, int &kid, float (&x)[8]) {
+        const int64_t rbase = (int64_t)tile * 32;                                 // uniform
+        const int lim = tile == n_tiles - 1 ? last_lim : 31;                      // last valid column of this tile
+        const int crel = col < lim ? col : lim;                                   // the lane's read, clamped into the job
+        const int d0 = (int)o[0] - (int)rbase, d1 = (int)o[1] - (int)rbase, d2 = (int)o[2] - (int)rbase;
+        rel = (crel >= d0 ? 1 : 0) + (crel >= d1 ? 1 : 0);
+        too_small |= lim >= d2 ? 1 : 0;
+        const int room = last_site - base;                                        // sites after the base site
+        const int ksr = kq_site < room ? kq_site : room;
+        kid = (int)(a.site_kmers + (int64_t)base * 3)[ksr * 3 + kq_byte];
+        // K slot 2i + half holds feature 2i + half, as in enc_kernel
+        const float *xp = a.X + rbase * 9 + (crel * 9 + half);
+#pragma unroll
+        for (int i = 0; i < 4; i++) x[i] = xp[2 * i];
+        x[4] = xp[half ? 6 : 8];
+    };
+    auto link2 = [&](int kid, float &ev) { ev = s_emb[2 * kid + (lane & 1)]; };
+    // lanes 0..17 hold float q % 6 of site a + q / 6; a lane of half h wants floats (1 - h), (1 - h) + 2, (1 - h) + 4 of
+    // site a + rel.  (A site beyond the job's last -- `room` above -- is never selected: rel counts real boundaries.)
+    auto link3 = [&](float ev, int rel, float (&x)[8]) {
+        const int ebits = __builtin_bit_cast(int, ev);
+        const int addr = 4 * (rel * 6 + 1 - half);
+        const float e0 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr, ebits));
+        const float e1 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr + 8, ebits));
+        const float e2 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr + 16, ebits));
+        x[4] = half ? e0 : x[4];
+        x[5] = half ? e1 : e0;
+        x[6] = half ? e2 : e1;
+        x[7] = half ? 1.0f : e2;
+    };
+
+    // prologue: first tile, unpipelined
+    float f[8];
+    s_base = __builtin_amdgcn_readfirstlane(s_base);
+    {
+        int64_t o[3];
+        int rel, kid;
+        float ev;
+        link0(s_base, o);
+        link1(tile0, s_base, o, rel, kid, f);
+        link2(kid, ev);
+        link3(ev, rel, f);
+        s_base += __builtin_amdgcn_readfirstlane(__shfl(rel, 31, 64));
+    }
+
+    BnPairs bnq;
+    bn_pairs_load(bnq, bn_half);
+    for (int tile = tile0; tile < tile1; ++tile) {
+        // the chain always runs (for the last tile it refetches that tile): no guard, no merge
+        const int tn = tile + 1 < tile1 ? tile + 1 : tile;
+        float fn[8], evn;
+        int64_t o[3];
+        int reln, kidn;
+        link0(s_base, o);
+
+        f32x16 acc2, h1a, h1b;
+#pragma unroll
+        for (int q = 0; q < 16; q++) { acc2[q] = 0.0f; h1a[q] = 0.0f; }
+#pragma unroll
+        for (int st = 0; st < 8; st++)
+            h1a = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[st], f[st], h1a, 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < 5; m++) {
+            f32x16 &cur = (m & 1) ? h1b : h1a;
+            f32x16 &nxt = (m & 1) ? h1a : h1b;
+            if (m < 4) {
+#pragma unroll
+                for (int q = 0; q < 16; q++) nxt[q] = 0.0f;
+#pragma unroll
+                for (int st = 0; st < 8; st++)
+                    nxt = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[(m + 1) * 8 + st], f[st], nxt, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (m == 0) link1(tn, s_base, o, reln, kidn, fn);
+            if (m == 1) link2(kidn, evn);
+            if (m == 3) link3(evn, reln, fn);
+            if (m == 0) layer2_with_bn<0>(acc2, cur, w2, bnq, bn_half);
+            if (m == 1) layer2_with_bn<1>(acc2, cur, w2, bnq, bn_half);
+            if (m == 2) layer2_with_bn<2>(acc2, cur, w2, bnq, bn_half);
+            if (m == 3) layer2_with_bn<3>(acc2, cur, w2, bnq, bn_half);
+            if (m == 4) layer2_with_bn<4>(acc2, cur, w2, bnq, bn_half);
+        }
+        const float z = gemv32_as_mkl(acc2, w3, half) + a.b3;
+        const float p = 1.0f / (1.0f + sleef_expf_u10(-z));
+        if (half == 0 && col <= (tile == n_tiles - 1 ? last_lim : 31)) (a.read_prob + (int64_t)tile * 32)[col] = p;
+        if (tn != tile) s_base += __builtin_amdgcn_readfirstlane(__shfl(reln, 31, 64));
+#pragma unroll
+        for (int i = 0; i < 8; i++) f[i] = fn[i];
+    }
+    if (too_small && lane == 0) atomicExch(a.err, 2);
+}
+
+// =====================================================================================
 // Read encoder, 12-slot variant (calls whose bags all have >= 16 reads).
 //
 // Six of the 16 inputs (the three k-mer embeddings) and the bias are constant per SITE, and a

@@ -145,12 +145,18 @@ class M6ANetEngine:
         self._chk(self._L.m6a_set_job_offset(self._h, int(first_site)))
 
     def set_encoder_variant(self, mode):
-        """0 auto, 1 general 16-slot kernel, 2 12-slot kernel (needs every bag >= 16 reads)."""
+        """0 auto, 1 16-slot kernel (the reference's operation order), 2 12-slot kernel (needs every bag >= 16 reads),
+        3 the 16-slot kernel behind the per-lane walk of off[] even when the scalar site chain would do (A/B, tests)."""
         self._chk(self._L.m6a_set_encoder_variant(self._h, int(mode)))
 
     @property
     def last_encoder_variant(self):
         return self._L.m6a_last_encoder_variant(self._h).decode()
+
+    @property
+    def last_encoder_kernel(self):
+        """Name of the __global__ function the last encode launched (enc_kernel | enc_site16_kernel | enc_csite_kernel)."""
+        return self._L.m6a_last_encoder_kernel(self._h).decode()
 
     def set_scan_driver(self, mode):
         """Ragged bags: 0 auto, 1 one wavefront per flush group, 2 counting pass + one wavefront per site, 3 index tables."""

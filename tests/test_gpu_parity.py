@@ -141,6 +141,49 @@ def test_encoder_general16_is_the_oracle_bit_for_bit(engines, orc, weights, bags
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (model, int((got.view(np.uint32) != want.view(np.uint32)).sum()))
 
 
+@pytest.mark.parametrize("bags", [[16] * 50, [20] * 333, [16, 17, 40, 16, 700, 16, 16, 33], list(range(16, 120)),
+                                  [32] * 9 + [31] * 9, [1000, 16, 16, 16, 2000], [20] * 7 + [19], [16], [47]])
+def test_encoder_site16_scalar_chain_is_the_walk_and_the_oracle_bit_for_bit(engines, orc, weights, bags):
+    """Bags >= 16 reads: the 16-slot arithmetic runs behind the 12-slot kernel's scalar 32-bit site chain
+    (enc_site16_kernel) instead of the per-lane walk (enc_kernel, mode 3).  Same float32 operations: the read
+    probabilities must be the same BITS as the walk's and the oracle's, NaN and far-out features included."""
+    X, km, off = rand_sites(sum(bags) % 89 + 3, bags)
+    if X.shape[0] > 40:
+        X[5] = 6.0
+        X[6] = -6.0
+        X[8, :] = [40.0, -35.0, 12.0, 0.5, -0.25, 3.0, -60.0, 1e-3, 9.0]
+        X[9, 2] = np.nan
+        X[10] = 1e6
+    for model in ("hct116", "hek293t_glori"):
+        e = engines[model]
+        try:
+            e.set_encoder_variant(1)
+            got = e.get_read_probability(X, km, off)
+            assert e.last_encoder_variant == "general16" and e.last_encoder_kernel == "enc_site16_kernel"
+            e.set_encoder_variant(3)
+            walk = e.get_read_probability(X, km, off)
+            assert e.last_encoder_variant == "general16" and e.last_encoder_kernel == "enc_kernel"
+        finally:
+            e.set_encoder_variant(0)
+        want = orc.encode_reads(weights[model], X, km, off)
+        assert np.array_equal(got.view(np.uint32), walk.view(np.uint32)), model
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), model
+
+
+def test_encoder_site16_needs_bags_of_16(eng):
+    """One bag below 16 reads anywhere in the call: variant 1 falls back to the walk by itself."""
+    X, km, off = rand_sites(2, [20] * 40 + [15])
+    eng.set_encoder_variant(1)
+    try:
+        eng.get_read_probability(X, km, off)
+        assert eng.last_encoder_kernel == "enc_kernel"
+        X, km, off = rand_sites(2, [20] * 40 + [16])
+        eng.get_read_probability(X, km, off)
+        assert eng.last_encoder_kernel == "enc_site16_kernel"
+    finally:
+        eng.set_encoder_variant(0)
+
+
 @pytest.mark.parametrize("variant", [1, 2])
 def test_encoder_nan_and_huge_features(eng, orc, weights, variant):
     """Layer 1's ReLU is the clamp modifier of the batch-norm fma (m6a_kernels.hip bn_relu): a NaN feature must still come
