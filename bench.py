@@ -37,6 +37,10 @@ sys.path.insert(0, REPO)
 
 ENC_FLOP_PER_READ = 14164      # 2*(15*150 + 150*32 + 32)           SURVEY.md section 8(d)
 ENC_BYTES_PER_READ = 40        # 9 f32 in + 1 f32 out               SURVEY.md section 8(d)
+# what the kernels EXECUTE per read: v_mfma_f32_32x32x2_f32 = 4096 FLOP for a tile of 32 reads; the 12-slot kernel issues 106 of
+# them per tile (30 layer 1 + 76 layer 2), the two 16-slot kernels 116 (40 + 76) -- padding of 150 hidden units to 160 rows included,
+# the 32 -> 1 layer and the embedding fold (VALU) not
+ENC_MFMA_PER_TILE = {"enc_csite_kernel": 106, "enc_site16_kernel": 116, "enc_kernel": 116}
 PEAK_F32_TFLOPS = 157.3        # MI355X_MICROARCH.md: f32 MFMA = f32 vector peak
 PEAK_HBM_GBPS = 8000.0
 # ds_read_b32 gathers, conflict-free: 64 lanes per 2 LDS cycles per CU (MI355X_MICROARCH.md, LDS table)
@@ -391,6 +395,44 @@ def smi_snapshot():
         return {"error": repr(e)[:200]}
 
 
+def with_h2d(b, T, steps=5):
+    """The same workload with its inputs in HOST memory and its results wanted there (the reference's seam:
+    m6anet/utils/inference_utils.py:35-36 moves every batch `.to(device)`; SURVEY.md section 8(e) last sentence): one
+    m6a_infer per step on host pointers -- the library's chunked pinned ring, H2D of chunk k+1 under the encoder of chunk k,
+    read probabilities flowing back the same way -- from pageable NumPy arrays and from pinned (hipHostMalloc) tensors.
+    Outside the headline's timed region; never `value`."""
+    import torch
+    eng = b.eng
+    X, km, off = b.X.cpu().numpy(), b.km.cpu().numpy(), b.off_host
+    out = (np.empty(b.R, np.float32), np.empty(b.Sr, np.float32), np.empty(b.Sr, np.float64))
+    res = {"steps": steps, "bytes_in_per_step": int(X.nbytes + km.nbytes + off.nbytes), "bytes_out_per_step": int(sum(o.nbytes for o in out)),
+           "note": "m6a_infer on host pointers, read_prob + site_prob + mod_ratio returned to host arrays that are reused across steps; "
+                   "each step synchronous (the call returns with the results in place); sites/s = sites / mean step"}
+    eng.set_stream(None)
+    try:
+        eng.prepare_host_io()
+
+        def rate(args, outs):
+            eng.infer(*args, T, 20, b.thr, 0, 16, 2, out=outs)                  # ring set up, pages touched
+            ts = []
+            for _ in range(steps):
+                t0 = time.perf_counter()
+                eng.infer(*args, T, 20, b.thr, 0, 16, 2, out=outs)
+                ts.append(time.perf_counter() - t0)
+            return {"sites_per_s": b.Sr * steps / sum(ts), "ms_per_step": sum(ts) / steps * 1e3, "best_ms": min(ts) * 1e3,
+                    "GBps_in_plus_out": (res["bytes_in_per_step"] + res["bytes_out_per_step"]) * steps / sum(ts) / 1e9}
+        res["pageable"] = rate((X, km, off), out)
+        pin = [torch.from_numpy(a).pin_memory() for a in (X, km, off)]
+        pout = tuple(torch.empty(o.shape, dtype=getattr(torch, str(o.dtype))).pin_memory() for o in out)
+        res["pinned"] = rate(tuple(pin), pout)
+        res["encoder_kernel"] = eng.last_encoder_kernel
+    except Exception as e:                                  # noqa: BLE001 -- an optional leg: the line goes out without it
+        res["error"] = "%s: %s" % (type(e).__name__, str(e)[:200])
+    finally:
+        eng.use_torch_stream()
+    return res
+
+
 class Bench:
     """One workload on this rank: data resident in HBM, engine, the step, and the timed regions."""
 
@@ -641,7 +683,9 @@ class Bench:
         enc_tflops = ENC_FLOP_PER_READ * R / (enc_avg_ms * 1e-3) / 1e12
         enc_gbps = ENC_BYTES_PER_READ * R / (enc_avg_ms * 1e-3) / 1e9
         draws = Sr * T * 20
-        enc_kernel = {"csite12": "enc_csite_kernel", "general16": "enc_kernel"}.get(eng.last_encoder_variant, "enc_kernel")
+        enc_kernel = eng.last_encoder_kernel
+        executed = ENC_MFMA_PER_TILE[enc_kernel] * 4096 // 32
+        enc_tflops_executed = executed * R / (enc_avg_ms * 1e-3) / 1e12
         tr = None
         if world == 1 and traffic:
             default_shape = S == spec["sites"] and T == 1000 and (self.workload == "ragged" or bag == spec["bag"])
@@ -684,8 +728,11 @@ class Bench:
             # ... and if the caller does NOTHING between m6a_create and that call (no loading, no H2D), the whole background
             # set-up is waited for as well: the worst case of a one-shot process, HIP runtime start-up aside
             "value_one_shot_incl_context": total_sites / ((r["first_call_ms"] + sum(self.context_ms.values())) * 1e-3),
-            "roofline": {"kernel": "read encoder (%s)" % eng.last_encoder_variant, "bound": "mfma", "achieved": enc_tflops,
+            "roofline": {"kernel": "read encoder (%s: %s)" % (eng.last_encoder_variant, enc_kernel), "bound": "mfma", "achieved": enc_tflops,
                          "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": enc_tflops / PEAK_F32_TFLOPS,
+                         # the same launch priced by the MFMA work it EXECUTES rather than SURVEY 8(d)'s algorithmic count
+                         "executed_flop_per_read": executed, "mfma_per_32_read_tile": ENC_MFMA_PER_TILE[enc_kernel],
+                         "achieved_executed": enc_tflops_executed, "frac_executed": enc_tflops_executed / PEAK_F32_TFLOPS,
                          "traffic": tr["traffic_bytes_per_launch"] if tr else None,
                          "traffic_source": tr["source"] if tr else None,
                          "algorithmic_bytes_per_launch": ENC_BYTES_PER_READ * R,
@@ -715,6 +762,9 @@ class Bench:
                 "num_iterations": self.T,
                 "bag_statistics": "host copy of off[] per step, device-checked (m6a_set_host_offsets)" if self.host_offsets else "read back per step",
                 "pool_kernel": self.eng.last_pool_variant, "encoder_kernel": self.eng.last_encoder_variant,
+                "encoder_kernel_function": self.eng.last_encoder_kernel,
+                "cli_default_encoder": "general16 (`m6anet_amd inference --encoder reference`: enc_site16_kernel on bags >= 16 reads, enc_kernel "
+                                       "otherwise; --encoder fast = the library's automatic choice, which this line's headline runs)",
                 "sharding": "contiguous flush-group-aligned site shards balanced by reads, 1 gather of site_prob + mod_ratio to rank 0 per step "
                             "over %s" % self.gather_kind if self.gather is not None else "none"}
 
@@ -888,8 +938,9 @@ def run(args, line, rank, world, local_rank, S, bag, T):
         default_run = (world == 1 and args.workload == "uniform" and S == WORKLOADS["uniform"]["sites"] and T == 1000 and
                        bag == WORKLOADS["uniform"]["bag"])
         if default_run and not args.no_ragged_extra:
-            # the same workload on the 16-slot encoder -- the kernel whose read probabilities are the reference's bit for bit
-            # (what `m6anet_amd inference` runs by default; the timed region above used the library's automatic choice)
+            # the same workload on the 16-slot encoder -- the kernel whose read probabilities are the reference's bit for bit:
+            # what `m6anet_amd inference` and INTEGRATION.md's stub run by default (the timed region above used the library's
+            # automatic choice, the 12-slot kernel) -- with its own roofline from HIP events around its launches
             b.eng.set_encoder_variant(1)
             for _ in range(3):
                 b.compute()
@@ -899,12 +950,30 @@ def run(args, line, rank, world, local_rank, S, bag, T):
                 b.compute()
             torch.cuda.synchronize(dev)
             ms = (time.perf_counter() - t0) / 10 * 1e3
+            b.eng.profile("encoder")
+            for _ in range(10):
+                b.compute()
+            k_ms, k_n = b.eng.profile_read(0)
+            b.eng.profile(False)
+            kern = b.eng.last_encoder_kernel
+            k_avg = k_ms / max(k_n, 1)
+            ex = ENC_MFMA_PER_TILE[kern] * 4096 // 32
+            tf, tfx = (f * b.R / (k_avg * 1e-3) / 1e12 for f in (ENC_FLOP_PER_READ, ex))
             line["reference_order_encoder"] = {
-                "encoder_kernel": b.eng.last_encoder_variant, "ms_per_step": ms, "value": b.Sr / (ms * 1e-3), "steps": 10, "warmup": 3,
+                "encoder_kernel": b.eng.last_encoder_variant, "kernel": kern, "ms_per_step": ms, "value": b.Sr / (ms * 1e-3), "steps": 10, "warmup": 3,
                 "note": "same workload, m6a_set_encoder_variant(1): every float32 operation of the reference's encoder in the "
                         "reference's order (DESIGN.md section 2) -- read and site probabilities bit-identical to the reference's on "
                         "this workload's bags; the headline above runs the 12-slot kernel (within 1e-5 relative)"}
+            line["roofline_product_default"] = {
+                "kernel": "read encoder (%s: %s) -- what `m6anet_amd inference` (--encoder reference, its default) and "
+                          "INTEGRATION.md's stub launch on this workload" % (b.eng.last_encoder_variant, kern),
+                "bound": "mfma", "achieved": tf, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_F32_TFLOPS,
+                "traffic": None, "avg_launch_ms": k_avg, "launches": k_n, "algorithmic_flop_per_read": ENC_FLOP_PER_READ,
+                "executed_flop_per_read": ex, "mfma_per_32_read_tile": ENC_MFMA_PER_TILE[kern], "achieved_executed": tfx,
+                "frac_executed": tfx / PEAK_F32_TFLOPS, "reads_per_launch": b.R,
+                "timed_in": "10 extra steps after reference_order_encoder's, HIP events around every launch"}
             b.eng.set_encoder_variant(0)
+            line["with_h2d"] = with_h2d(b, T)
             # the path real data takes (bags are never uniform), in the same record: configs[4]'s per-GPU shape
             del b.X, b.rp
             b.eng.close()

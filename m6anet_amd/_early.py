@@ -71,13 +71,39 @@ def start_ranks(world, input_dirs, out_dir, argv):
     os.makedirs(str(out_dir), exist_ok=True)
     xdir = tempfile.mkdtemp(prefix="m6a_gpus_", dir=exchange_base(0 if given_store else store_size_estimate(input_dirs), out_dir))
     store = os.path.abspath(str(input_dirs[0])) if given_store else os.path.join(xdir, "job" + STORE_SUFFIX)
-    st = {"world": world, "xdir": xdir, "store": store, "given_store": given_store, "procs": [], "argv": list(argv)}
+    st = {"world": world, "xdir": xdir, "store": store, "given_store": given_store, "procs": [], "argv": list(argv),
+          "input_dirs": [str(d) for d in input_dirs], "out_dir": str(out_dir)}
     state = st
     atexit.register(cleanup)
     env = dict(os.environ, M6A_WORLD=str(world), M6A_XDIR=xdir, M6A_STORE=store)
     for r in range(1, world):
         st["procs"].append(subprocess.Popen([sys.executable, "-m", "m6anet_amd", "inference"] + list(argv), env=dict(env, M6A_RANK=str(r))))
     return st
+
+
+def ranks_may_share_a_gpu():
+    return os.environ.get("M6A_SHARE_GPU") == "1" or os.environ.get("M6A_EXCHANGE") == "host"
+
+
+def strip_command(argv):
+    """argv without the sub-command word: what start_ranks was given by maybe_start."""
+    return list(argv[1:]) if argv and argv[0] == "inference" else list(argv)
+
+
+def visible_devices_estimate():
+    """Devices this process will see, without loading the HIP runtime: the render nodes of the container, cut down by
+    HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES when they are set (a list of indices or UUIDs: its
+    length; empty = none).  An estimate that errs low only delays the ranks' start (launch() starts them), one that errs
+    high starts ranks that exchange_mode() then ends with its message."""
+    try:
+        n = sum(1 for f in os.listdir("/dev/dri") if f.startswith("renderD"))
+    except OSError:
+        n = 0
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
 
 
 def cleanup():
@@ -101,13 +127,8 @@ def maybe_start(argv):
             return
         # more ranks than GPUs is refused later, with a message, unless the debugging transport lets ranks share one: do not
         # start what would only be killed (the render nodes the container sees are a cheap stand-in for hipGetDeviceCount)
-        if os.environ.get("M6A_EXCHANGE", "rccl") != "host":
-            try:
-                n_dev = sum(1 for f in os.listdir("/dev/dri") if f.startswith("renderD"))
-            except OSError:
-                n_dev = 0
-            if int(g[0]) > n_dev:
-                return
+        if not ranks_may_share_a_gpu() and int(g[0]) > visible_devices_estimate():
+            return
         dirs, out = _values(argv[1:], "--input_dir"), _values(argv[1:], "--out_dir")
         if not dirs or not out or len(out) != 1:
             return

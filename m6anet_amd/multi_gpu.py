@@ -3,12 +3,17 @@
 The reference has no multi-device path; this is north_star's: candidate sites are independent, so the job is cut
 into contiguous, flush-group-aligned shards balanced by read count (`m6a_shard_plan`), every rank -- one process per
 GPU -- runs the whole hot path on its shard with `m6a_set_job_offset(first_site)` (flush groups and RNG restarts are
-those of the whole job, so the CSVs do not depend on N), and ONE exchange at the end brings site_prob + mod_ratio
-(`m6a_gather`, 12 B per site) to rank 0 over RCCL/xGMI -- the library's own communicator, no torch.distributed.
+those of the whole job, so the CSVs do not depend on N).
 The OUTPUT is sharded like the compute: every rank maps the store, so it formats the rows of its own sites and
 pwrite()s them at its offset into data.site_proba.csv / data.indiv_proba.csv (`m6a_io_csv_shard_size / _write`; the
-byte counts meet in the exchange directory) -- the per-read probabilities, 4 B per read and the bulk of the output, never
-leave the rank that computed them, and the 8-GPU job is not one host thread's write().
+byte counts meet in the exchange directory, 16 bytes per rank) -- neither the per-read probabilities (4 B per read, the
+bulk of the output) nor the site results leave the rank that computed them, and the 8-GPU job is not one host thread's
+write().  So the CSVs need NO device exchange, and by default the command performs none (round 4 always ran north_star's
+gather and then used it only to re-check rank 0's own shard: an RCCL bring-up the result did not depend on, and one more
+way for the job to fail -- ADVICE r4).  The gather stays available for callers that want the site results in ONE place:
+M6A_EXCHANGE=rccl brings site_prob + mod_ratio (`m6a_gather`, 12 B per site) to rank 0 over RCCL/xGMI -- the library's own
+communicator, no torch.distributed -- and rank 0 checks them against the rows it can see; `bench.py --gpus N` measures
+that gather every step.
 
     the process the user started = rank 0
       |- makes an exchange directory, starts ranks 1..N-1: the same command line with M6A_RANK / M6A_WORLD / M6A_XDIR /
@@ -18,10 +23,11 @@ leave the rank that computed them, and the 8-GPU job is not one host thread's wr
       |- runs its own shard, joins the exchange, writes its rows
       '- waits for the others; a rank that dies ends the job (exact pids) with its exit code
 
-The 128-byte RCCL id travels through the exchange directory (rank 0 writes it, the others wait for it).
-M6A_EXCHANGE=host is a debugging aid like bench.py's M6A_BENCH_BACKEND=gloo: the gather goes through files in the
-exchange directory instead of RCCL and ranks may share a GPU (RCCL refuses two ranks on one device), which is how the
-one-GPU test box checks that N ranks give the CSV bytes of one.
+M6A_EXCHANGE = none (default) | rccl | host.  rccl: the 128-byte RCCL id travels through the exchange directory (rank 0
+writes it, the others wait for it).  host is a debugging aid like bench.py's M6A_BENCH_BACKEND=gloo: the gather goes
+through files in the exchange directory instead of RCCL.  M6A_SHARE_GPU=1 (implied by host) lets ranks share a GPU
+(rank % devices; RCCL refuses two ranks on one device), which is how the one-GPU test box checks that N = 2..8 ranks give
+the CSV bytes of one.
 """
 import os
 import shutil
@@ -68,13 +74,18 @@ def _publish(path, data):
 
 
 def exchange_mode(world):
-    mode = os.environ.get("M6A_EXCHANGE", "rccl")
-    if mode not in ("rccl", "host"):
-        raise ValueError("M6A_EXCHANGE must be 'rccl' or 'host'")
-    if mode == "rccl" and device_count() < world:
-        raise RuntimeError("--gpus %d but only %d HIP device(s) visible (M6A_EXCHANGE=host lets ranks share a GPU for debugging)"
+    """(mode, share): mode = what brings the site results to rank 0 (none: nothing, the default -- the CSVs are written
+    sharded), share = ranks may sit on the same GPU (debugging)."""
+    mode = os.environ.get("M6A_EXCHANGE", "none")
+    if mode not in ("none", "rccl", "host"):
+        raise ValueError("M6A_EXCHANGE must be 'none', 'rccl' or 'host'")
+    share = _early.ranks_may_share_a_gpu()
+    if mode == "rccl" and share:
+        raise ValueError("M6A_EXCHANGE=rccl needs one GPU per rank (M6A_SHARE_GPU is set)")
+    if not share and device_count() < world:
+        raise RuntimeError("--gpus %d but only %d HIP device(s) visible (M6A_SHARE_GPU=1 lets ranks share a GPU for debugging)"
                            % (world, device_count()))
-    return mode
+    return mode, share
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -101,10 +112,16 @@ def launch(args, weights):
     # ranks 1..N-1 were normally started by m6anet_amd/_early.py, before this process imported NumPy; if not (the CLI called
     # as a function), they are started here
     st = _early.state
-    if st is None or st["world"] != world:
+    dirs = [str(d) for d in args.input_dir]
+    if st is not None and (st["world"] != world or st["input_dirs"] != dirs or st["out_dir"] != str(args.out_dir)
+                           or st["argv"] != _early.strip_command(sys.argv[1:])):
+        # the hand-parsed command line of the early start is not what argparse made of it (abbreviated options, `=` forms
+        # it does not know): those ranks would run another job -- end them, start again from the parsed arguments
         _early.cleanup()
+        st = None
+    if st is None:
         exchange_mode(world)                               # fails before anything is started, with the reason
-        st = _early.start_ranks(world, [str(d) for d in args.input_dir], args.out_dir, rank_argv(args))
+        st = _early.start_ranks(world, dirs, args.out_dir, rank_argv(args))
     xdir, store, given_store, procs = st["xdir"], st["store"], st["given_store"], st["procs"]
     exchange_mode(world)                                   # more ranks than devices etc.: the `finally` below ends the early ranks
     # a terminated launcher still takes its ranks down and removes the exchange directory (a packed store can be hundreds of MB
@@ -139,7 +156,8 @@ def launch(args, weights):
 
         def make_engine():
             try:
-                made["engine"] = M6ANetEngine(weights=weights, device=0)
+                from .scripts.inference import make_engine_for
+                made["engine"] = make_engine_for(args, weights, 0)
             except BaseException as exc:                    # noqa: BLE001 -- re-raised on the main thread
                 made["error"] = exc
         starter = threading.Thread(target=make_engine)
@@ -231,12 +249,13 @@ def run_rank(args, weights, engine=None):
     rank, world = int(os.environ["M6A_RANK"]), int(os.environ["M6A_WORLD"])
     xdir, store = os.environ["M6A_XDIR"], os.environ["M6A_STORE"]
     parent = os.getppid()                                    # ranks 1..: the launcher (= rank 0); rank 0: whoever started the job
-    mode = exchange_mode(world)
-    device = rank if mode == "rccl" else rank % max(device_count(), 1)
+    mode, share = exchange_mode(world)
+    device = rank % max(device_count(), 1) if share else rank
 
     # the GPU context comes up while the launcher may still be packing the store
     if engine is None:
-        engine = M6ANetEngine(weights=weights, device=device)
+        from .scripts.inference import make_engine_for
+        engine = make_engine_for(args, weights, device)
     _wait_for(store, "the launcher's site store", parent, busy=os.path.join(xdir, "packing"))
     batch = open_store(store, args.norm_path, DEFAULT_MIN_READS)
     off = batch.off
@@ -250,8 +269,10 @@ def run_rank(args, weights, engine=None):
         batch.X[r0:r1], batch.site_kmers[a:b], np.ascontiguousarray(off[a:b + 1] - r0), args.num_iterations, N_SAMPLES,
         args.read_proba_threshold, args.seed, args.batch_size, args.save_per_batch)
 
-    # ---- the job's one exchange: site_prob + mod_ratio (12 B per site) to rank 0 -- over RCCL/xGMI, or through the exchange
-    # directory in the debugging mode.  The per-read probabilities (4 B per read, the bulk of the output) never travel.
+    # ---- opt-in (M6A_EXCHANGE): site_prob + mod_ratio (12 B per site) to rank 0 -- over RCCL/xGMI, or through the exchange
+    # directory in the debugging mode.  The CSVs below do not need it (every rank writes its own rows); the per-read
+    # probabilities (4 B per read, the bulk of the output) never travel.
+    site_all = mod_all = None
     if mode == "rccl":
         ident_path = os.path.join(xdir, "rccl_id")
         if rank == 0:
@@ -264,8 +285,7 @@ def run_rank(args, weights, engine=None):
             raise RuntimeError("RCCL formed a communicator of %d ranks, the job has %d" % (seen, world))
         site_all, mod_all = engine.gather(site_prob, mod_ratio, cuts, dst=0)
         engine.comm_destroy()
-    else:
-        site_all = mod_all = None
+    elif mode == "host":
         if rank != 0:
             _publish(os.path.join(xdir, "shard%d.bin" % rank), mod_ratio.tobytes() + site_prob.tobytes())
         else:
@@ -286,8 +306,8 @@ def run_rank(args, weights, engine=None):
     if getattr(args, "drop_unflushed_tail", False):
         n_write = reference_written_sites(batch.n_sites, args.batch_size, args.save_per_batch)
     write_rows_sharded(batch.native, args.out_dir, xdir, rank, world, a, b, read_prob, site_prob, mod_ratio, n_write, parent)
-    if rank == 0:
-        # rank 0 is the job: it checks the gathered site results against what it can see of them (its own shard) -- its exit
-        # code is the job's
+    if rank == 0 and site_all is not None:
+        # the caller asked for the gather: rank 0 checks the gathered site results against what it can see of them (its own
+        # shard) -- its exit code is the job's
         if not (np.array_equal(site_all[a:b], site_prob) and np.array_equal(mod_all[a:b], mod_ratio, equal_nan=True)):
             raise RuntimeError("the gathered site results do not contain rank 0's own shard")

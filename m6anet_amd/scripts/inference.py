@@ -39,18 +39,30 @@ def argparser():
                         help="default probability threshold for a read to be considered modified.")
     parser.add_argument("--gpus", default=1, type=int,
                         help="GPUs of this node to split the job's sites over: one process per GPU, flush-group-aligned shards, "
-                             "one RCCL gather to the rank that writes the CSVs; the output does not depend on it.")
+                             "every rank writes the rows of its own sites; the output does not depend on it.")
     parser.add_argument("--encoder", default="reference", choices=["reference", "fast"],
                         help="read encoder kernel.  reference (default): the 16-slot kernel, which performs the reference's float32 "
-                             "operations in the reference's order all the way to the sigmoid -- read probabilities bit-identical "
-                             "to `m6anet inference` on an AVX-512 host wherever MKL groups a batch's rows in fours (every read of "
-                             "20-read bags, > 99.9 %% of ragged ones); fast: the automatic choice, for bags of >= 16 reads a 12-slot "
-                             "kernel 10 %% faster and within 1e-5 relative of the reference.  The encoder is under 1 %% of this "
-                             "command's wall time either way.  The environment variable M6A_ENCODER overrides both.")
+                             "operations in the reference's order all the way to the sigmoid -- on the host configuration it was "
+                             "validated against (torch + MKL on AVX-512) read probabilities are bit-identical to `m6anet inference` "
+                             "wherever MKL groups a batch's rows in fours (every read of 20-read bags, > 99.9 %% of ragged ones); "
+                             "activations beyond 2^64 saturate and a -inf pre-activation becomes NaN (DESIGN.md).  fast: the "
+                             "library's automatic choice, for bags of >= 16 reads a 12-slot kernel 9 %% faster and within 1e-5 "
+                             "relative of the reference.  The encoder is under 1 %% of this command's wall time either way.  "
+                             "The environment variable M6A_ENCODER, if set, decides instead.")
     parser.add_argument("--drop_unflushed_tail", action="store_true",
                         help="reference-compatible output: omit the batches after the reference's last flush, which "
                              "`m6anet inference` never writes (its flush test is inverted); default: write every site.")
     return parser
+
+
+def make_engine_for(args, weights, device):
+    """The context of one `inference` process with --encoder applied to IT (m6a_set_encoder_variant), not to the process's
+    environment: a library caller's other contexts keep the automatic choice.  M6A_ENCODER, if the user set it, was read
+    by m6a_create and stays."""
+    engine = M6ANetEngine(weights=weights, device=device)
+    if args.encoder == "reference" and "M6A_ENCODER" not in os.environ:
+        engine.set_encoder_variant(1)
+    return engine
 
 
 def _device_index(device):
@@ -99,8 +111,6 @@ def main(args):
 
     if args.gpus < 1:
         raise ValueError("--gpus must be >= 1")
-    if args.encoder == "reference":
-        os.environ.setdefault("M6A_ENCODER", "general16")     # read by m6a_create; inherited by the ranks of a --gpus N job
     if "M6A_RANK" in os.environ:                         # one rank of a --gpus N job (started by multi_gpu.launch)
         from .. import multi_gpu
         multi_gpu.run_rank(args, weights)
@@ -119,7 +129,7 @@ def main(args):
 
     def make_engine():
         try:
-            made["engine"] = M6ANetEngine(weights=weights, device=_device_index(args.device))
+            made["engine"] = make_engine_for(args, weights, _device_index(args.device))
             made["engine"].prepare_host_io()     # pinned staging for the host arrays the loader is producing
         except BaseException as exc:        # re-raised on the main thread below
             made["error"] = exc

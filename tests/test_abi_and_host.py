@@ -199,13 +199,22 @@ def test_multi_gpu_exchange_plumbing(tmp_path, monkeypatch):
     import os
     from m6anet_amd import multi_gpu
     monkeypatch.delenv("M6A_EXCHANGE", raising=False)
+    monkeypatch.delenv("M6A_SHARE_GPU", raising=False)
     with pytest.raises(RuntimeError, match="HIP device"):
         multi_gpu.exchange_mode(2)
     monkeypatch.setenv("M6A_EXCHANGE", "carrier-pigeon")
     with pytest.raises(ValueError):
         multi_gpu.exchange_mode(2)
     monkeypatch.setenv("M6A_EXCHANGE", "host")
-    assert multi_gpu.exchange_mode(64) == "host"
+    assert multi_gpu.exchange_mode(64) == ("host", True)
+    # the default: NO device exchange (every rank writes its own rows); sharing a GPU is its own switch, and RCCL refuses it
+    monkeypatch.delenv("M6A_EXCHANGE")
+    monkeypatch.setenv("M6A_SHARE_GPU", "1")
+    assert multi_gpu.exchange_mode(8) == ("none", True)
+    monkeypatch.setenv("M6A_EXCHANGE", "rccl")
+    with pytest.raises(ValueError, match="one GPU per rank"):
+        multi_gpu.exchange_mode(2)
+    monkeypatch.delenv("M6A_SHARE_GPU")
     monkeypatch.setenv("M6A_EXCHANGE_TIMEOUT", "0.2")
     with pytest.raises(TimeoutError, match="rank 3"):
         multi_gpu._wait_for(str(tmp_path / "never"), "rank 3's results", os.getppid())
@@ -267,6 +276,16 @@ def test_early_rank_start_helpers(tmp_path, monkeypatch):
         assert _early.state is None, av
         for k in env:
             monkeypatch.delenv(k)
+    # the early device estimate honours the *_VISIBLE_DEVICES variables (never more than the list names)
+    n_all = _early.visible_devices_estimate()
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0")
+    assert _early.visible_devices_estimate() == min(n_all, 1)
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "")
+    assert _early.visible_devices_estimate() == 0
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    monkeypatch.delenv("ROCR_VISIBLE_DEVICES")
+    assert _early.strip_command(["inference", "--gpus", "2"]) == ["--gpus", "2"] and _early.strip_command(["--gpus", "2"]) == ["--gpus", "2"]
+    assert not _early.ranks_may_share_a_gpu()
 
 
 def test_cpu_baseline_reports_what_the_process_may_use():

@@ -353,18 +353,20 @@ def csv_bytes(out_dir):
 
 @pytest.mark.parametrize("extra", [[], ["--batch_size", "8", "--save_per_batch", "3", "--drop_unflushed_tail", "--seed", "5"]])
 def test_cli_gpus_n_writes_the_bytes_of_one_gpu(tmp_path, extra):
-    """`inference --gpus N` (self-launched ranks, flush-group-aligned shards, job offsets, gather to rank 0, rank 0
-    writes) == the one-GPU run, byte for byte, from data.json (the launcher packs it once) and from a 5 050-site
-    store (every rank maps it).  The box has one GPU: M6A_EXCHANGE=host lets the ranks share it and moves the gather
-    through the exchange directory -- everything but the RCCL transport is the code an 8-GPU node runs."""
+    """`inference --gpus N` (self-launched ranks, flush-group-aligned shards, job offsets, every rank pwrite()s the rows
+    of its own sites) == the one-GPU run, byte for byte, for N = 2, 3, 5 and 8 -- the size of the node the driver runs --
+    from data.json (the launcher packs it once) and from a 5 050-site store (every rank maps it).  The box has one GPU:
+    M6A_SHARE_GPU=1 lets the ranks share it; everything else is the code an 8-GPU node runs.  The default performs NO device
+    exchange; M6A_EXCHANGE=host (the debugging stand-in for the opt-in RCCL gather) additionally brings the site results to
+    rank 0 through the exchange directory, where they are checked."""
     common = ["--num_iterations", "40", "--n_processes", "4"] + extra
     one = str(tmp_path / "one")
     cli(["inference", "--input_dir", DATA, "--out_dir", one] + common)
     want = csv_bytes(one)
     assert want[0].count(b"\n") > 50
-    for n in (2, 3):
+    for n, env in ((2, {"M6A_SHARE_GPU": "1"}), (3, {"M6A_EXCHANGE": "host"}), (8, {"M6A_SHARE_GPU": "1"})):
         out = str(tmp_path / ("n%d" % n))
-        cli(["inference", "--input_dir", DATA, "--out_dir", out, "--gpus", str(n)] + common, env={"M6A_EXCHANGE": "host"})
+        cli(["inference", "--input_dir", DATA, "--out_dir", out, "--gpus", str(n)] + common, env=env)
         assert csv_bytes(out) == want, n
     big = str(tmp_path / "big")
     replicate_bundled(50, big)
@@ -374,10 +376,25 @@ def test_cli_gpus_n_writes_the_bytes_of_one_gpu(tmp_path, extra):
     cli(["inference", "--input_dir", store, "--out_dir", one] + common)
     want = csv_bytes(one)
     assert want[0].count(b"\n") > 2500
-    for n in (2, 5):
-        out = str(tmp_path / ("big_n%d" % n))
-        cli(["inference", "--input_dir", store, "--out_dir", out, "--gpus", str(n)] + common, env={"M6A_EXCHANGE": "host"})
-        assert csv_bytes(out) == want, n
+    for n, env in ((2, {"M6A_EXCHANGE": "host"}), (5, {"M6A_SHARE_GPU": "1"}), (8, {"M6A_SHARE_GPU": "1"}), (8, {"M6A_EXCHANGE": "host"})):
+        out = str(tmp_path / ("big_n%d_%s" % (n, "x".join(env))))
+        cli(["inference", "--input_dir", store, "--out_dir", out, "--gpus", str(n)] + common, env=env)
+        assert csv_bytes(out) == want, (n, env)
+
+
+def test_cli_gpus_8_fast_encoder_and_a_command_line_the_early_parser_misreads(tmp_path):
+    """Eight ranks with --encoder fast (every rank applies it to its own context: nothing rides in the environment), on a
+    command line the early starter's hand parser reads differently from argparse: `--input_dir` given twice -- argparse
+    keeps the last, the hand parser saw the first, so the early ranks wait for a packed store nobody will write.  launch()
+    must notice, end them and start the ranks from the parsed arguments."""
+    store = str(tmp_path / "b.m6astore")
+    cli(["pack", "--input_dir", DATA, "--out", store])
+    one = str(tmp_path / "one")
+    cli(["inference", "--input_dir", store, "--out_dir", one, "--num_iterations", "30", "--encoder", "fast"])
+    out = str(tmp_path / "n8")
+    cli(["inference", "--input_dir", str(tmp_path / "not_there"), "--input_dir", store, "--out_dir", out, "--gpus=8", "--num_iter", "30",
+         "--encoder", "fast"], env={"M6A_SHARE_GPU": "1", "M6A_EXCHANGE_TIMEOUT": "60"})
+    assert csv_bytes(out) == csv_bytes(one)
 
 
 def test_cli_rank_over_rccl_on_one_gpu(tmp_path):
@@ -393,7 +410,7 @@ def test_cli_rank_over_rccl_on_one_gpu(tmp_path):
     out = str(tmp_path / "rank")
     os.makedirs(out)
     cli(["inference", "--input_dir", store, "--out_dir", out, "--gpus", "1"] + common,
-        env={"M6A_RANK": "0", "M6A_WORLD": "1", "M6A_XDIR": str(xdir), "M6A_STORE": store})
+        env={"M6A_RANK": "0", "M6A_WORLD": "1", "M6A_XDIR": str(xdir), "M6A_STORE": store, "M6A_EXCHANGE": "rccl"})
     assert (xdir / "rccl_id").stat().st_size == 128
     assert csv_bytes(out) == csv_bytes(one)
 
@@ -600,6 +617,28 @@ def test_configs1_at_full_size(eng, orc, weights):
     assert np.allclose(rp, want_rp, rtol=1e-5, atol=1e-8)
     want_site, want_mod = orc.site_pool(rp, d["off"], 100, THR, n_threads=threads)
     assert np.array_equal(site, want_site) and np.array_equal(mod, want_mod)
+
+
+@pytest.mark.parametrize("workload,sites", [("uniform", 4001), ("ragged", 1201)])
+def test_bench_world_8_rehearsal_on_one_gpu(workload, sites):
+    """The driver's 8-GPU run, rehearsed: `bench.py --gpus 8` starts its own eight ranks (gloo here, so that they can
+    share the one GPU of a test box; on the node the same code runs on backend nccl), every rank runs the HIP engine on its
+    flush-group-aligned shard of the 8 x sites job with its job offset, one gather per step brings site_prob / mod_ratio to
+    rank 0, certify() collects every rank's facts with all_gather_object, and --verify recomputes the whole job unsharded on
+    rank 0: bit-identical.  What it cannot rehearse is the RCCL transport itself."""
+    out, lines = run_bench(["--gpus", "8", "--workload", workload, "--sites", str(sites), "--iters", "60", "--steps", "2", "--warmup", "1",
+                            "--min-seconds", "0", "--verify", "--no-cpu-baseline"], {"M6A_BENCH_BACKEND": "gloo", "M6A_BENCH_TIMEOUT": "600"},
+                           timeout=900)
+    assert out.returncode == 0 and len(lines) == 1, out.stderr[-2000:]
+    d = lines[0]
+    assert d["n_gpus"] == 8 and d["verify"] is True and "error" not in d
+    assert d["value"] > 0 and d["config"]["sites_per_gpu"] == sites and d["scaling"] == "weak"
+    pr = d["per_rank"]
+    for key in ("sites", "reads", "ms_per_step", "local_ms_per_step", "gather_ms_per_step"):
+        assert len(pr[key]) == 8, key
+    assert sum(pr["sites"]) == 8 * sites and all(x > 0 for x in pr["ms_per_step"] + pr["local_ms_per_step"])
+    assert max(pr["reads"]) < 1.2 * (sum(pr["reads"]) / 8)                   # shards balanced by reads
+    assert d["rccl"]["ranks_seen"] is None and "gloo" in d["rccl"]["communicator"] and d["efficiency"] > 0
 
 
 def test_bench_sustained_leg_with_two_ranks():
