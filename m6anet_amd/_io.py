@@ -151,6 +151,9 @@ class NativeSites:
     def csv_shard_size(self, a, b, read_prob, site_prob, mod_ratio, n_threads=0):
         """Bytes the rows of sites [a, b) take in (data.site_proba.csv, data.indiv_proba.csv); the arrays hold that range only."""
         rp, sp, mr = self._shard_args(a, b, read_prob, site_prob, mod_ratio)
+        # the library keeps the text it formats for the csv_shard_write that follows, keyed on the arrays' addresses (and a
+        # checksum): converted temporaries are kept alive until then, together with the caller's objects they were made from
+        self._shard_kept = ((a, b, read_prob, site_prob, mod_ratio), (rp, sp, mr))
         ns, ni = C.c_int64(), C.c_int64()
         _chk(self._L.m6a_io_csv_shard_size(self._h, rp.ctypes.data, sp.ctypes.data, mr.ctypes.data, int(a), int(b), int(n_threads),
                                            C.byref(ns), C.byref(ni)))
@@ -159,7 +162,11 @@ class NativeSites:
     def csv_shard_write(self, out_dir, a, b, read_prob, site_prob, mod_ratio, site_offset, indiv_offset, header_and_totals=None, n_threads=0):
         """pwrite()s the rows of sites [a, b) at the given byte offsets; `header_and_totals` = (site_total, indiv_total) on the
         one rank that also writes the header lines and sets the files' final sizes."""
-        rp, sp, mr = self._shard_args(a, b, read_prob, site_prob, mod_ratio)
+        kept, self._shard_kept = getattr(self, "_shard_kept", None), None
+        if kept is not None and kept[0][:2] == (a, b) and all(x is y for x, y in zip(kept[0][2:], (read_prob, site_prob, mod_ratio))):
+            rp, sp, mr = kept[1]                     # the very arrays csv_shard_size formatted: the kept text is reused
+        else:
+            rp, sp, mr = self._shard_args(a, b, read_prob, site_prob, mod_ratio)
         st, it = header_and_totals if header_and_totals is not None else (-1, -1)
         _chk(self._L.m6a_io_csv_shard_write(self._h, os.fsencode(out_dir), rp.ctypes.data, sp.ctypes.data, mr.ctypes.data, int(a), int(b),
                                             int(n_threads), int(site_offset), int(indiv_offset), 1 if header_and_totals is not None else 0,

@@ -299,8 +299,11 @@ struct m6a_sites {
     struct CsvKeep {
         int64_t a = -1, b = -1;
         const void *rp = nullptr, *sp = nullptr, *mr = nullptr;
+        // the kept text belongs to VALUES, not to addresses: a caller's temporary arrays can be freed after the size call and
+        // other values allocated at the same addresses before the write -- a checksum of what was formatted is compared too
+        uint64_t sum = 0;
         std::vector<std::string> site, indiv;
-        void clear() { a = b = -1; std::vector<std::string>().swap(site); std::vector<std::string>().swap(indiv); }
+        void clear() { a = b = -1; sum = 0; std::vector<std::string>().swap(site); std::vector<std::string>().swap(indiv); }
     } csv_keep;
     void view_owned()
     {
@@ -914,6 +917,19 @@ int m6a_io_write_csv_n(const m6a_sites *s, const char *out_dir, const float *rea
     return rc;
 }
 
+// Checksum of the arrays a shard's rows are formatted from: every site value, and the read probabilities sampled at a stride
+// that keeps the pass under ~1 M loads (plus both ends) -- a guard against stale text, not a hash of the job.
+static uint64_t csv_args_sum(const float *rp, int64_t nr, const float *sp, const double *mr, int64_t ns)
+{
+    uint64_t h = 0x9E3779B97F4A7C15ull ^ (uint64_t)nr ^ ((uint64_t)ns << 32);
+    auto mix = [&](uint64_t v) { h = (h ^ v) * 0x100000001B3ull; h ^= h >> 29; };
+    for (int64_t i = 0; i < ns; i++) { uint32_t u; uint64_t w; memcpy(&u, sp + i, 4); memcpy(&w, mr + i, 8); mix(u); mix(w); }
+    const int64_t step = std::max<int64_t>(1, nr >> 20);
+    for (int64_t i = 0; i < nr; i += step) { uint32_t u; memcpy(&u, rp + i, 4); mix(u); }
+    for (int64_t i = std::max<int64_t>(0, nr - 64); i < nr; i++) { uint32_t u; memcpy(&u, rp + i, 4); mix(u); }
+    return h;
+}
+
 int64_t m6a_io_csv_header_bytes(int which) { return which == 0 ? (int64_t)sizeof(kSiteHeader) - 1 : (int64_t)sizeof(kIndivHeader) - 1; }
 
 int m6a_io_csv_shard_size(const m6a_sites *s, const float *read_prob, const float *site_prob, const double *mod_ratio,
@@ -935,7 +951,10 @@ int m6a_io_csv_shard_size(const m6a_sites *s, const float *read_prob, const floa
                                if (keeping) { keep.site.push_back(std::move(a)); keep.indiv.push_back(std::move(b)); }
                                return 0;
                            });
-    if (!rc && keeping) { keep.a = site_begin; keep.b = site_end; keep.rp = read_prob; keep.sp = site_prob; keep.mr = mod_ratio; }
+    if (!rc && keeping) {
+        keep.a = site_begin; keep.b = site_end; keep.rp = read_prob; keep.sp = site_prob; keep.mr = mod_ratio;
+        keep.sum = csv_args_sum(read_prob, s->vOff[site_end] - s->vOff[site_begin], site_prob, mod_ratio, site_end - site_begin);
+    }
     else keep.clear();
     *site_bytes = na; *indiv_bytes = nb;
     return rc;
@@ -970,7 +989,8 @@ int m6a_io_csv_shard_write(const m6a_sites *s, const char *out_dir, const float 
     }
     int64_t sa = site_offset, sb = indiv_offset;
     m6a_sites::CsvKeep &keep = const_cast<m6a_sites *>(s)->csv_keep;
-    if (ok && keep.a == site_begin && keep.b == site_end && keep.rp == read_prob && keep.sp == site_prob && keep.mr == mod_ratio) {
+    if (ok && keep.a == site_begin && keep.b == site_end && keep.rp == read_prob && keep.sp == site_prob && keep.mr == mod_ratio &&
+        keep.sum == csv_args_sum(read_prob, s->vOff[site_end] - s->vOff[site_begin], site_prob, mod_ratio, site_end - site_begin)) {
         // the text m6a_io_csv_shard_size formatted a moment ago
         ok = pwrite_round(f, g, keep.site, keep.indiv, sa, sb, n_workers(n_threads, (int64_t)keep.site.size())) == 0;
         keep.clear();
@@ -1325,15 +1345,26 @@ inline void append_ll(std::string &s, long long v)
     s.append(b, (size_t)(r.ptr - b));
 }
 
+// An exception on a worker thread would be std::terminate, one on the calling thread would unwind through the C ABI: both
+// are caught here, the remaining items are dropped, and ONE std::bad_alloc is thrown on the calling thread after every worker
+// has been joined -- m6a_io_dataprep turns it into M6A_IO_ENOMEM.
 template <class F>
 void on_threads(int nw, int n_items, F &&f)
 {
     std::atomic<int> next{0};
-    auto worker = [&]() { for (int k; (k = next.fetch_add(1)) < n_items;) f(k); };
+    std::atomic<bool> threw{false};
+    auto worker = [&]() {
+        for (int k; (k = next.fetch_add(1)) < n_items;) {
+            try { f(k); } catch (...) { threw = true; next = n_items; }
+        }
+    };
     std::vector<std::thread> th;
-    for (int t = 1; t < std::min(nw, n_items); t++) th.emplace_back(worker);
+    try {
+        for (int t = 1; t < std::min(nw, n_items); t++) th.emplace_back(worker);
+    } catch (...) { /* fewer threads than asked for: the ones that started and this one do the work */ }
     worker();
     for (auto &t : th) t.join();
+    if (threw) throw std::bad_alloc();
 }
 
 }  // namespace
@@ -1347,9 +1378,31 @@ extern "C" int m6a_io_py_repr(double v, char *buf40)
     return (int)s.size();
 }
 
+static int dataprep_impl(const char *eventalign_path, const char *out_dir, int n_threads,
+                         int readcount_min, int readcount_max, int min_segment_count, int n_neighbors,
+                         int compress, int skip_index);
+
+// No exception crosses the C ABI: the files this targets run to hundreds of GB, and the index (32 B per read run), the
+// per-transcript buffers and the writers' text can all exhaust memory -- that is M6A_IO_ENOMEM, not an aborted interpreter.
 extern "C" int m6a_io_dataprep(const char *eventalign_path, const char *out_dir, int n_threads,
                                int readcount_min, int readcount_max, int min_segment_count, int n_neighbors,
                                int compress, int skip_index)
+{
+    try {
+        return dataprep_impl(eventalign_path, out_dir, n_threads, readcount_min, readcount_max, min_segment_count, n_neighbors,
+                             compress, skip_index);
+    } catch (const std::bad_alloc &) {
+        return fail(M6A_IO_ENOMEM, "dataprep: out of memory");
+    } catch (const std::exception &e) {
+        return fail(M6A_IO_EIO, "dataprep: %s", e.what());
+    } catch (...) {
+        return fail(M6A_IO_EIO, "dataprep: unexpected exception");
+    }
+}
+
+static int dataprep_impl(const char *eventalign_path, const char *out_dir, int n_threads,
+                         int readcount_min, int readcount_max, int min_segment_count, int n_neighbors,
+                         int compress, int skip_index)
 {
     if (!eventalign_path || !out_dir) return fail(M6A_IO_EINVAL, "null argument");
     if (n_neighbors < 1 || n_neighbors > 16) return fail(M6A_IO_EINVAL, "n_neighbors must be 1..16");
@@ -1383,7 +1436,7 @@ extern "C" int m6a_io_dataprep(const char *eventalign_path, const char *out_dir,
     // Declared after `idx` / `tx_names`, which it reads: its destructor joins the thread before they go, on every return path.
     struct IndexFileWriter {
         std::thread th;
-        std::atomic<bool> ok{true};
+        std::atomic<bool> ok{true}, oom{false};
         void wait() { if (th.joinable()) th.join(); }
         ~IndexFileWriter() { wait(); }
     } idx_writer;
@@ -1480,6 +1533,7 @@ extern "C" int m6a_io_dataprep(const char *eventalign_path, const char *out_dir,
         for (int k = 0; k < NC; k++) bounds[(size_t)k] = chunks[(size_t)k].out;
         const int nbg = std::max(1, nw / 4);
         idx_writer.th = std::thread([&idx, &tx_names, &idx_writer, fd, nbg, bounds = std::move(bounds)]() {
+          try {
             static const char kIdxHeader[] = "transcript_id,read_index,pos_start,pos_end\n";
             int64_t file_off = (int64_t)sizeof(kIdxHeader) - 1;
             bool io_ok = ::pwrite(fd, kIdxHeader, sizeof(kIdxHeader) - 1, 0) == (ssize_t)(sizeof(kIdxHeader) - 1);
@@ -1521,6 +1575,11 @@ extern "C" int m6a_io_dataprep(const char *eventalign_path, const char *out_dir,
             }
             if (::close(fd) != 0) io_ok = false;
             if (!io_ok) idx_writer.ok = false;
+          } catch (...) {                              // out of memory for a batch of text: reported as the file's failure
+            (void)::close(fd);
+            idx_writer.ok = false;
+            idx_writer.oom = true;
+          }
         });
     }
     trace.mark("dataprep: index file handed to its writer");
@@ -1573,7 +1632,7 @@ extern "C" int m6a_io_dataprep(const char *eventalign_path, const char *out_dir,
         // logged like the reference: only transcripts that yielded at least one DRACH window (dataprep_utils.py:415,431,472)
         if (o.logged) fprintf(fl, "%s: Data preparation ... Done.\n", tx_names[(size_t)t].c_str());
     };
-    auto worker = [&]() {
+    auto worker_body = [&]() {
         for (;;) {
             const int64_t t = next.fetch_add(1);
             if (t >= NT) break;
@@ -1612,9 +1671,23 @@ extern "C" int m6a_io_dataprep(const char *eventalign_path, const char *out_dir,
             writing = false;
         }
     };
+    // a worker that runs out of memory (the transcript's feature / JSON buffers) fails the job instead of the process: the
+    // others see `failed` at their next wait and leave
+    auto worker = [&]() {
+        try {
+            worker_body();
+        } catch (...) {
+            std::lock_guard<std::mutex> lk(mu);
+            if (!failed) { failed = true; fail_rc = M6A_IO_ENOMEM; fail_msg = "dataprep: out of memory in the transcript pass"; }
+            writing = false;
+            cv.notify_all();
+        }
+    };
     {
         std::vector<std::thread> th;
-        for (int w = 1; w < nw; w++) th.emplace_back(worker);
+        try {
+            for (int w = 1; w < nw; w++) th.emplace_back(worker);
+        } catch (...) { /* fewer threads than asked for */ }
         worker();
         for (auto &t : th) t.join();
     }
@@ -1625,6 +1698,7 @@ extern "C" int m6a_io_dataprep(const char *eventalign_path, const char *out_dir,
     if (bad) return fail(M6A_IO_EIO, "cannot close outputs in %s", out_dir);
     trace.mark("dataprep: transcripts");
     idx_writer.wait();
+    if (idx_writer.oom) return fail(M6A_IO_ENOMEM, "out of memory while writing %s", idx_path.c_str());
     if (!idx_writer.ok) return fail(M6A_IO_EIO, "cannot write %s", idx_path.c_str());
     trace.mark("dataprep: index file finished behind them");
     if (trace.on) fprintf(stderr, "m6a_io: dataprep peak of finished-but-unwritten json: %.1f MB (budget %.0f MB, window %lld transcripts)\n", peak_pending / 1e6, pending_budget / 1e6, (long long)window);

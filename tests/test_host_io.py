@@ -328,3 +328,39 @@ def test_sharded_csv_writer_gives_the_bytes_of_one_writer(golden, tmp_path, cuts
         with pytest.raises(_io.M6AIOError):                      # a range outside the job
             _io._chk(_io.load().m6a_io_csv_shard_size(nat._h, None, None, None, 5, S + 1, 1, None, None))
         nat.close()
+
+
+def test_sharded_csv_writer_never_writes_stale_text(tmp_path):
+    """m6a_io_csv_shard_size keeps the text it formatted for the m6a_io_csv_shard_write that follows with the same range and
+    arrays.  The kept text belongs to the VALUES: other values at the same addresses (a caller's buffer reused, or temporaries
+    freed and reallocated between the two calls -- ADVICE r4) must be formatted again, not served from the cache."""
+    from m6anet_amd import _io
+    nat = _io.NativeSites([DATA], 20, data_utils.load_norm_factors("norm_hct116.npz"), 2)
+    S, R = nat.tx_pos.size, nat.X.shape[0]
+    g = np.random.Generator(np.random.PCG64(9))
+    rp, sp, mr = g.random(R, dtype=np.float32), g.random(S, dtype=np.float32), g.random(S)
+    head = nat.csv_header_bytes()
+
+    def files(d):
+        return [(d / fn).read_bytes() for fn in ("data.site_proba.csv", "data.indiv_proba.csv")]
+
+    for what in ("same", "site value", "one read in the middle", "last read", "list input"):
+        out, one = tmp_path / ("o_" + what.replace(" ", "_")), tmp_path / ("w_" + what.replace(" ", "_"))
+        out.mkdir()
+        one.mkdir()
+        args = (rp.tolist(), sp, mr) if what == "list input" else (rp, sp, mr)      # a list: converted to a temporary per call
+        sizes = nat.csv_shard_size(0, S, *args)
+        if what == "site value":
+            sp[S // 2] = np.float32(0.123456)
+        elif what == "one read in the middle":
+            rp[(R >> 1) & ~1023] = np.float32(0.5)               # an index the strided sample visits whatever the stride
+        elif what == "last read":
+            rp[R - 1] = np.float32(0.25)
+        args = (rp.tolist(), sp, mr) if what == "list input" else (rp, sp, mr)
+        nat.csv_shard_write(str(out), 0, S, *args, head[0], head[1], header_and_totals=(-1, -1))
+        nat.write_csv(str(one), rp, sp, mr, write_header=True)
+        got, want = files(out), files(one)
+        assert got == want, what
+        if what == "same":
+            assert (len(got[0]), len(got[1])) == (head[0] + sizes[0], head[1] + sizes[1])
+    nat.close()
