@@ -34,6 +34,7 @@ import numpy as np
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC for RCCL's P2P set-up (the boxes export it; kept for scrubbed environments)
 
 ENC_FLOP_PER_READ = 14164      # 2*(15*150 + 150*32 + 32)           SURVEY.md section 8(d)
 ENC_BYTES_PER_READ = 40        # 9 f32 in + 1 f32 out               SURVEY.md section 8(d)
@@ -96,7 +97,7 @@ def measured_traffic(S, bag):
     return best
 
 
-def live_traffic(workload, kernel_name, timeout_s=240):
+def live_traffic(workload, kernel_name, pool_kernel_name=None, timeout_s=240):
     """HBM bytes per encoder launch measured NOW: two short re-runs of this script under
     `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, --kernel-trace only, as
     MI355X_MICROARCH.md prescribes), read back from the rocpd database.  FETCH_SIZE x2: gfx950 tallies the 128-byte
@@ -107,7 +108,7 @@ def live_traffic(workload, kernel_name, timeout_s=240):
     import tempfile
     if shutil.which("rocprofv3") is None:
         return None
-    vals = {}
+    vals, pool_vals = {}, {}
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="m6a_pmc_")
         try:
@@ -120,17 +121,26 @@ def live_traffic(workload, kernel_name, timeout_s=240):
             con = sqlite3.connect(dbs[0])
             cols = [r[1] for r in con.execute("pragma table_info(counters_collection)")]
             kn = "kernel_name" if "kernel_name" in cols else "name"
-            row = con.execute("select avg(value), count(*) from counters_collection where counter_name = ? and %s like ?" % kn,
-                              (ctr, kernel_name + "%")).fetchone()
+            q = "select avg(value), count(*) from counters_collection where counter_name = ? and %s like ?" % kn
+            row = con.execute(q, (ctr, kernel_name + "%")).fetchone()
+            prow = con.execute(q, (ctr, pool_kernel_name + "%")).fetchone() if pool_kernel_name else None
             con.close()
             if not row or not row[1]:
                 return None
             vals[ctr] = float(row[0])
+            if prow and prow[1]:
+                pool_vals[ctr] = float(prow[0])
         except (subprocess.SubprocessError, OSError, sqlite3.Error):
             return None
         finally:
             shutil.rmtree(d, ignore_errors=True)
-    return {"traffic_bytes_per_launch": (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0,
+    pool = None
+    if len(pool_vals) == 2:
+        # the pooling kernel's reads are 80-byte bags at a 2.5 KB stride per lane, not wide streams: whether gfx950's x2 applies to
+        # them is not established, so both readings are given
+        pool = {"kernel": pool_kernel_name, "FETCH_SIZE_KiB": pool_vals["FETCH_SIZE"], "WRITE_SIZE_KiB": pool_vals["WRITE_SIZE"],
+                "fetch_bytes_as_counted": pool_vals["FETCH_SIZE"] * 1024.0, "fetch_bytes_with_gfx950_x2": 2048.0 * pool_vals["FETCH_SIZE"]}
+    return {"traffic_bytes_per_launch": (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, "pool": pool,
             "source": "measured by this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over 4 launches of %s "
                       "(FETCH_SIZE %.0f KiB x2 gfx950 correction + WRITE_SIZE %.0f KiB)" % (kernel_name, vals["FETCH_SIZE"], vals["WRITE_SIZE"])}
 
@@ -686,17 +696,17 @@ class Bench:
         enc_kernel = eng.last_encoder_kernel
         executed = ENC_MFMA_PER_TILE[enc_kernel] * 4096 // 32
         enc_tflops_executed = executed * R / (enc_avg_ms * 1e-3) / 1e12
+        pool_kernel = {"table-reg": "pool_reg_kernel", "table": "pool_table_kernel", "ragged-table": "pool_rtab_kernel"}.get(
+            eng.last_pool_variant, "pool_scan_kernels")
         tr = None
         if world == 1 and traffic:
             default_shape = S == spec["sites"] and T == 1000 and (self.workload == "ragged" or bag == spec["bag"])
             if default_shape and not args.no_live_traffic:
-                tr = live_traffic(self.workload, enc_kernel)
+                tr = live_traffic(self.workload, enc_kernel, pool_kernel)
             if tr is None:
                 tr = measured_traffic(S, bag)
                 if tr is not None:
                     tr = dict(tr, source="%s (%s) -- committed, not measured by this run" % (tr["file"], tr["source"]))
-        pool_kernel = {"table-reg": "pool_reg_kernel", "table": "pool_table_kernel", "ragged-table": "pool_rtab_kernel"}.get(
-            eng.last_pool_variant, "pool_scan_kernels")
         proof = pool_roofline(eng.last_pool_variant, draws, pool_avg_ms, r["pool_n"])
         # the pooling kernels are priced against what the part DELIVERS for their instruction mix, measured by this run with the
         # microbenchmark of their inner loop: `peak` / `frac` are that; the nominal figure stays beside it
@@ -711,6 +721,9 @@ class Bench:
         # `peak` / `frac` are ALWAYS the nominal figure (comparable across rounds); what the part delivers for the kernel's
         # instruction mix, measured by this run, sits beside them
         proof["peak_source"] = "nominal"
+        if tr and tr.get("pool"):
+            # HBM reads of the pooling kernel from the same PMC passes, next to the read probabilities it needs (4 B per read)
+            proof["traffic"] = dict(tr["pool"], algorithmic_read_bytes=4 * R)
         if m is not None:
             proof["measured_ceiling"] = dict({"peak": m["rate"] / 1e12, "unit": "T draws/s", "frac": proof["achieved"] * 1e12 / m["rate"],
                                               "source": m["source"]}, **detail)
@@ -944,12 +957,15 @@ def run(args, line, rank, world, local_rank, S, bag, T):
             b.eng.set_encoder_variant(1)
             for _ in range(3):
                 b.compute()
-            torch.cuda.synchronize(dev)
-            t0 = time.perf_counter()
-            for _ in range(10):
-                b.compute()
-            torch.cuda.synchronize(dev)
-            ms = (time.perf_counter() - t0) / 10 * 1e3
+            legs = []
+            for _ in range(3):                            # three legs of 10 steps, the median reported: a 27 ms region is one hiccup away from +4 %
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                for _ in range(10):
+                    b.compute()
+                torch.cuda.synchronize(dev)
+                legs.append((time.perf_counter() - t0) / 10 * 1e3)
+            ms = sorted(legs)[1]
             b.eng.profile("encoder")
             for _ in range(10):
                 b.compute()
@@ -961,6 +977,7 @@ def run(args, line, rank, world, local_rank, S, bag, T):
             tf, tfx = (f * b.R / (k_avg * 1e-3) / 1e12 for f in (ENC_FLOP_PER_READ, ex))
             line["reference_order_encoder"] = {
                 "encoder_kernel": b.eng.last_encoder_variant, "kernel": kern, "ms_per_step": ms, "value": b.Sr / (ms * 1e-3), "steps": 10, "warmup": 3,
+                "ms_per_step_of_each_leg": legs,
                 "note": "same workload, m6a_set_encoder_variant(1): every float32 operation of the reference's encoder in the "
                         "reference's order (DESIGN.md section 2) -- read and site probabilities bit-identical to the reference's on "
                         "this workload's bags; the headline above runs the 12-slot kernel (within 1e-5 relative)"}

@@ -815,12 +815,13 @@ int launch_pool(m6a_ctx *c, const float *rp, const int64_t *off, int64_t S, int 
         if (dry) return M6A_OK;
         c->pool_variant = "table-reg";
         prof_begin(c, 1);
-        // one wavefront = position j of 256 flush groups (4 sites per lane); blockIdx % jmax = j keeps a
-        // position's index rows in one XCD's L2
+        // one wavefront = position j of 256 flush groups (4 sites per lane); the grid is 8 x ceil(items / 8) so that every
+        // XCD takes a contiguous run of items (m6a_pool_reg.hip: the waves that share cache lines of read_prob share an L2)
         const int64_t wpj = (a.n_groups + 255) / 256;
+        a.reg_items = wpj * a.jmax;
         a.reg_site = (float *)c->reg_out.p;
         a.reg_cnt = (uint8_t *)c->reg_out.p + (size_t)a.jmax * a.reg_gpad * 4;
-        hipLaunchKernelGGL(pool_reg_kernel, dim3((unsigned)(wpj * a.jmax)), dim3(64), 0, c->stream, a);
+        hipLaunchKernelGGL(pool_reg_kernel, dim3((unsigned)((a.reg_items + 7) / 8 * 8)), dim3(64), 0, c->stream, a);
         hipLaunchKernelGGL(pool_reg_finish_kernel, dim3((unsigned)((a.n_groups + 31) / 32), (unsigned)((a.jmax + 31) / 32)), dim3(256), 0, c->stream, a);
         prof_end(c, 1);
     } else if (uniform && c->plan.max_merge <= 15) {

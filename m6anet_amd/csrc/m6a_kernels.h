@@ -66,6 +66,7 @@ struct PoolArgs {
     float *reg_site;              // [jmax][reg_gpad] site probability
     uint8_t *reg_cnt;             // [jmax][reg_gpad] reads with p >= thr
     int64_t reg_gpad;
+    int64_t reg_items;            // pool_reg_kernel's work items: ceil(n_groups / 256) * jmax
     int *err;
     int64_t n_groups, n_sites, raw_len;
     int T, K, uniform_n, jmax, bag_cap;

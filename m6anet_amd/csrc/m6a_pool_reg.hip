@@ -111,8 +111,17 @@
 __global__ __launch_bounds__(64) void pool_reg_kernel(PoolArgs a)
 {
     const int lane = threadIdx.x;
-    const int j = (int)(blockIdx.x % (unsigned)a.jmax);
-    const int64_t g0 = (int64_t)(blockIdx.x / (unsigned)a.jmax) * 256;
+    // Work item = (block of 256 flush groups, position j), items numbered with j fastest.  Workgroups go to the 8 XCDs
+    // round-robin (blockIdx % 8) and every XCD has its own L2, so XCD x takes the CONTIGUOUS items [x * per, (x + 1) * per) in
+    // dispatch order: the jmax waves that read the same 256 bags' worth of read_prob -- bag j and bag j+1 of a group share a
+    // 128-byte line (80-byte bags) -- run in one XCD at the same time, and the line is fetched from HBM once.  With
+    // item = blockIdx (j = blockIdx % jmax, round 4) the two waves sharing a line always sat in different XCDs: FETCH_SIZE
+    // 152 MB per launch for 80 MB of read probabilities (profiles/r04_kernel_trace_and_pmc.txt).
+    const unsigned per = gridDim.x >> 3;                                   // the host launches 8 * per workgroups
+    const unsigned item = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+    if (item >= (unsigned)a.reg_items) return;
+    const int j = (int)(item % (unsigned)a.jmax);
+    const int64_t g0 = (int64_t)(item / (unsigned)a.jmax) * 256;
     int64_t site[4];
     uint32_t boff[4];
 #pragma unroll

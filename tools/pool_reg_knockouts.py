@@ -50,18 +50,18 @@ def vprefetch(look):
 
 
 def stamps(s):
-    """s_memtime at wave start, after the prologue and at the end, delivered through the four site results of lane 0..63:
-    q0 = prologue cycles, q1 = loop cycles, q2 = start (low 24 bits, in 256-cycle units), q3 = end (same units)."""
-    s = s.replace('"v_mov_b32 v32, %[b0]\\n"', '"s_memtime s[86:87]\\n"\n        "v_mov_b32 v32, %[b0]\\n"', 1)
+    """Per wave, delivered through the four site results of lanes 0..63: q0 = prologue ticks and q1 = loop ticks (s_memtime: the
+    shader clock, whose base differs from one part of the chip to the next -- good for durations only), q2 = start and q3 = end on
+    s_memrealtime (the 100 MHz constant clock, one base for the whole device; low 24 bits)."""
+    s = s.replace('"v_mov_b32 v32, %[b0]\\n"', '"s_memtime s[86:87]\\n"\n        "s_memrealtime s[94:95]\\n"\n        "v_mov_b32 v32, %[b0]\\n"', 1)
     s = s.replace('"82:\\n"', '"82:\\n"\n        "s_waitcnt lgkmcnt(0)\\n"\n        "s_memtime s[88:89]\\n"', 1)
     s = s.replace('"v_mov_b32 %[o0], v60\\n"\n        "v_mov_b32 %[o1], v61\\n"\n        "v_mov_b32 %[o2], v62\\n"\n        "v_mov_b32 %[o3], v63\\n"',
-                  '"s_memtime s[90:91]\\n"\n        "s_waitcnt lgkmcnt(0)\\n"\n'
+                  '"s_memtime s[90:91]\\n"\n        "s_memrealtime s[96:97]\\n"\n        "s_waitcnt lgkmcnt(0)\\n"\n'
                   '        "s_sub_u32 s92, s88, s86\\n"\n        "s_sub_u32 s93, s90, s88\\n"\n'
-                  '        "s_lshr_b64 s[86:87], s[86:87], 8\\n"\n        "s_and_b32 s86, s86, 0xffffff\\n"\n'
-                  '        "s_lshr_b64 s[90:91], s[90:91], 8\\n"\n        "s_and_b32 s90, s90, 0xffffff\\n"\n'
-                  '        "v_cvt_f32_u32 %[o0], s92\\n"\n        "v_cvt_f32_u32 %[o1], s93\\n"\n        "v_cvt_f32_u32 %[o2], s86\\n"\n        "v_cvt_f32_u32 %[o3], s90\\n"', 1)
-    s = s.replace('"s84", "s85",', '"s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93",', 1)
-    assert "s_memtime s[90:91]" in s and "s_memtime s[88:89]" in s and "s_memtime s[86:87]" in s and '"s93",' in s
+                  '        "s_and_b32 s94, s94, 0xffffff\\n"\n        "s_and_b32 s96, s96, 0xffffff\\n"\n'
+                  '        "v_cvt_f32_u32 %[o0], s92\\n"\n        "v_cvt_f32_u32 %[o1], s93\\n"\n        "v_cvt_f32_u32 %[o2], s94\\n"\n        "v_cvt_f32_u32 %[o3], s96\\n"', 1)
+    s = s.replace('"s84", "s85",', '"s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97",', 1)
+    assert "s_memtime s[90:91]" in s and "s_memtime s[88:89]" in s and "s_memrealtime s[96:97]" in s and '"s97",' in s
     return s
 
 
@@ -155,19 +155,45 @@ def read_stamps():
         for _ in range(3):
             site, _ = eng.calculate_site_proba(p, off, T)
         eng.sync()
-        v = site.cpu().numpy().astype(np.float64) * T                 # the kernel divides by T
-        G = S // 32
-        v = v[:G * 32].reshape(G, 32)                                  # [group][position j]
+        v = np.rint(site.cpu().numpy().astype(np.float64) * T)         # the kernel divides by T
+        # flush groups: the first has batch_size = 16 sites, the others 32 (m6anet's inverted flush test): site s of
+        # group g at position j
+        G = 1 + (S - 16 + 31) // 32
+        full = np.full((G, 32), np.nan)
+        full[0, :16] = v[:16]
+        rest = v[16:]
+        full[1:1 + rest.size // 32] = rest[:rest.size // 32 * 32].reshape(-1, 32)
+        v = full
         # lane = group (g0 + q*64 + lane): q = (group % 256) // 64
         q = (np.arange(G) % 256) // 64
+        v = np.where(np.isnan(v), np.nanmedian(v, axis=1, keepdims=True), v)
         pro, loop = v[q == 0].ravel(), v[q == 1].ravel()
-        start, end = v[q == 2].ravel() * 256.0, v[q == 3].ravel() * 256.0
+        # start / end are 24-bit counters in units of 256 ticks: they wrap, so everything is taken relative to one wave's
+        # start on the circle (a kernel lasts < 2^23 units)
+        ref = v[q == 2].ravel()[0]
+
+        def rel(x):
+            return (((x - ref) + (1 << 23)) % (1 << 24) - (1 << 23)) * 10.0          # ns
+        # one value per WAVE: lane 0 of class 2 / 3 of every (256-group block, j)
+        gb = np.arange(G) // 256
+        first2 = np.array([np.flatnonzero((gb == b) & (q == 2))[0] for b in range(gb.max() + 1) if ((gb == b) & (q == 2)).any()])
+        first3 = np.array([np.flatnonzero((gb == b) & (q == 3))[0] for b in range(gb.max() + 1) if ((gb == b) & (q == 3)).any()])
+        start, end = rel(v[first2].ravel()), rel(v[first3].ravel())
         t0 = start.min()
+        start, end = start - t0, end - t0
+        cl = np.zeros(start.size, int)
+        np.savez(os.path.join(REPO, "gpurun_out", "pool_reg_stamps_%d.npz" % S), start=start, end=end, cluster=cl,
+                 prologue=v[np.array([np.flatnonzero((gb == b) & (q == 0))[0] for b in range(gb.max() + 1) if ((gb == b) & (q == 0)).any()])].ravel(),
+                 loop=v[np.array([np.flatnonzero((gb == b) & (q == 1))[0] for b in range(gb.max() + 1) if ((gb == b) & (q == 1)).any()])].ravel())
+        order = np.sort(start)
         out[S] = {"waves": 32 * ((G + 255) // 256),
-                  "prologue_cycles": {"median": float(np.median(pro)), "p95": float(np.quantile(pro, 0.95)), "max": float(pro.max())},
-                  "loop_cycles": {"median": float(np.median(loop)), "p5": float(np.quantile(loop, 0.05)), "p95": float(np.quantile(loop, 0.95))},
-                  "wave_start_cycles_after_first": {"median": float(np.median(start - t0)), "p95": float(np.quantile(start - t0, 0.95)), "max": float((start - t0).max())},
-                  "kernel_span_cycles": float(end.max() - t0)}
+                  "prologue_ticks": {"median": float(np.median(pro)), "p95": float(np.quantile(pro, 0.95)), "max": float(pro.max())},
+                  "loop_ticks": {"median": float(np.median(loop)), "p5": float(np.quantile(loop, 0.05)), "p95": float(np.quantile(loop, 0.95))},
+                  # when the k-th wave (in start order) began, ticks after the first: how long the dispatcher takes to fill the machine
+                  "start_of_wave_k_after_first": {str(k): float(order[min(k, order.size - 1)]) for k in (1, 256, 1024, 2000, 2047, 2048, 2100, 3000, order.size - 1)},
+                  "end_quantiles": {str(qq): float(np.quantile(end, qq)) for qq in (0.0, 0.25, 0.5, 0.52, 0.75, 0.9, 0.96, 1.0)},
+                  "first_end": float(end.min()), "median_end": float(np.median(end)), "last_end": float(end.max()),
+                  "waves_ending_in_last_10pct_of_span": int((end > 0.9 * end.max()).sum())}
         print(S, out[S], file=sys.stderr)
     print(json.dumps(out, indent=1))
 
