@@ -49,6 +49,16 @@ void release_staging(m6a_ctx *c)
     g = Staging();
 }
 
+// Caller memory the DMA engines can address directly: page-locked by hipHostMalloc / hipHostRegister (torch's pin_memory()).
+// Such buffers skip the staging copy in both directions -- the chunks are still cut and overlapped the same way.
+bool is_pinned_host(const void *p)
+{
+    if (!p) return false;
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return at.type == hipMemoryTypeHost;
+}
+
 // Encodes a job whose X / site_kmers / off live in HOST memory: the job is cut at site boundaries into chunks of
 // <= chunk_reads reads; chunk k is copied by the host threads into a pinned slot, DMA'd on its own stream and
 // encoded on the context's stream while chunk k+1 is being copied; read probabilities flow back the same way
@@ -78,6 +88,9 @@ int staged_encode(m6a_ctx *c, const float *X, const uint8_t *km, const int64_t *
         return M6A_OK;
     }
     const size_t slot_bytes = (size_t)g.chunk_reads * 9 * 4;
+    // pinned caller buffers (the first and the last byte are looked up: one allocation) go straight onto the link
+    const bool x_pinned = is_pinned_host(X) && is_pinned_host((const char *)(X + R * 9) - 1);
+    const bool rp_pinned = rp_host && is_pinned_host(rp_host) && is_pinned_host((const char *)(rp_host + R) - 1);
     // ring item 0: the CSR offsets and the k-mer ids, through a pinned slot like everything else
     const size_t off_bytes = (size_t)(S + 1) * 8, km_bytes = (size_t)S * 3;
     int item = 0;
@@ -118,11 +131,12 @@ int staged_encode(m6a_ctx *c, const float *X, const uint8_t *km, const int64_t *
         const int64_t s0 = cs[k], s1 = cs[k + 1], r0 = off[s0], nr = off[s1] - r0;
         if (nr == 0) continue;
         if (item >= kStageSlots) {
-            HIPCHK(c, hipEventSynchronize(g.ev_h2d[slot]));            // the slot's previous DMA has left it
+            if (!x_pinned) HIPCHK(c, hipEventSynchronize(g.ev_h2d[slot]));   // the slot's previous DMA has left it
             if (k >= kStageSlots) { rc = drain_out(k - kStageSlots); if (rc) return rc; }
         }
-        g.pool->copy(g.pin_in[slot], X + r0 * 9, (size_t)nr * 9 * 4);
-        HIPCHK(c, hipMemcpyAsync((float *)c->sX.p + r0 * 9, g.pin_in[slot], (size_t)nr * 9 * 4, hipMemcpyHostToDevice, g.s_h2d));
+        const float *src = X + r0 * 9;
+        if (!x_pinned) { g.pool->copy(g.pin_in[slot], src, (size_t)nr * 9 * 4); src = (const float *)g.pin_in[slot]; }
+        HIPCHK(c, hipMemcpyAsync((float *)c->sX.p + r0 * 9, src, (size_t)nr * 9 * 4, hipMemcpyHostToDevice, g.s_h2d));
         HIPCHK(c, hipEventRecord(g.ev_h2d[slot], g.s_h2d));
         HIPCHK(c, hipStreamWaitEvent(c->stream, g.ev_h2d[slot], 0));
         // the encoder wants offsets that start at 0: the chunk's own CSR row
@@ -134,12 +148,16 @@ int staged_encode(m6a_ctx *c, const float *X, const uint8_t *km, const int64_t *
         if (rp_host) {
             HIPCHK(c, hipEventRecord(g.ev_enc[slot], c->stream));
             HIPCHK(c, hipStreamWaitEvent(g.s_d2h, g.ev_enc[slot], 0));
-            HIPCHK(c, hipMemcpyAsync(g.pin_out[slot], (const float *)c->sP.p + r0, (size_t)nr * 4, hipMemcpyDeviceToHost, g.s_d2h));
+            HIPCHK(c, hipMemcpyAsync(rp_pinned ? rp_host + r0 : (float *)g.pin_out[slot], (const float *)c->sP.p + r0, (size_t)nr * 4,
+                                     hipMemcpyDeviceToHost, g.s_d2h));
             HIPCHK(c, hipEventRecord(g.ev_d2h[slot], g.s_d2h));
-            out_pending[(size_t)k] = 1;
+            out_pending[(size_t)k] = rp_pinned ? 0 : 1;
         }
     }
     for (int64_t k = 0; k < nchunk; k++) { rc = drain_out(k); if (rc) return rc; }
+    if (rp_pinned) HIPCHK(c, hipStreamSynchronize(g.s_d2h));         // the contract: the read probabilities are in rp_host on return
+    // the caller may reuse X as soon as the call returns: its last chunk must have left it
+    if (x_pinned) HIPCHK(c, hipStreamSynchronize(g.s_h2d));
     return M6A_OK;
 }
 
@@ -149,7 +167,8 @@ int staged_outputs(m6a_ctx *c, int64_t S, float *site, double *mod)
 {
     Staging &g = c->stg;
     const size_t slot_bytes = g.ready ? (size_t)g.chunk_reads * 9 * 4 : 0;
-    if ((size_t)S * 8 > slot_bytes) {
+    const bool direct = is_pinned_host(site) && is_pinned_host(mod);
+    if (direct || (size_t)S * 8 > slot_bytes) {
         HIPCHK(c, hipMemcpyAsync(site, c->sSite.p, (size_t)S * 4, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipMemcpyAsync(mod, c->sMod.p, (size_t)S * 8, hipMemcpyDeviceToHost, c->stream));
         return sync_and_check(c);

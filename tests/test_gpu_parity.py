@@ -873,6 +873,37 @@ def test_host_pointer_pipeline_matches_device_path(engines, orc, weights):
     assert np.allclose(rp2[sl], p, rtol=1e-5, atol=1e-8)
 
 
+def test_pinned_host_buffers_skip_the_staging_copy_same_bits(engines):
+    """Caller buffers that are already page-locked (hipHostMalloc / torch's pin_memory()) are DMA'd chunk by chunk straight
+    from / into the caller's memory (m6a_host_ring.hip is_pinned_host): same chunks, same kernels, same bits as the pageable
+    path and the device path -- inputs pinned, outputs pinned, both, and the encoder-only entry point."""
+    import torch
+    eng = engines["hek293t_glori"]
+    eng.prepare_host_io()
+    d = synthetic.make_sites(60_000, (20, 90), seed=12)            # 119 MB of X: 5 chunks
+    R, S = int(d["off"][-1]), 60_000
+    want = eng.infer(d["X"], d["site_kmers"], d["off"], 50)        # pageable path (pinned against the device path above)
+    pin = tuple(torch.from_numpy(d[k]).pin_memory() for k in ("X", "site_kmers", "off"))
+
+    def pinned_outs():
+        return (torch.full((R,), -1.0, dtype=torch.float32).pin_memory(), torch.full((S,), -1.0, dtype=torch.float32).pin_memory(),
+                torch.full((S,), -1.0, dtype=torch.float64).pin_memory())
+    for ins, outs in ((pin, None), ((d["X"], d["site_kmers"], d["off"]), pinned_outs()), (pin, pinned_outs())):
+        got = eng.infer(*ins, 50, out=outs)
+        for g, w in zip(got, want):
+            g = g.numpy() if hasattr(g, "numpy") and not isinstance(g, np.ndarray) else g
+            assert np.array_equal(g, w)
+    rp = torch.empty(R, dtype=torch.float32).pin_memory()
+    eng.get_read_probability(*pin, out=rp)
+    assert np.array_equal(rp.numpy(), want[0])
+    # a pinned array that is reused right after the call returns: the call must have finished reading it
+    Xp = pin[0].clone().pin_memory()
+    got = eng.infer(Xp, pin[1], pin[2], 50)
+    Xp.zero_()
+    eng.sync()
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+
+
 def test_infer_equals_encode_then_pool_for_every_pooling_kernel(engines):
     """m6a_infer sets the pooling up on a side stream while the encoder runs (a dry launch_pool); whatever kernel the
     pooling takes -- forced scan drivers, index tables, both uniform-bag kernels -- the fused call must give what

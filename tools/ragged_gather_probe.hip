@@ -3,6 +3,9 @@
 //   2. ds_read_b32 gathers at random indices of an n-entry bag, n = 20..1000: LDS cycles per wave-gather
 //      (bank conflicts of random addresses), 8 waves per SIMD.
 //   3. ds_bpermute_b32 rate (a conflict-free crossbar gather for bags <= 64).
+//   4. (round 5) the bag stored TWICE, the copy picked by lane parity: copy B rotated by 16 banks
+//      (MODE 2) or by 0 banks at +64 dwords (MODE 3), and the pair layout read with ds_read_b64 + select (MODE 4: entries
+//      i and i + 32 side by side, so any bag <= 64 touches each bank pair once).  Do any of them beat one copy for 32 < n <= 64?
 // build: hipcc --offload-arch=gfx950 -O3 ragged_gather_probe.hip -o rg_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -33,7 +36,11 @@ __global__ __launch_bounds__(256) void gather_kernel(const uint32_t *idx, float 
     for (int i = lane; i < 1024; i += 64) bag[i] = 1.0f + 1e-7f * i;
     uint32_t o[20];
 #pragma unroll
-    for (int i = 0; i < 20; i++) o[i] = idx[(blockIdx.x * 256 + threadIdx.x) * 20 + i] % (uint32_t)n;
+    for (int i = 0; i < 20; i++) {
+        o[i] = idx[(blockIdx.x * 256 + threadIdx.x) * 20 + i] % (uint32_t)n;
+        if (MODE == 2) o[i] = (lane & 1) ? 64 + ((o[i] + 16) & 63) : o[i];      // copy B at +64 dwords, rotated by 16 banks
+        if (MODE == 3) o[i] = (lane & 1) ? 64 + o[i] : o[i];                    // copy B at +64 dwords, same banks
+    }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     float acc = 1.0f;
     const float mine = bag[lane];
@@ -42,8 +49,11 @@ __global__ __launch_bounds__(256) void gather_kernel(const uint32_t *idx, float 
 #pragma unroll
         for (int i = 0; i < 20; i++) {
             asm volatile("" : "+v"(o[i]));
-            if (MODE == 0) g[i] = bag[o[i]];
-            else g[i] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((int)(o[i] << 2), __builtin_bit_cast(int, mine)));
+            if (MODE == 0 || MODE == 2 || MODE == 3) g[i] = bag[o[i]];
+            else if (MODE == 4) {                                               // pair (i % 32) holds entries i % 32 and i % 32 + 32
+                const float2 pr = *(const float2 *)(bag + 2 * (o[i] & 31));
+                g[i] = (o[i] & 32) ? pr.y : pr.x;
+            } else g[i] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((int)(o[i] << 2), __builtin_bit_cast(int, mine)));
         }
 #pragma unroll
         for (int i = 0; i < 20; i++) acc *= g[i];
@@ -86,12 +96,17 @@ int main()
     hipEvent_t a, b;
     CHK(hipEventCreate(&a)); CHK(hipEventCreate(&b));
     const int iters = 1000;
-    for (int mode = 0; mode < 2; mode++)
+    const bool extra = getenv("RG_PROBE_COPIES") != nullptr;       // bench.py runs the probe for modes 0 / 1 only
+    static const char *names[] = {"ds_read_b32   ", "ds_bpermute_b32", "2 copies, B rotated 16 banks", "2 copies, same banks", "pairs, ds_read_b64 + select"};
+    for (int mode = 0; mode < (extra ? 5 : 2); mode++)
         for (int n : {20, 32, 40, 50, 64, 100, 128, 200, 275, 400, 500, 1000}) {
-            if (mode == 1 && n > 64) continue;
+            if (mode >= 1 && n > 64) continue;
             auto launch = [&](int it) {
                 if (mode == 0) hipLaunchKernelGGL(gather_kernel<0>, dim3(blocks), dim3(256), 0, 0, d_idx, d_out, it, n);
-                else hipLaunchKernelGGL(gather_kernel<1>, dim3(blocks), dim3(256), 0, 0, d_idx, d_out, it, n);
+                else if (mode == 1) hipLaunchKernelGGL(gather_kernel<1>, dim3(blocks), dim3(256), 0, 0, d_idx, d_out, it, n);
+                else if (mode == 2) hipLaunchKernelGGL(gather_kernel<2>, dim3(blocks), dim3(256), 0, 0, d_idx, d_out, it, n);
+                else if (mode == 3) hipLaunchKernelGGL(gather_kernel<3>, dim3(blocks), dim3(256), 0, 0, d_idx, d_out, it, n);
+                else hipLaunchKernelGGL(gather_kernel<4>, dim3(blocks), dim3(256), 0, 0, d_idx, d_out, it, n);
             };
             launch(10);
             CHK(hipDeviceSynchronize());
@@ -104,7 +119,7 @@ int main()
             const double wave_gathers = (double)blocks * 4 * iters * 20;
             const double clk = ms * 1e-3 * 2.4e9 * 256.0 / wave_gathers;
             printf("%s n=%4d  %.3f ms  %.2f clk per wave-gather per CU (at 2.4 GHz)  %.2f T gathers/s\n",
-                   mode ? "ds_bpermute_b32" : "ds_read_b32   ", n, ms, clk, wave_gathers * 64 / (ms * 1e-3) / 1e12);
+                   names[mode], n, ms, clk, wave_gathers * 64 / (ms * 1e-3) / 1e12);
         }
     return 0;
 }
