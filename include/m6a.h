@@ -248,13 +248,18 @@ int m6a_random_stream(m6a_ctx *ctx, uint32_t seed, int64_t n_words, uint32_t *wo
  * timed launch cost ~5 us each on the stream).  m6a_profile_read synchronises the stream. */
 int m6a_profile_enable(m6a_ctx *ctx, int on);
 int m6a_profile_read(m6a_ctx *ctx, int kind, double *total_ms, int64_t *n_launches);
-/* Tuning knob for the read encoder: 0 = auto (default), 1 = general kernel (16 K-slots, any bags),
- * 2 = 12-slot kernel (per-site constants folded; requires every bag >= 16 reads -- a call that
- * violates this reports M6A_EINVAL at the next sync).  Results agree to float32 rounding: the general kernel performs the
- * reference's float32 operations in the reference's order all the way (its read probabilities are those of torch on an
- * AVX-512 host, bit for bit, for every read of a 20-read-bag job); the 12-slot kernel, 10 % faster, adds a site's six
- * embedding terms and b1 pre-summed and sums the 32 -> 1 layer in register order.  The environment variable
- * M6A_ENCODER=general16|csite12 preselects 1 / 2 in every context the process creates. */
+/* Tuning knob for the read encoder: 0 = auto (default), 1 = the 16-slot kernels (any bags), 2 = 12-slot kernel (per-site
+ * constants folded; requires every bag >= 16 reads -- a call that violates this reports M6A_EINVAL at the next sync), 3 = the
+ * 16-slot arithmetic behind the per-lane walk of off[] even where the scalar site chain would do (A/B and tests).  Results agree
+ * to float32 rounding: the 16-slot kernels perform the reference's float32 operations in the reference's order all the way (their
+ * read probabilities are those of torch on an AVX-512 host, bit for bit, for every read of a 20-read-bag job); the 12-slot kernel
+ * adds a site's six embedding terms and b1 pre-summed and sums the 32 -> 1 layer in register order.
+ * Why auto is still the 12-slot kernel for bags >= 16 reads: it issues 106 MFMAs per 32-read tile against
+ * 116, and both kernels now sit at the same 0.83-0.85 of the matrix peak in executed work, so the gap IS the instruction count --
+ * 2.07 vs 2.22-2.26 ms per 20 M reads, 2.49 vs 2.63-2.70 ms per step (profiles/r05_step_by_encoder.json): 5.5-8 % per step, outside
+ * the 6 % within which one default would have been the better trade.  Callers that want the reference's bits say so: mode 1, the
+ * CLI's --encoder reference (its default), or the environment variable M6A_ENCODER=general16|csite12|walk16, which preselects
+ * 1 / 2 / 3 in every context the process creates. */
 int m6a_set_encoder_variant(m6a_ctx *ctx, int mode);
 const char *m6a_last_encoder_variant(const m6a_ctx *ctx);   /* "general16" | "csite12" */
 /* The __global__ function the last encode launched: "enc_site16_kernel" (16 slots, scalar 32-bit site chain: every bag

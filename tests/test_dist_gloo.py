@@ -64,6 +64,14 @@ def test_two_rank_shards_equal_the_whole_job(tmp_path, bag, n_sites):
     assert ok == 1 and n == n_sites and 0 < cut < n_sites
 
 
+def test_eight_rank_shards_equal_the_whole_job(tmp_path):
+    """The size of the node the driver runs: eight gloo ranks, ragged bags, a site count that leaves the shards unequal."""
+    out = str(tmp_path / "res8.npy")
+    mp.spawn(_worker, args=(8, _free_port(), (20, 120), 4003, out), nprocs=8, join=True)
+    ok, n, cut = np.load(out)
+    assert ok == 1 and n == 4003 and 0 < cut < 4003
+
+
 def test_site_gather_single_rank_odd_count():
     """world = 1 with an odd site count: the float64 view of the packed buffer must stay aligned."""
     import torch

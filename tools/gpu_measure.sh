@@ -12,25 +12,30 @@ python bench.py --min-seconds 10 --no-cpu-baseline --no-live-traffic --no-ragged
 python bench.py --workload ragged --min-seconds 10 --no-cpu-baseline --no-live-traffic > $O/${T}_bench_ragged_sustained.json 2>> $O/${T}_sustained.err
 # kernel trace + PMC passes (counters in their own runs, --kernel-trace only)
 CMD="python bench.py --min-seconds 0 --no-cpu-baseline --no-live-traffic --no-ragged-extra"
-rocprofv3 --kernel-trace --stats -d $O/${T}_trace -o bench -- $CMD > $O/${T}_trace.json 2> $O/${T}_trace.err
+timeout 600 rocprofv3 --kernel-trace --stats -d $O/${T}_trace -o bench -- $CMD > $O/${T}_trace.json 2> $O/${T}_trace.err
 SHORT="python bench.py --min-seconds 0 --steps 6 --warmup 2 --no-cpu-baseline --no-live-traffic --no-ragged-extra"
-rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/${T}_pmc_fetch -o pmc -- $SHORT > /dev/null 2> $O/${T}_pmc_fetch.err
-rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/${T}_pmc_write -o pmc -- $SHORT > /dev/null 2> $O/${T}_pmc_write.err
-rocprofv3 --pmc SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT --kernel-trace -d $O/${T}_pmc_sq -o pmc -- $SHORT > /dev/null 2> $O/${T}_pmc_sq.err
+timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/${T}_pmc_fetch -o pmc -- $SHORT > /dev/null 2> $O/${T}_pmc_fetch.err
+timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/${T}_pmc_write -o pmc -- $SHORT > /dev/null 2> $O/${T}_pmc_write.err
+timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT --kernel-trace -d $O/${T}_pmc_sq -o pmc -- $SHORT > /dev/null 2> $O/${T}_pmc_sq.err
+# the product's default encoder (16 slots, the reference's order): the same trace with it selected
+M6A_ENCODER=general16 timeout 600 rocprofv3 --kernel-trace --stats -d $O/${T}_trace_general16 -o bench -- $CMD > $O/${T}_trace_general16.json 2> $O/${T}_trace_general16.err
 RCMD="python bench.py --workload ragged --min-seconds 0 --no-cpu-baseline --no-live-traffic"
-rocprofv3 --kernel-trace --stats -d $O/${T}_trace_ragged -o bench -- $RCMD > $O/${T}_trace_ragged.json 2> $O/${T}_trace_ragged.err
+timeout 600 rocprofv3 --kernel-trace --stats -d $O/${T}_trace_ragged -o bench -- $RCMD > $O/${T}_trace_ragged.json 2> $O/${T}_trace_ragged.err
 RSHORT="python bench.py --workload ragged --min-seconds 0 --steps 6 --warmup 2 --no-cpu-baseline --no-live-traffic"
-rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/${T}_pmc_fetch_ragged -o pmc -- $RSHORT > /dev/null 2> $O/${T}_pmc_fetch_ragged.err
-rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/${T}_pmc_write_ragged -o pmc -- $RSHORT > /dev/null 2> $O/${T}_pmc_write_ragged.err
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_SALU SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU --kernel-trace -d $O/${T}_pmc_sq_ragged -o pmc -- $RSHORT > /dev/null 2> $O/${T}_pmc_sq_ragged.err
+timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/${T}_pmc_fetch_ragged -o pmc -- $RSHORT > /dev/null 2> $O/${T}_pmc_fetch_ragged.err
+timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/${T}_pmc_write_ragged -o pmc -- $RSHORT > /dev/null 2> $O/${T}_pmc_write_ragged.err
+timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_SALU SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU --kernel-trace -d $O/${T}_pmc_sq_ragged -o pmc -- $RSHORT > /dev/null 2> $O/${T}_pmc_sq_ragged.err
 for f in $(find $O -name "*_results.db" -path "*${T}_*" | sort); do python tools/rocpd_summary.py $f; done > $O/${T}_summary.txt 2>&1
 # the first call, as a timeline (HIP API + kernels) and by phase
-rocprofv3 --hip-trace --kernel-trace --memory-copy-trace --output-format csv -d $O/${T}_tl -o tl -- python bench.py --steps 2 --warmup 1 --min-seconds 0 --no-cpu-baseline --no-live-traffic --no-ragged-extra > /dev/null 2> $O/${T}_tl.err
+timeout 600 rocprofv3 --hip-trace --kernel-trace --memory-copy-trace --output-format csv -d $O/${T}_tl -o tl -- python bench.py --steps 2 --warmup 1 --min-seconds 0 --no-cpu-baseline --no-live-traffic --no-ragged-extra > /dev/null 2> $O/${T}_tl.err
 python tools/first_call_timeline.py $O/${T}_tl > $O/${T}_first_call_timeline.txt 2>&1
 python tools/first_call_probe.py > $O/${T}_first_call.json 2> $O/${T}_first_call.err
 # microbenchmarks behind the ceilings, the stream generator, the feed API from plain C
 ./tools/valu_rate_bench > $O/${T}_valu_rate.json 2>&1
-./tools/rg_probe > $O/${T}_rg_probe.txt 2>&1
+RG_PROBE_COPIES=1 ./tools/rg_probe > $O/${T}_rg_probe.txt 2>&1
+python tools/h2d_probe.py 8 > $O/${T}_h2d_probe.json 2> $O/${T}_h2d_probe.err
+python tools/step_ab.py 20 3 > $O/${T}_step_by_encoder.json 2>> $O/${T}_h2d_probe.err
+python tools/time_encoder.py > $O/${T}_encoder_kernels.txt 2>&1
 python tools/stream_probe.py > $O/${T}_stream.json 2> $O/${T}_stream.err
 { ./tools/feed_probe 20000 16; ./tools/feed_probe 20000 1024; ./tools/feed_probe 1000000 16 20 20; ./tools/feed_probe 1000000 4096 20 20; } > $O/${T}_feed_probe.json 2>&1
 python tools/measure_misc.py > $O/${T}_misc.json 2> $O/${T}_misc.err

@@ -9,7 +9,9 @@ measure_io.replicate(1400, d)
 store = os.path.join(d, "data.m6astore")
 data_utils.pack_sites([d], store, 20, "norm_hct116.npz")
 res = {}
-for tag, extra, env in (("gpus1", [], {}), ("gpus2_host", ["--gpus", "2"], {"M6A_EXCHANGE": "host"}), ("gpus4_host", ["--gpus", "4"], {"M6A_EXCHANGE": "host"})):
+# one GPU box: the ranks share the GPU (M6A_SHARE_GPU=1); the default performs no device exchange, `_host` adds the debugging gather
+for tag, extra, env in (("gpus1", [], {}), ("gpus2", ["--gpus", "2"], {"M6A_SHARE_GPU": "1"}), ("gpus4", ["--gpus", "4"], {"M6A_SHARE_GPU": "1"}),
+                        ("gpus8", ["--gpus", "8"], {"M6A_SHARE_GPU": "1"}), ("gpus8_host", ["--gpus", "8"], {"M6A_EXCHANGE": "host"})):
     ts = []
     for rep in range(4):
         t0 = time.perf_counter()
@@ -17,6 +19,6 @@ for tag, extra, env in (("gpus1", [], {}), ("gpus2_host", ["--gpus", "2"], {"M6A
         ts.append(time.perf_counter() - t0)
     res[tag] = {"best_s": min(ts), "all_s": ts}
 a = open(os.path.join(d, "ogpus1", "data.indiv_proba.csv"), "rb").read()
-res["bytes_equal"] = all(open(os.path.join(d, "o" + t, "data.indiv_proba.csv"), "rb").read() == a for t in ("gpus2_host", "gpus4_host"))
+res["bytes_equal"] = all(open(os.path.join(d, "o" + t, "data.indiv_proba.csv"), "rb").read() == a for t in ("gpus2", "gpus4", "gpus8", "gpus8_host"))
 print(json.dumps(res))
 PY
