@@ -539,15 +539,16 @@ int uniform_slice(m6a_ctx *c, uint32_t seed, int n, int T, int K, int jmax, cons
     return M6A_OK;
 }
 
-// accepted indices for pool_reg_kernel: idx2[j][T + 8][K] bytes, 2 x index (a register pair per bag entry),
-// iterations in order, one round of zero padding for the prefetch past the end.
+// accepted indices for pool_reg_kernel: idx16[j][T + 8][K] 16-bit words (0x1000 | 2 x index: the draw's M0, a register pair
+// per bag entry), iterations in order, one round of zero padding for the prefetch past the end.  Bags of one read: all zero
+// (no operand indexed: every draw reads entry 0).
 int ensure_table_reg(m6a_ctx *c, uint32_t seed, int n, int T, int K, int jmax)
 {
     auto &k = c->tab_reg_key;
     if (k.valid && k.seed == seed && k.n == n && k.T == T && k.K == K && k.jmax >= jmax) return M6A_OK;
     k.valid = false;                                       // the table is rewritten below: a failure must not leave the old key standing
-    const size_t per_j = (size_t)(T + 8) * K;              // K = 20: a multiple of 4 bytes
-    const size_t bytes = (size_t)jmax * per_j + 4096;      // the kernel's look-ahead touches up to 2 KB past the last row
+    const size_t per_j = (size_t)(T + 8) * K;              // 16-bit words per position; K = 20: 40 bytes per iteration
+    const size_t bytes = (size_t)jmax * per_j * 2 + 4096;  // the kernel's look-ahead touches up to 2 KB past the last row
     HIPCHK(c, c->tab_reg.ensure(bytes));
     HIPCHK(c, hipMemsetAsync(c->tab_reg.p, 0, bytes, c->stream));
     const uint16_t *C = nullptr;
@@ -556,7 +557,7 @@ int ensure_table_reg(m6a_ctx *c, uint32_t seed, int n, int T, int K, int jmax)
     if (C) {
         const int64_t A = (int64_t)T * K;
         hipLaunchKernelGGL(rtab_to_reg_table_kernel, dim3((unsigned)((A * jmax + 255) / 256)), dim3(256), 0, c->stream,
-                           C, A, (int64_t)per_j, jmax, (uint8_t *)c->tab_reg.p);
+                           C, A, (int64_t)per_j, jmax, (uint16_t *)c->tab_reg.p);
         HIPCHK(c, hipGetLastError());
     }
     k = {seed, n, T, K, jmax, true};
@@ -804,7 +805,7 @@ int launch_pool(m6a_ctx *c, const float *rp, const int64_t *off, int64_t S, int 
     const bool uniform = nmin == nmax && nmin >= 1 && nmin <= M6A_TABLE_MAX_N && K == 20 && gmax <= 4096;
     // register kernel: stack in 8 register quads, 32-bit byte offsets into read_prob, table <= 256 MB
     const bool reg_ok = uniform && c->plan.depth <= M6A_REG_STACK && c->n_reads < (int64_t)1 << 30 &&
-                        (int64_t)gmax * (T + 8) * K <= (int64_t)256 << 20;
+                        (int64_t)gmax * (T + 8) * K * 2 <= (int64_t)256 << 20;
     if (uniform && reg_ok && c->table_variant != 1) {
         rc = ensure_table_reg(c, seed, (int)nmin, T, K, (int)gmax);
         if (rc) return rc;

@@ -119,7 +119,7 @@ __global__ void mt_jump_kernel(const uint32_t *xhead, const uint64_t *polys, uin
 __global__ void rtab_count_kernel(RtabBuild a);
 __global__ void rtab_scan_kernel(RtabBuild a);
 __global__ void rtab_fill_kernel(RtabBuild a);
-__global__ void rtab_to_reg_table_kernel(const uint16_t *C, int64_t A, int64_t row_bytes, int jmax, uint8_t *tab);
+__global__ void rtab_to_reg_table_kernel(const uint16_t *C, int64_t A, int64_t row_words, int jmax, uint16_t *tab);
 __global__ void rtab_to_lds_table_kernel(const uint16_t *C, int64_t A, int K, int rows, int jmax, const int *iter_of, uint32_t *tab);
 __global__ void rtab_prep_kernel(PoolArgs a, RtabUse u, uint32_t *cursor, uint32_t *order, unsigned n_order_blocks);
 template <int KT> __global__ void pool_rtab_kernel(PoolArgs a, RtabUse u);

@@ -22,8 +22,8 @@
 //   v[96:127]   the 8 accumulator chains of NumPy's pairwise sum, chain c at v[96+4c .. 99+4c]
 //   v[64:95]    merge stack of the pairwise sum, entry d at v[64+4d .. 67+4d] (height <= 8)
 //   v[56:59]    running products, v[60:63] leaf sum / result, v[32:35] byte offsets, v[40:47] temps
-//   s[36:55]    draw indices of iterations 0..3 of a round (one byte per draw: 2 x index, 5 dwords per
-//               iteration), s[56:75] of iterations 4..7; each half is fetched four iterations ahead
+//   s[36:55]    draw indices of iterations 0..1 and 4..5 of a round (one 16-bit word per draw: the value M0 takes for
+//               it, 10 dwords per iteration), s[56:75] of iterations 2..3 and 6..7; each pair is fetched two iterations ahead
 //   s76 round control word, s77 rounds left, s78 4*stack height, s79 temp, s[80:81] table cursor,
 //   s[82:83] control cursor
 //
@@ -35,10 +35,18 @@
 // says and pushed -- the stack is addressed through the same index mode (SRC0 / DST relative).
 // The last leaf is finished after the loop: combine, add the T % 8 tail values one by one, merge.
 //
-// Index bytes are scalar loads (80 B = four iterations per s_load_dwordx16 + x4), fetched half a round
+// Index words are scalar loads (80 B = two iterations per s_load_dwordx16 + x4), fetched two iterations
 // ahead: the waves of a CU stream different rows through the scalar cache, so a load is an L2 round trip,
-// longer than one iteration.  The table is idx2[j][T + 8][20] bytes (2 x index, iteration-major, padded
-// by one round so the prefetch past the end stays in bounds).
+// longer than one iteration.  The table is idx16[j][T + 8][20] 16-bit words, iteration-major, padded by one
+// round so the prefetch past the end stays in bounds.
+//
+// ONE scalar instruction per draw (round 5; rounds 1-4: two).  A draw's index has to reach M0[7:0] with M0[15:12] = the
+// operand enables of the index mode.  Index BYTES needed s_lshr_b32 (next byte down) + s_set_gpr_idx_idx (M0[7:0] = low
+// byte, the rest of M0 kept) per draw.  A wave issues one instruction per turn, so a draw was four turns for two
+// multiplies and the SIMD's VALU was busy only when the two resident waves interleaved perfectly (in-kernel stamps: 4.86
+// ticks per v_pk_mul_f32 against the nominal 4; the knock-out without the shift ran 4.4 % faster,
+// profiles/r04_pool_reg_knockouts.json).  A table entry now IS the M0 value -- 0x1000 (SRC0 enable) | 2 x index -- two per
+// dword: s_sext_i32_i16 m0, s[r] for the low one, s_lshr_b32 m0, s[r], 16 for the high one.
 #include "m6a_kernels.h"
 
 #define S1(x) #x
@@ -51,16 +59,15 @@
 #define MUL \
     "v_pk_mul_f32 v[56:57], v[128:129], v[56:57]\n" \
     "v_pk_mul_f32 v[58:59], v[192:193], v[58:59]\n"
-// four draws from index dword s[r] (one byte each = 2 x index; s_set_gpr_idx_* reads bits 7:0 only, so the
-// dword is shifted down in place)
-#define IDX(r) "s_set_gpr_idx_idx s[" S(r) "]\n"
-#define SHR(r) "s_lshr_b32 s[" S(r) "], s[" S(r) "], 8\n"
-#define DRAW4(r) IDX(r) MUL SHR(r) IDX(r) MUL SHR(r) IDX(r) MUL SHR(r) IDX(r) MUL
-// the 20 draws of one iteration from index dwords s[b .. b+4], then 1 - prod
+// two draws from index dword s[r]: each half is the draw's M0 (0x1000 | 2 x index; see the header)
+#define LO(r) "s_sext_i32_i16 m0, s[" S(r) "]\n"
+#define HI(r) "s_lshr_b32 m0, s[" S(r) "], 16\n"
+#define DRAW2(r) LO(r) MUL HI(r) MUL
+// the 20 draws of one iteration from index dwords s[b .. b+9], then 1 - prod
 #define DRAWS(b) \
     "s_set_gpr_idx_on s[" S(b) "], gpr_idx(SRC0)\n" \
-    MUL0 SHR(b) IDX(b) MUL SHR(b) IDX(b) MUL SHR(b) IDX(b) MUL \
-    DRAW4(b+1) DRAW4(b+2) DRAW4(b+3) DRAW4(b+4) \
+    MUL0 HI(b) MUL \
+    DRAW2(b+1) DRAW2(b+2) DRAW2(b+3) DRAW2(b+4) DRAW2(b+5) DRAW2(b+6) DRAW2(b+7) DRAW2(b+8) DRAW2(b+9) \
     "s_set_gpr_idx_off\n" \
     "v_pk_add_f32 v[56:57], v[56:57], 1.0 op_sel_hi:[1,0] neg_lo:[1,0] neg_hi:[1,0]\n" \
     "v_pk_add_f32 v[58:59], v[58:59], 1.0 op_sel_hi:[1,0] neg_lo:[1,0] neg_hi:[1,0]\n"
@@ -135,7 +142,7 @@ __global__ __launch_bounds__(64) void pool_reg_kernel(PoolArgs a)
         boff[q] = site[q] >= 0 ? (uint32_t)(a.off[site[q]] * 4) : 0u;      // idle lanes replay site 0
     }
     const uint64_t rp = (uint64_t)a.read_prob;
-    const uint64_t tab = (uint64_t)((const uint8_t *)a.tab + (size_t)j * (size_t)(a.T + 8) * 20);
+    const uint64_t tab = (uint64_t)((const uint8_t *)a.tab + (size_t)j * (size_t)(a.T + 8) * 40);
     const uint64_t ctl = (uint64_t)a.reg_ctl;
     float o0, o1, o2, o3;
     int c0, c1, c2, c3;
@@ -156,6 +163,8 @@ __global__ __launch_bounds__(64) void pool_reg_kernel(PoolArgs a)
         "s_mov_b64 s[82:83], %[ctl]\n"
         "s_load_dwordx16 s[36:51], s[80:81], 0\n"
         "s_load_dwordx4 s[52:55], s[80:81], 64\n"
+        "s_load_dwordx16 s[56:71], s[80:81], 80\n"
+        "s_load_dwordx4 s[72:75], s[80:81], 144\n"
         "s_mov_b32 s77, %[nr]\n"
         "s_mov_b32 s78, 0\n"
         // mod_ratio numerators: reads with p >= thr among the bag's n entries (v40..v43, one per site)
@@ -291,18 +300,27 @@ __global__ __launch_bounds__(64) void pool_reg_kernel(PoolArgs a)
         "s_waitcnt lgkmcnt(0)\n"
         "s_cmp_eq_u32 s77, 0\n"
         "s_cbranch_scc1 3f\n"
-        // ---- rounds of 8 iterations
+        // ---- rounds of 8 iterations: index pairs A = s[36:55], B = s[56:75]; on entry A holds iterations 0..1 and B's load
+        // (2..3) is in flight; every pair is requested two iterations before its first draw
         "1:\n"
         "s_load_dword s76, s[82:83], 0\n"
-        "s_load_dwordx16 s[56:71], s[80:81], 80\n"
-        "s_load_dwordx4 s[72:75], s[80:81], 144\n"
-        ITER(0, 36) ITER(1, 41) ITER(2, 46) ITER(3, 51)
+        ITER(0, 36) ITER(1, 46)
         "s_waitcnt lgkmcnt(0)\n"
         "s_load_dwordx16 s[36:51], s[80:81], 160\n"
         "s_load_dwordx4 s[52:55], s[80:81], 224\n"
-        ITER(4, 56) ITER(5, 61) ITER(6, 66) ITER(7, 71)
+        ITER(2, 56) ITER(3, 66)
         "s_waitcnt lgkmcnt(0)\n"
-        "s_add_u32 s80, s80, 160\n"
+        "s_load_dwordx16 s[56:71], s[80:81], 240\n"
+        "s_load_dwordx4 s[72:75], s[80:81], 304\n"
+        ITER(4, 36) ITER(5, 46)
+        "s_waitcnt lgkmcnt(0)\n"
+        "s_load_dwordx16 s[36:51], s[80:81], 320\n"
+        "s_load_dwordx4 s[52:55], s[80:81], 384\n"
+        ITER(6, 56) ITER(7, 66)
+        "s_waitcnt lgkmcnt(0)\n"
+        "s_load_dwordx16 s[56:71], s[80:81], 400\n"
+        "s_load_dwordx4 s[72:75], s[80:81], 464\n"
+        "s_add_u32 s80, s80, 320\n"
         "s_addc_u32 s81, s81, 0\n"
         "s_add_u32 s82, s82, 4\n"
         "s_addc_u32 s83, s83, 0\n"
@@ -324,19 +342,21 @@ __global__ __launch_bounds__(64) void pool_reg_kernel(PoolArgs a)
         "s_cmp_lg_u32 s77, 0\n"
         "s_cbranch_scc1 1b\n"
         "3:\n"
-        // ---- the last leaf: combine, then its tail (s[80:81] points at iteration 8 * rounds)
+        // ---- the last leaf: combine, then its tail (s[80:81] points at iteration 8 * rounds; the loop's last prefetch may
+        // still be writing s[56:75], and the tail's loads below reuse s[36:45])
+        "s_waitcnt lgkmcnt(0)\n"
         COMBINE
         "s_mov_b32 s77, %[nt]\n"
         "s_cmp_eq_u32 s77, 0\n"
         "s_cbranch_scc1 6f\n"
         "5:\n"
-        "s_load_dwordx4 s[36:39], s[80:81], 0\n"
-        "s_load_dword s40, s[80:81], 16\n"
+        "s_load_dwordx8 s[36:43], s[80:81], 0\n"
+        "s_load_dwordx2 s[44:45], s[80:81], 32\n"
         "s_waitcnt lgkmcnt(0)\n"
         DRAWS(36)
         "v_pk_add_f32 v[60:61], v[60:61], v[56:57]\n"
         "v_pk_add_f32 v[62:63], v[62:63], v[58:59]\n"
-        "s_add_u32 s80, s80, 20\n"
+        "s_add_u32 s80, s80, 40\n"
         "s_addc_u32 s81, s81, 0\n"
         "s_sub_u32 s77, s77, 1\n"
         "s_cmp_lg_u32 s77, 0\n"

@@ -288,14 +288,15 @@ __global__ __launch_bounds__(256) void rtab_fill_kernel(RtabBuild a)
     }
 }
 
-// accepted-index table of pool_reg_kernel from a C_n row: idx2[j][T+8][K] bytes = 2 * index, row j =
-// draws [j*T*K, (j+1)*T*K) of the stream (site j of every flush group of uniform bags)
-__global__ __launch_bounds__(256) void rtab_to_reg_table_kernel(const uint16_t *C, int64_t A, int64_t row_bytes, int jmax, uint8_t *tab)
+// accepted-index table of pool_reg_kernel from a C_n row: idx16[j][T+8][K] 16-bit words, row j = draws [j*T*K, (j+1)*T*K) of
+// the stream (site j of every flush group of uniform bags).  A word is the value M0 takes for the draw: 0x1000 (the index
+// mode's SRC0 enable, M0[15:12]) | 2 x index (a register pair per bag entry, M0[7:0]) -- m6a_pool_reg.hip
+__global__ __launch_bounds__(256) void rtab_to_reg_table_kernel(const uint16_t *C, int64_t A, int64_t row_words, int jmax, uint16_t *tab)
 {
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= A * jmax) return;
     const int64_t j = e / A, w = e - j * A;
-    tab[j * row_bytes + w] = (uint8_t)(2u * ((const uint8_t *)C)[e]);      // uniform bags are <= 32 reads: a byte table
+    tab[j * row_words + w] = (uint16_t)(0x1000u | (2u * ((const uint8_t *)C)[e]));      // uniform bags are <= 32 reads: a byte table
 }
 
 // accepted-index table of pool_table_kernel from a C_n row: tab[j][row][plane][lane], four byte offsets (8 * index) per

@@ -145,6 +145,9 @@ def main():
         sd[k] = torch.from_numpy(w[at:at + n].reshape(shp).copy())
         at += n
     model = ns["HipModel"](sd)
+    eng.set_encoder_variant(1)                      # the stub selects the 16-slot encoder (the reference's bits): compare like with like
+    want = eng.infer(X, km, off, 1000)
+    eng.set_encoder_variant(0)
     tb = [(torch.from_numpy(bx), torch.from_numpy(np.repeat(bk.astype(np.int64), np.diff(bo), axis=0)), torch.from_numpy(np.diff(bo)))
           for bx, bk, bo in batches]
     best = None

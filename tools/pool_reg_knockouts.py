@@ -68,20 +68,16 @@ def stamps(s):
 VARIANTS = {
     "asis": lambda s: s,
     "stamps": stamps,
-    # 3 instructions per draw: no in-place shift of the index dword (every draw of a dword uses its low byte)
-    "noshr": lambda s: sub(r'#define SHR\(r\) .*', '#define SHR(r) ""', s),
-    # 2 instructions per draw: no index switch either (index mode stays on with the first draw's index)
-    "noidx": lambda s: sub(r'#define IDX\(r\) .*', '#define IDX(r) ""', sub(r'#define SHR\(r\) .*', '#define SHR(r) ""', s)),
+    # round 5's loop has ONE scalar instruction per draw (the draw's M0 value straight out of a 16-bit table entry); without it
+    # (index mode stays on with the first draw's index): what is that one still worth?
+    "nom0": lambda s: sub(r'#define HI\(r\) .*', '#define HI(r) ""', sub(r'#define LO\(r\) .*', '#define LO(r) ""', s)),
     # the scalar index loads of the round loop removed (stale registers)
     "noload": no_loop_loads,
-    "pkonly": lambda s: no_loop_loads(VARIANTS["noidx"](s)),
+    "pkonly": lambda s: no_loop_loads(VARIANTS["nom0"](s)),
     # the shift moved between the two multiplies of the PREVIOUS draw (same instruction count, SALU never back to back)
     "vpre640": vprefetch(640),
     "vpre1600": vprefetch(1600),
     "vpre3200": vprefetch(3200),
-    "spread": lambda s: sub(r'#define DRAW4\(r\) .*',
-                            '#define MULA "v_pk_mul_f32 v[56:57], v[128:129], v[56:57]\\\\n"\n#define MULB "v_pk_mul_f32 v[58:59], v[192:193], v[58:59]\\\\n"\n'
-                            '#define DRAW4(r) IDX(r) MULA SHR(r) MULB IDX(r) MULA SHR(r) MULB IDX(r) MULA SHR(r) MULB IDX(r) MULA MULB', s),
 }
 
 
