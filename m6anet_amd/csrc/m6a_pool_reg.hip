@@ -4,13 +4,12 @@
 // accepted indices of "the j-th site of a flush group" are the same in every group, so a wavefront
 // that takes position j of 256 different groups -- lane = 4 sites -- sees a WAVE-UNIFORM index for
 // every draw.  A uniform index into per-lane data is exactly what the VGPR index mode of gfx9/CDNA
-// does for free: s_set_gpr_idx_idx puts the index in M0 and the next v_pk_mul_f32 reads
-// v[base + M0].  No LDS gather at all: the inner loop is 1-2 SALU + 2 VALU per draw of 4 sites
-// (v_pk_mul_f32 advances two sites), against 5 VALU + 4.25 LDS instructions per draw of 8 sites in
-// the LDS kernel, whose floor is the LDS pipe (0.57 ms per 1 M sites x T=1000, 0.93 ms measured).
-// This one is bound by VALU issue: a v_pk_mul_f32 costs ~7 cycles per wavefront on this part, indexed or
-// not (tools/gpr_variants_gen.py, profiles/r02_gpr_variants.txt): 14 cycles per draw of 4 sites, 0.445 ms
-// per 1 M sites x T=1000 measured.
+// does for free: with the index in M0[7:0] the next v_pk_mul_f32 reads v[base + M0].  No LDS gather at all: the
+// inner loop is 1 SALU + 2 VALU per draw of 4 sites (v_pk_mul_f32 advances two sites), against 5 VALU + 4.25 LDS
+// instructions per draw of 8 sites in the LDS kernel, whose floor is the LDS pipe (0.57 ms per 1 M sites x T=1000,
+// 0.93 ms measured).  This one is bound by VALU issue: two resident waves deliver a v_pk_mul_f32 every 4.7 shader
+// ticks per SIMD (nominal 4; in-kernel stamps, profiles/r05_pool_reg_wave_timeline.txt) at the ~1.85 GHz the part
+// clocks under this load: 0.390 ms per 1 M sites x T=1000 in bench.py (rounds 1-3: 0.445, round 4: 0.413).
 //
 // The compiler cannot express "this instruction's source register is v[128 + M0]" and has no
 // register class beyond 32 dwords, so the core is one hand-written assembly block with its own
