@@ -641,6 +641,36 @@ def test_bench_world_8_rehearsal_on_one_gpu(workload, sites):
     assert d["rccl"]["ranks_seen"] is None and "gloo" in d["rccl"]["communicator"] and d["efficiency"] > 0
 
 
+def test_bench_default_line_has_the_contract_and_the_round_5_keys():
+    """The line the driver reads (default shape, no flags but shorter legs): the contract's keys, the roofline with the executed-work
+    fraction, the product-default encoder's own roofline (what `m6anet_amd inference` launches), the host-input leg, the ragged
+    shape -- every extra leg is optional in bench.py, so a leg that broke would silently vanish from the record: this test is where
+    it fails loudly."""
+    out, lines = run_bench(["--steps", "3", "--warmup", "1", "--min-seconds", "0", "--no-cpu-baseline", "--no-live-traffic"], {}, timeout=600)
+    assert out.returncode == 0 and len(lines) == 1, out.stderr[-2000:]
+    d = lines[0]
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["dtype"] == "f32" and d["vs_baseline"] is None and "workload" in d["config"] and "error" not in d
+    assert 2.0e8 < d["value"] < 6.0e8 and abs(d["value"] - 1e6 / (d["ms_per_step"] * 1e-3)) < 1e-3 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.7 < r["frac"] < 1.0
+    assert r["executed_flop_per_read"] == 13568 and r["mfma_per_32_read_tile"] == 106 and 0.7 < r["frac_executed"] < r["frac"]
+    assert "enc_csite_kernel" in r["kernel"] and d["config"]["encoder_kernel_function"] == "enc_csite_kernel" and "general16" in d["config"]["cli_default_encoder"]
+    pd = d["roofline_product_default"]
+    assert "enc_site16_kernel" in pd["kernel"] and pd["executed_flop_per_read"] == 14848 and pd["mfma_per_32_read_tile"] == 116
+    assert 0.7 < pd["frac"] < r["frac"] and pd["frac"] < pd["frac_executed"] < 1.0 and pd["launches"] == 10
+    ro = d["reference_order_encoder"]
+    assert ro["kernel"] == "enc_site16_kernel" and len(ro["ms_per_step_of_each_leg"]) == 3 and d["ms_per_step"] < ro["ms_per_step"] < 1.15 * d["ms_per_step"]
+    h = d["with_h2d"]
+    assert "error" not in h and h["pageable"]["sites_per_s"] > 2e7 and h["pinned"]["sites_per_s"] > 2e7 and h["bytes_in_per_step"] == 731000008
+    assert d["value"] > 3 * h["pinned"]["sites_per_s"]                      # PCIe-inclusive rates are never the headline
+    p = d["pool_roofline"]
+    assert p["bound"] == "valu" and 0.5 < p["frac"] < 1.0 and (p["measured_ceiling"] is None or p["measured_ceiling"]["frac"] < 1.05)
+    g = d["ragged"]
+    assert g["value"] > 1e7 and g["config"]["pool_kernel"] == "ragged-table" and 0.7 < g["roofline"]["frac"] < 1.0
+
+
 def test_bench_sustained_leg_with_two_ranks():
     """--min-seconds keeps stepping after the timed region; with several ranks the loop's exit is a collective decision
     (every rank adds the slowest rank's time), so nobody is left waiting at a barrier."""
