@@ -954,58 +954,72 @@ def run(args, line, rank, world, local_rank, S, bag, T):
         default_run = (world == 1 and args.workload == "uniform" and S == WORKLOADS["uniform"]["sites"] and T == 1000 and
                        bag == WORKLOADS["uniform"]["bag"])
         if default_run and not args.no_ragged_extra:
-            # the same workload on the 16-slot encoder -- the kernel whose read probabilities are the reference's bit for bit:
-            # what `m6anet_amd inference` and INTEGRATION.md's stub run by default (the timed region above used the library's
-            # automatic choice, the 12-slot kernel) -- with its own roofline from HIP events around its launches
-            b.eng.set_encoder_variant(1)
-            for _ in range(3):
-                b.compute()
-            legs = []
-            for _ in range(3):                            # three legs of 10 steps, the median reported: a 27 ms region is one hiccup away from +4 %
-                torch.cuda.synchronize(dev)
-                t0 = time.perf_counter()
+            # three EXTRA legs after the headline; each is optional: a failure is recorded under "<leg>_error" and the line goes out
+            def optional(name, leg):
+                try:
+                    leg()
+                except Exception as e:                      # noqa: BLE001
+                    line[name + "_error"] = "%s: %s" % (type(e).__name__, str(e)[:300])
+
+            def leg_product_default():
+                # the same workload on the 16-slot encoder -- the kernel whose read probabilities are the reference's bit for bit:
+                # what `m6anet_amd inference` and INTEGRATION.md's stub run by default (the timed region above used the library's
+                # automatic choice, the 12-slot kernel) -- with its own roofline from HIP events around its launches
+                b.eng.set_encoder_variant(1)
+                for _ in range(3):
+                    b.compute()
+                legs = []
+                for _ in range(3):                            # three legs of 10 steps, the median reported: a 27 ms region is one hiccup away from +4 %
+                    torch.cuda.synchronize(dev)
+                    t0 = time.perf_counter()
+                    for _ in range(10):
+                        b.compute()
+                    torch.cuda.synchronize(dev)
+                    legs.append((time.perf_counter() - t0) / 10 * 1e3)
+                ms = sorted(legs)[1]
+                b.eng.profile("encoder")
                 for _ in range(10):
                     b.compute()
-                torch.cuda.synchronize(dev)
-                legs.append((time.perf_counter() - t0) / 10 * 1e3)
-            ms = sorted(legs)[1]
-            b.eng.profile("encoder")
-            for _ in range(10):
-                b.compute()
-            k_ms, k_n = b.eng.profile_read(0)
-            b.eng.profile(False)
-            kern = b.eng.last_encoder_kernel
-            k_avg = k_ms / max(k_n, 1)
-            ex = ENC_MFMA_PER_TILE[kern] * 4096 // 32
-            tf, tfx = (f * b.R / (k_avg * 1e-3) / 1e12 for f in (ENC_FLOP_PER_READ, ex))
-            line["reference_order_encoder"] = {
-                "encoder_kernel": b.eng.last_encoder_variant, "kernel": kern, "ms_per_step": ms, "value": b.Sr / (ms * 1e-3), "steps": 10, "warmup": 3,
-                "ms_per_step_of_each_leg": legs,
-                "note": "same workload, m6a_set_encoder_variant(1): every float32 operation of the reference's encoder in the "
-                        "reference's order (DESIGN.md section 2) -- read and site probabilities bit-identical to the reference's on "
-                        "this workload's bags; the headline above runs the 12-slot kernel (within 1e-5 relative)"}
-            line["roofline_product_default"] = {
-                "kernel": "read encoder (%s: %s) -- what `m6anet_amd inference` (--encoder reference, its default) and "
-                          "INTEGRATION.md's stub launch on this workload" % (b.eng.last_encoder_variant, kern),
-                "bound": "mfma", "achieved": tf, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_F32_TFLOPS,
-                "traffic": None, "avg_launch_ms": k_avg, "launches": k_n, "algorithmic_flop_per_read": ENC_FLOP_PER_READ,
-                "executed_flop_per_read": ex, "mfma_per_32_read_tile": ENC_MFMA_PER_TILE[kern], "achieved_executed": tfx,
-                "frac_executed": tfx / PEAK_F32_TFLOPS, "reads_per_launch": b.R,
-                "timed_in": "10 extra steps after reference_order_encoder's, HIP events around every launch"}
+                k_ms, k_n = b.eng.profile_read(0)
+                b.eng.profile(False)
+                kern = b.eng.last_encoder_kernel
+                k_avg = k_ms / max(k_n, 1)
+                ex = ENC_MFMA_PER_TILE[kern] * 4096 // 32
+                tf, tfx = (f * b.R / (k_avg * 1e-3) / 1e12 for f in (ENC_FLOP_PER_READ, ex))
+                line["reference_order_encoder"] = {
+                    "encoder_kernel": b.eng.last_encoder_variant, "kernel": kern, "ms_per_step": ms, "value": b.Sr / (ms * 1e-3), "steps": 10, "warmup": 3,
+                    "ms_per_step_of_each_leg": legs,
+                    "note": "same workload, m6a_set_encoder_variant(1): every float32 operation of the reference's encoder in the "
+                            "reference's order (DESIGN.md section 2) -- read and site probabilities bit-identical to the reference's on "
+                            "this workload's bags; the headline above runs the 12-slot kernel (within 1e-5 relative)"}
+                line["roofline_product_default"] = {
+                    "kernel": "read encoder (%s: %s) -- what `m6anet_amd inference` (--encoder reference, its default) and "
+                              "INTEGRATION.md's stub launch on this workload" % (b.eng.last_encoder_variant, kern),
+                    "bound": "mfma", "achieved": tf, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_F32_TFLOPS,
+                    "traffic": None, "avg_launch_ms": k_avg, "launches": k_n, "algorithmic_flop_per_read": ENC_FLOP_PER_READ,
+                    "executed_flop_per_read": ex, "mfma_per_32_read_tile": ENC_MFMA_PER_TILE[kern], "achieved_executed": tfx,
+                    "frac_executed": tfx / PEAK_F32_TFLOPS, "reads_per_launch": b.R,
+                    "timed_in": "10 extra steps after reference_order_encoder's, HIP events around every launch"}
+                b.eng.set_encoder_variant(0)
+
+            def leg_ragged():
+                # the path real data takes (bags are never uniform), in the same record: configs[4]'s per-GPU shape
+                del b.X, b.rp
+                b.eng.close()
+                torch.cuda.empty_cache()
+                rs = WORKLOADS["ragged"]
+                rb = Bench(args, "ragged", rs["sites"], rs["bag"], 1000, 0, 1, local_rank, dev, backend)
+                rr = rb.run(10, 3, args.min_seconds)
+                rg = rb.report(rr, 10)                        # incl. its own live PMC passes for roofline.traffic
+                rg["config"] = rb.config()
+                rg["steps"], rg["warmup"] = 10, 3
+                line["ragged"] = rg
+                rb.eng.close()
+
+            optional("roofline_product_default", leg_product_default)
             b.eng.set_encoder_variant(0)
             line["with_h2d"] = with_h2d(b, T)
-            # the path real data takes (bags are never uniform), in the same record: configs[4]'s per-GPU shape
-            del b.X, b.rp
-            b.eng.close()
-            torch.cuda.empty_cache()
-            rs = WORKLOADS["ragged"]
-            rb = Bench(args, "ragged", rs["sites"], rs["bag"], 1000, 0, 1, local_rank, dev, backend)
-            rr = rb.run(10, 3, args.min_seconds)
-            rg = rb.report(rr, 10)                        # incl. its own live PMC passes for roofline.traffic
-            rg["config"] = rb.config()
-            rg["steps"], rg["warmup"] = 10, 3
-            line["ragged"] = rg
-            rb.eng.close()
+            optional("ragged", leg_ragged)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = run_cpu_baseline_subprocess(args.workload, T)
     if multi:
