@@ -54,7 +54,7 @@ PEAK_VALU_MULS = PEAK_F32_TFLOPS * 1e12 / 2
 def pool_roofline(variant, draws, avg_ms, launches):
     """The pooling kernel against the resource that bounds it: the register kernel of uniform bags issues one
     v_pk_mul_f32 per two draws and no LDS gather at all (VALU issue); every other variant gathers one 4-byte value
-    per draw from LDS.  DESIGN.md sections 4.2r / 4.3 derive both and the practical ceilings under them."""
+    per draw from LDS.  DESIGN.md sections 4.2 / 4.3 (HISTORY.md 4.2r / 4.3 for the derivations) give both and the practical ceilings under them."""
     rate = draws / (avg_ms * 1e-3) if avg_ms else None
     if variant == "table-reg":
         bound, peak = "valu", PEAK_VALU_MULS

@@ -3,7 +3,7 @@
 Only `validate` (training_utils.py:213-268) and its metric helpers (:15-45) -- SURVEY.md section 8(f)
 rank 4: the same dictionary the reference returns, with the predictions computed by
 M6ANetEngine.validate_forward (every read encoded once on the GPU; the reference re-encodes the 20
-sampled reads of every site in every pass).  Training itself is out of scope (DESIGN.md section 7).
+sampled reads of every site in every pass).  Training itself is out of scope (DESIGN.md section 8).
 """
 import time
 

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Numerical experiment behind DESIGN.md section 8 (test infrastructure: it uses the oracle): would layer 2 of the read
+"""Numerical experiment behind HISTORY.md section 8 (test infrastructure: it uses the oracle): would layer 2 of the read
 encoder (150 -> 32, 68 % of the FLOPs) on the bf16 matrix pipe -- float32 operands split exactly into three bf16 parts,
 6 or 9 partial products, float32 accumulation -- stay inside the reference's read-probability bar (np.allclose,
 rtol 1e-5, atol 1e-8)?  Prints, per checkpoint, the largest |a-b| / (1e-8 + 1e-5 |b|) ("tolerance used") against the

@@ -87,7 +87,7 @@ def test_oracle_layers_are_the_references_bits(golden, weights, tag):
 
 
 def test_numpy_emulation_of_the_order_reproduces_the_references_hidden_layer(golden, weights):
-    """tools/emulate_encoder.py is where the order of operations was worked out and where DESIGN.md's noise-budget figures come
+    """tools/emulate_encoder.py is where the order of operations was worked out and where HISTORY.md's noise-budget figures (section 2) come
     from; this keeps it honest: its restatement of torch's order (fma chains in float64-exact NumPy steps) gives the reference's
     read representation bit for bit, and its 32 -> 1 model (the AVX-512 gemv: a one-element head, two 16-lane butterflies) the
     reference's logits."""

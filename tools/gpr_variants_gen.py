@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """SUPERSEDED by tools/valu_rate_bench.hip (round 4): this probe waits for a scalar load in every iteration with two waves to
-cover it, so its 6-7 cycles per v_pk_mul_f32 / 3.05 per v_mul_f32 were its own loop, not the part; kept
+cover it, so its 6-7 cycles per v_pk_mul_f32 / 3.05 per v_mul_f32 were its own loop, not the part (HISTORY.md section 4.2r); kept
 because profiles/r02_gpr_variants.txt and r03_gpr_variants.txt came from it.
 
 Generates tools/gpr_variants.hip: the inner loop of pool_reg_kernel (bags in VGPRs, wave-uniform draw index through
