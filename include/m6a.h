@@ -82,7 +82,9 @@ int m6a_set_host_offsets(m6a_ctx *ctx, const int64_t *off_host);
  * pinning) instead of inside the first call that passes host buffers -- e.g. while the caller is still parsing
  * its input.  Host-buffer calls to m6a_infer / m6a_encode_reads cut the job into chunks and overlap the PCIe
  * transfer of chunk k+1 with the encoder of chunk k (the shape of the reference's batch loop,
- * m6anet/utils/inference_utils.py:33-41, without its per-batch synchronisation). */
+ * m6anet/utils/inference_utils.py:33-41, without its per-batch synchronisation).  Pageable buffers pass through the ring
+ * (copy threads + DMA); buffers the caller has page-locked (hipHostMalloc / hipHostRegister, torch's pin_memory()) are recognised
+ * with hipPointerGetAttributes and DMA'd in place, chunk by chunk, in both directions -- same chunks, same kernels, same bits. */
 int m6a_prepare_host_io(m6a_ctx *ctx);
 
 /* Read encoder.  Replaces, for one batch of sites,
