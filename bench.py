@@ -373,8 +373,8 @@ def measured_gather_ceiling(bag):
 def measured_multiply_ceiling():
     """What float32 multiplies cost on THIS box, measured now by tools/valu_rate_bench --ceiling (chain-free streams with
     random mantissas, events over ~1 ms kernels): the plain and the packed multiply at 2 and 8 waves per SIMD, and
-    pool_reg_kernel's own draw -- two indexed v_pk_mul_f32 behind a shift and an index switch, 256-register single-wave
-    workgroups, 2 waves per SIMD -- with nothing else around it.  `rate` = the last one: what the kernel's instruction
+    pool_reg_kernel's own draw -- two indexed v_pk_mul_f32 behind ONE scalar instruction that writes the draw's M0 (rounds 1-4: a
+    shift and an index switch), 256-register single-wave workgroups, 2 waves per SIMD -- with nothing else around it.  `rate` = the last one: what the kernel's instruction
     stream can reach; the chain-free rows say what the datapath delivers (profiles/r04_valu_rate.json has every variant)."""
     exe = os.path.join(REPO, "tools", "valu_rate_bench")
     if not os.path.exists(exe):
@@ -385,12 +385,12 @@ def measured_multiply_ceiling():
     except (subprocess.SubprocessError, OSError, ValueError, KeyError):
         return None
     table = {"%s @ %d waves/SIMD" % (" ".join(r["variant"].split()), r["waves_per_simd"]): r["T_lane_ops_per_s"] for r in rows}
-    like = [r for r in rows if "2 SALU" in r["variant"]]
+    like = [r for r in rows if "M0 write" in r["variant"]] or [r for r in rows if "2 SALU" in r["variant"]]
     if not like:
         return None
     return {"rate": like[0]["T_lane_ops_per_s"] * 1e12, "variant": like[0]["variant"], "rows": table,
-            "source": "tools/valu_rate_bench --ceiling run by this bench: pool_reg_kernel's draw (shift + index switch + two indexed "
-                      "v_pk_mul_f32, random mantissas, 2 waves per SIMD) with nothing else around it"}
+            "source": "tools/valu_rate_bench --ceiling run by this bench: pool_reg_kernel's draw (%s; two indexed v_pk_mul_f32, random "
+                      "mantissas, 2 waves per SIMD) with nothing else around it" % like[0]["variant"]}
 
 
 def smi_snapshot():

@@ -102,7 +102,8 @@ constexpr int INSTR_PER_ITER = 64;
 
 // pool_reg_kernel's own situation: sources in v[128:129] / v[192:193] (a 256-register wave: two per SIMD by register
 // budget alone), products in v[56:59], index mode on, random mantissas; as 64-thread and as 256-thread workgroups
-#define KLIKE(name, THREADS, IDXSW)                                                                                  \
+#define KLIKE(name, THREADS, IDXSW) KLIKE2(name, THREADS, "", IDXSW)
+#define KLIKE2(name, THREADS, INIT, IDXSW)                                                                                  \
     __global__ void __launch_bounds__(THREADS) name(int n, float a, float *out, unsigned long long *cyc)             \
     {                                                                                                               \
         float o; unsigned c0, c1;                                                                                   \
@@ -111,7 +112,7 @@ constexpr int INSTR_PER_ITER = 64;
         for (int i = 0; i < 4; i++) { unsigned h = (g32 * 4 + i) * 2654435761u; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; \
                                       r[i] = a * (0.999f + 0.002f * (float)(h >> 8) * (1.0f / 16777216.0f)); }      \
         asm volatile(                                                                                               \
-            "  s_mov_b32 s36, %[n]\n  s_mov_b32 s37, 0\n"                                                          \
+            "  s_mov_b32 s36, %[n]\n  s_mov_b32 s37, 0\n" INIT                                                     \
             "  v_mov_b32 v128, %[r0]\n  v_mov_b32 v129, %[r1]\n  v_mov_b32 v192, %[r2]\n  v_mov_b32 v193, %[r3]\n"  \
             "  v_mov_b32 v56, %[r2]\n  v_mov_b32 v57, %[r3]\n  v_mov_b32 v58, %[r0]\n  v_mov_b32 v59, %[r1]\n"      \
             "  s_memtime s[38:39]\n  s_waitcnt lgkmcnt(0)\n"                                                       \
@@ -135,6 +136,8 @@ KLIKE(k_klike64, 64, "")
 KLIKE(k_klike256, 256, "")
 KLIKE(k_klike64_sw, 64, "  s_set_gpr_idx_idx s37\n")
 KLIKE(k_klike64_sw2, 64, "  s_lshr_b32 s37, s37, 8\n  s_set_gpr_idx_idx s37\n")
+// round 5's draw: ONE scalar instruction -- the table entry is the draw's M0 (SRC0 enable | 2 x index), written straight into M0
+KLIKE2(k_klike64_m0, 64, "  s_mov_b32 s37, 0x10001000\n", "  s_lshr_b32 m0, s37, 16\n")
 
 KERNEL_RAND(k_pkmul_rand, BODY_PKMUL)
 KERNEL_RAND(k_pkmul_dep2_rand, BODY_PKMUL_DEP2)
@@ -237,6 +240,7 @@ int main(int argc, char **argv)
         {"kernel-like, 256-thread workgroups, index mode on", k_klike256, 256},
         {"kernel-like, 64-thread, 1 SALU (idx) per draw", k_klike64_sw, 64},
         {"kernel-like, 64-thread, 2 SALU (shift + idx) per draw", k_klike64_sw2, 64},
+        {"kernel-like, 64-thread, 1 SALU (M0 write: round 5's draw) per draw", k_klike64_m0, 64},
     };
     for (const KL &v : kl) {
         const int waves = cus * 4 * 2, blocks = waves * 64 / v.threads;
