@@ -103,7 +103,9 @@ constexpr int INSTR_PER_ITER = 64;
 // pool_reg_kernel's own situation: sources in v[128:129] / v[192:193] (a 256-register wave: two per SIMD by register
 // budget alone), products in v[56:59], index mode on, random mantissas; as 64-thread and as 256-thread workgroups
 #define KLIKE(name, THREADS, IDXSW) KLIKE2(name, THREADS, "", IDXSW)
-#define KLIKE2(name, THREADS, INIT, IDXSW)                                                                                  \
+#define KLIKE2(name, THREADS, INIT, IDXSW) KLIKE3(name, THREADS, INIT, IDXSW, "192", "193", "v255")
+// SRCB0/SRCB1: the second source pair; VMAX: the highest register the wave claims (v255: two waves per SIMD, v167: three)
+#define KLIKE3(name, THREADS, INIT, IDXSW, SRCB0, SRCB1, VMAX)                                                                                  \
     __global__ void __launch_bounds__(THREADS) name(int n, float a, float *out, unsigned long long *cyc)             \
     {                                                                                                               \
         float o; unsigned c0, c1;                                                                                   \
@@ -113,12 +115,12 @@ constexpr int INSTR_PER_ITER = 64;
                                       r[i] = a * (0.999f + 0.002f * (float)(h >> 8) * (1.0f / 16777216.0f)); }      \
         asm volatile(                                                                                               \
             "  s_mov_b32 s36, %[n]\n  s_mov_b32 s37, 0\n" INIT                                                     \
-            "  v_mov_b32 v128, %[r0]\n  v_mov_b32 v129, %[r1]\n  v_mov_b32 v192, %[r2]\n  v_mov_b32 v193, %[r3]\n"  \
+            "  v_mov_b32 v128, %[r0]\n  v_mov_b32 v129, %[r1]\n  v_mov_b32 v" SRCB0 ", %[r2]\n  v_mov_b32 v" SRCB1 ", %[r3]\n"  \
             "  v_mov_b32 v56, %[r2]\n  v_mov_b32 v57, %[r3]\n  v_mov_b32 v58, %[r0]\n  v_mov_b32 v59, %[r1]\n"      \
             "  s_memtime s[38:39]\n  s_waitcnt lgkmcnt(0)\n"                                                       \
             "1:\n"                                                                                                  \
             "  s_set_gpr_idx_on s37, gpr_idx(SRC0)\n"                                                               \
-            "  .rept 32\n" IDXSW "  v_pk_mul_f32 v[56:57], v[128:129], v[56:57]\n  v_pk_mul_f32 v[58:59], v[192:193], v[58:59]\n  .endr\n" \
+            "  .rept 32\n" IDXSW "  v_pk_mul_f32 v[56:57], v[128:129], v[56:57]\n  v_pk_mul_f32 v[58:59], v[" SRCB0 ":" SRCB1 "], v[58:59]\n  .endr\n" \
             "  s_set_gpr_idx_off\n"                                                                                 \
             "  s_sub_u32 s36, s36, 1\n  s_cmp_lg_u32 s36, 0\n  s_cbranch_scc1 1b\n"                                 \
             "  s_memtime s[40:41]\n  s_waitcnt lgkmcnt(0)\n"                                                       \
@@ -127,7 +129,7 @@ constexpr int INSTR_PER_ITER = 64;
             "  v_add_f32 %[o], v56, v57\n  v_add_f32 %[o], %[o], v58\n  v_add_f32 %[o], %[o], v59\n"                \
             : [o] "=&v"(o), [c0] "=&v"(c0), [c1] "=&v"(c1)                                                          \
             : [n] "s"(n), [r0] "v"(r[0]), [r1] "v"(r[1]), [r2] "v"(r[2]), [r3] "v"(r[3])                            \
-            : "s36", "s37", "s38", "s39", "s40", "s41", "scc", "memory", "v56", "v57", "v58", "v59", "v128", "v129", "v192", "v193", "v255"); \
+            : "s36", "s37", "s38", "s39", "s40", "s41", "scc", "memory", "v56", "v57", "v58", "v59", "v128", "v129", "v" SRCB0, "v" SRCB1, VMAX); \
         const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;                                             \
         if (o == 12345.678f) out[g] = o;                                                                            \
         if ((threadIdx.x & 63) == 0) cyc[g >> 6] = ((unsigned long long)c1 << 32) | c0;                             \
@@ -138,6 +140,8 @@ KLIKE(k_klike64_sw, 64, "  s_set_gpr_idx_idx s37\n")
 KLIKE(k_klike64_sw2, 64, "  s_lshr_b32 s37, s37, 8\n  s_set_gpr_idx_idx s37\n")
 // round 5's draw: ONE scalar instruction -- the table entry is the draw's M0 (SRC0 enable | 2 x index), written straight into M0
 KLIKE2(k_klike64_m0, 64, "  s_mov_b32 s37, 0x10001000\n", "  s_lshr_b32 m0, s37, 16\n")
+// the same draw in a 168-register wave (three per SIMD): what a 20-read-only register map would buy
+KLIKE3(k_klike64_m0_3w, 64, "  s_mov_b32 s37, 0x10001000\n", "  s_lshr_b32 m0, s37, 16\n", "160", "161", "v167")
 
 KERNEL_RAND(k_pkmul_rand, BODY_PKMUL)
 KERNEL_RAND(k_pkmul_dep2_rand, BODY_PKMUL_DEP2)
@@ -235,15 +239,17 @@ int main(int argc, char **argv)
         }
     }
     // the kernel-like variants: occupancy comes from their 256 registers (2 waves per SIMD), no LDS
-    struct KL { const char *name; kern_t fn; int threads; } kl[] = {
+    struct KL { const char *name; kern_t fn; int threads; int wps = 2; } kl[] = {
         {"kernel-like, 64-thread workgroups, index mode on", k_klike64, 64},
         {"kernel-like, 256-thread workgroups, index mode on", k_klike256, 256},
         {"kernel-like, 64-thread, 1 SALU (idx) per draw", k_klike64_sw, 64},
         {"kernel-like, 64-thread, 2 SALU (shift + idx) per draw", k_klike64_sw2, 64},
         {"kernel-like, 64-thread, 1 SALU (M0 write: round 5's draw) per draw", k_klike64_m0, 64},
+        {"kernel-like, 1 SALU (M0 write) per draw, 168-register waves: 3 per SIMD", k_klike64_m0_3w, 64, 3},
     };
     for (const KL &v : kl) {
-        const int waves = cus * 4 * 2, blocks = waves * 64 / v.threads;
+        if (quick && v.wps != 2) continue;
+        const int waves = cus * 4 * v.wps, blocks = waves * 64 / v.threads;
         hipLaunchKernelGGL(v.fn, dim3(blocks), dim3(v.threads), 0, 0, iters, 1.0000001f, out, cyc);
         CHECK(hipDeviceSynchronize());
         float ms = 1e30f;
@@ -258,8 +264,8 @@ int main(int argc, char **argv)
         }
         const double n_instr = (double)iters * INSTR_PER_ITER;
         const double chip = (double)waves * n_instr * 64 * 2 / (ms * 1e-3);
-        printf(",\n {\"variant\": \"%s\", \"waves_per_simd\": 2, \"T_lane_ops_per_s\": %.2f, \"cycles_per_wave_instr_at_2.4GHz\": %.3f, "
-               "\"s_memtime_ticks_per_wave_instr_per_simd\": 0, \"ms\": %.4f}", v.name, chip / 1e12, (ms * 1e-3) * 2.4e9 / (n_instr * 2), ms);
+        printf(",\n {\"variant\": \"%s\", \"waves_per_simd\": %d, \"T_lane_ops_per_s\": %.2f, \"cycles_per_wave_instr_at_2.4GHz\": %.3f, "
+               "\"s_memtime_ticks_per_wave_instr_per_simd\": 0, \"ms\": %.4f}", v.name, v.wps, chip / 1e12, (ms * 1e-3) * 2.4e9 / (n_instr * v.wps), ms);
     }
     // pool_reg_kernel's launch shape: how does a kernel of N single-wave, 256-register workgroups (the chip holds 2 048)
     // scale with N when one wave takes ~0.2 ms?  (tools/pool_reg_rounds.py: the kernel itself is 0.36 ms at 2 048 waves but
