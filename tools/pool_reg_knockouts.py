@@ -71,6 +71,11 @@ VARIANTS = {
     # round 5's loop has ONE scalar instruction per draw (the draw's M0 value straight out of a 16-bit table entry); without it
     # (index mode stays on with the first draw's index): what is that one still worth?
     "nom0": lambda s: sub(r'#define HI\(r\) .*', '#define HI(r) ""', sub(r'#define LO\(r\) .*', '#define LO(r) ""', s)),
+    # CORRECT variants of the one scalar instruction: the low half through s_set_gpr_idx_idx (M0[7:0] only; the enables were set by
+    # s_set_gpr_idx_on), and a s_nop behind every M0 write (does the indexed multiply wait on M0?)
+    "lowidx": lambda s: sub(r'#define LO\(r\) .*', lambda m: r'#define LO(r) "s_set_gpr_idx_idx s[" S(r) "]\n"', s),
+    "m0nop": lambda s: sub(r'#define HI\(r\) .*', lambda m: r'#define HI(r) "s_lshr_b32 m0, s[" S(r) "], 16\ns_nop 0\n"',
+                            sub(r'#define LO\(r\) .*', lambda m: r'#define LO(r) "s_sext_i32_i16 m0, s[" S(r) "]\ns_nop 0\n"', s)),
     # the scalar index loads of the round loop removed (stale registers)
     "noload": no_loop_loads,
     "pkonly": lambda s: no_loop_loads(VARIANTS["nom0"](s)),
