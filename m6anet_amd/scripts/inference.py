@@ -46,7 +46,7 @@ def argparser():
                              "validated against (torch + MKL on AVX-512) read probabilities are bit-identical to `m6anet inference` "
                              "wherever MKL groups a batch's rows in fours (every read of 20-read bags, > 99.9 %% of ragged ones); "
                              "activations beyond 2^64 saturate and a -inf pre-activation becomes NaN (DESIGN.md).  fast: the "
-                             "library's automatic choice, for bags of >= 16 reads a 12-slot kernel 9 %% faster and within 1e-5 "
+                             "library's automatic choice, for bags of >= 16 reads a 12-slot kernel 6 %% faster per step and within 1e-5 "
                              "relative of the reference.  The encoder is under 1 %% of this command's wall time either way.  "
                              "The environment variable M6A_ENCODER, if set, decides instead.")
     parser.add_argument("--drop_unflushed_tail", action="store_true",
