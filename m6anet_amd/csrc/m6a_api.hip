@@ -811,8 +811,6 @@ int launch_pool(m6a_ctx *c, const float *rp, const int64_t *off, int64_t S, int 
         if (rc) return rc;
         plan_args(c, a);
         a.tab = (const uint32_t *)c->tab_reg.p; a.uniform_n = (int)nmin; a.jmax = (int)gmax;
-        a.reg_gpad = (a.n_groups + 63) / 64 * 64;
-        HIPCHK(c, c->reg_out.ensure((size_t)a.jmax * a.reg_gpad * 5));
         if (dry) return M6A_OK;
         c->pool_variant = "table-reg";
         prof_begin(c, 1);
@@ -820,10 +818,7 @@ int launch_pool(m6a_ctx *c, const float *rp, const int64_t *off, int64_t S, int 
         // XCD takes a contiguous run of items (m6a_pool_reg.hip: the waves that share cache lines of read_prob share an L2)
         const int64_t wpj = (a.n_groups + 255) / 256;
         a.reg_items = wpj * a.jmax;
-        a.reg_site = (float *)c->reg_out.p;
-        a.reg_cnt = (uint8_t *)c->reg_out.p + (size_t)a.jmax * a.reg_gpad * 4;
         hipLaunchKernelGGL(pool_reg_kernel, dim3((unsigned)((a.reg_items + 7) / 8 * 8)), dim3(64), 0, c->stream, a);
-        hipLaunchKernelGGL(pool_reg_finish_kernel, dim3((unsigned)((a.n_groups + 31) / 32), (unsigned)((a.jmax + 31) / 32)), dim3(256), 0, c->stream, a);
         prof_end(c, 1);
     } else if (uniform && c->plan.max_merge <= 15) {
         rc = ensure_table(c, seed, (int)nmin, T, K, (int)gmax);
@@ -1212,7 +1207,7 @@ void m6a_destroy(m6a_ctx *c)
     for (void *p : c->graveyard) (void)hipFree(p);
     if (c->rt.C) (void)hipFree(c->rt.C);
     if (c->rt.RS) (void)hipFree(c->rt.RS);
-    for (DevBuf *b : {&c->ctl_dev, &c->rt_rank, &c->rt_order, &c->sOffChunk, &c->reg_out, &c->jX, &c->jP, &c->jOff, &c->gSite, &c->gMod, &c->gP, &c->mt_scratch}) b->release();
+    for (DevBuf *b : {&c->ctl_dev, &c->rt_rank, &c->rt_order, &c->sOffChunk, &c->jX, &c->jP, &c->jOff, &c->gSite, &c->gMod, &c->gP, &c->mt_scratch}) b->release();
     for (auto e : c->job.ev_h2d) (void)hipEventDestroy(e);
     for (auto e : c->job.ev_enc) (void)hipEventDestroy(e);
     release_staging(c);

@@ -221,7 +221,7 @@ struct m6a_ctx {
     uint32_t *h_hist = nullptr, *d_hist = nullptr;
     std::vector<uint32_t> hist_part;         // host_bag_range: eight interleaved histograms
     uint32_t *h_ctl = nullptr;                // [cursor HIST_BINS | slot_of_n MAX_N+1 | build_n MAX_N | build_slot MAX_N]
-    DevBuf ctl_dev, rt_rank, rt_order, reg_out;
+    DevBuf ctl_dev, rt_rank, rt_order;
     // m6a_infer runs the pooling's set-up on a side stream next to the encoder (pool_setup_aside)
     bool side_work = false;                   // something is queued on s_prep that the main stream does not wait for
     const int64_t *hint_off = nullptr;        // m6a_set_host_offsets: host copy of the next device call's off[]

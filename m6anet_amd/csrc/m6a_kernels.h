@@ -61,11 +61,6 @@ struct PoolArgs {
     // pool_reg_kernel: one control word per round of 8 iterations (bit 0 leaf ends, bits 8.. merges)
     const uint32_t *reg_ctl;
     int reg_rounds, reg_final_merges;
-    // pool_reg_kernel's results in (position j, flush group) order -- consecutive lanes write consecutive addresses --
-    // which pool_reg_finish_kernel transposes into site order
-    float *reg_site;              // [jmax][reg_gpad] site probability
-    uint8_t *reg_cnt;             // [jmax][reg_gpad] reads with p >= thr
-    int64_t reg_gpad;
     int64_t reg_items;            // pool_reg_kernel's work items: ceil(n_groups / 256) * jmax
     int *err;
     int64_t n_groups, n_sites, raw_len;
@@ -105,7 +100,6 @@ template <int KT> __global__ void pool_scan_group_kernel(PoolArgs a);
 template <int KT> __global__ void pool_scan_site_kernel(PoolArgs a);
 __global__ void pool_table_kernel(PoolArgs a);
 __global__ void pool_reg_kernel(PoolArgs a);
-__global__ void pool_reg_finish_kernel(PoolArgs a);
 __global__ void bag_noisy_or_kernel(const float *read_prob, int64_t n_bags, int bag, float *site_prob);
 __global__ void iota_off_kernel(int64_t *off, int64_t n_plus_1, int64_t step);
 __global__ void rebase_off_kernel(const int64_t *off, int64_t count, int64_t *out);

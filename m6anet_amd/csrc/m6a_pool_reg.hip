@@ -389,49 +389,20 @@ __global__ __launch_bounds__(64) void pool_reg_kernel(PoolArgs a)
           "v219", "v220", "v221", "v222", "v223", "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232",
           "v233", "v234", "v235", "v236", "v237", "v238", "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246",
           "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255");
-    // A lane's four sites are position j of four different flush groups, 32+ sites apart in site order: stored
-    // there directly every 4- or 8-byte result would dirty its own cache line (measured 6.5x write amplification).
-    // They go out in (j, group) order instead -- consecutive lanes, consecutive addresses -- and
-    // pool_reg_finish_kernel transposes 32 x 32 tiles into site_prob / mod_ratio.
+    // A lane's four sites are position j of four different flush groups, 32+ sites apart in site order, so every store
+    // instruction touches 64 cache lines with 4 or 8 bytes each.  Rounds 1-4 therefore wrote (position, group)-ordered
+    // staging arrays and a second kernel transposed them: with items dealt to the XCDs by blockIdx % jmax the 32 writers of
+    // a line sat in different XCDs and every partial line went to HBM on its own (75.9 MB written for 12 MB of output).
+    // With an XCD's items contiguous (above) the 32 waves that fill a line run in ONE XCD at the same time and its L2 merges
+    // them: WRITE_SIZE 12.8 MB for the 12 MB of output, no staging, no second kernel (profiles/r05_pool_reg_pmc.txt).
     const float o[4] = {o0, o1, o2, o3};
     const int cge[4] = {c0, c1, c2, c3};
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-        const int64_t g = g0 + q * 64 + lane;
-        if (g < a.n_groups) {
-            a.reg_site[(int64_t)j * a.reg_gpad + g] = o[q] / (float)a.T;
-            a.reg_cnt[(int64_t)j * a.reg_gpad + g] = (uint8_t)cge[q];
-        }
-    }
-}
-
-// [jmax][groups] -> site order: a 32 x 32 tile through LDS, reads and writes both in 128-byte runs;
-// mod_ratio = count / n in float64 (np.mean of a boolean array, inference_utils.py:53)
-__global__ __launch_bounds__(256) void pool_reg_finish_kernel(PoolArgs a)
-{
-    __shared__ float t_site[32][33];
-    __shared__ uint8_t t_cnt[32][36];
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    const int64_t g0 = (int64_t)blockIdx.x * 32;
-    const int j0 = (int)blockIdx.y * 32;
-#pragma unroll
-    for (int r = 0; r < 32; r += 8) {
-        const int j = j0 + r + ty;
-        const int64_t g = g0 + tx;
-        if (j < a.jmax && g < a.n_groups) {
-            t_site[r + ty][tx] = a.reg_site[(int64_t)j * a.reg_gpad + g];
-            t_cnt[r + ty][tx] = a.reg_cnt[(int64_t)j * a.reg_gpad + g];
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < 32; r += 8) {
-        const int64_t g = g0 + r + ty;
-        if (g >= a.n_groups) continue;
-        const int64_t s = a.goff[g] + j0 + tx;
-        if (j0 + tx < a.jmax && s < a.goff[g + 1]) {
-            a.site_prob[s] = t_site[tx][r + ty];
-            a.mod_ratio[s] = (double)t_cnt[tx][r + ty] / (double)a.uniform_n;
+        if (site[q] >= 0) {
+            a.site_prob[site[q]] = o[q] / (float)a.T;
+            // mod_ratio = count / n in float64 (np.mean of a boolean array, inference_utils.py:53)
+            a.mod_ratio[site[q]] = (double)cge[q] / (double)a.uniform_n;
         }
     }
 }
