@@ -258,8 +258,9 @@ int m6a_profile_read(m6a_ctx *ctx, int kind, double *total_ms, int64_t *n_launch
  * adds a site's six embedding terms and b1 pre-summed and sums the 32 -> 1 layer in register order.
  * Why auto is still the 12-slot kernel for bags >= 16 reads: it issues 106 MFMAs per 32-read tile against
  * 116, and both kernels now sit at the same 0.83-0.85 of the matrix peak in executed work, so the gap IS the instruction count --
- * 2.07 vs 2.22-2.26 ms per 20 M reads, 2.49 vs 2.63-2.70 ms per step (profiles/r05_step_by_encoder.json): 5.5-8 % per step, outside
- * the 6 % within which one default would have been the better trade.  Callers that want the reference's bits say so: mode 1, the
+ * 2.07 vs 2.21 ms per 20 M reads, 2.46-2.48 vs 2.61-2.63 ms per step (profiles/r05_step_by_encoder.json, r05_bench_default.json):
+ * 5.7-6.3 % per step, at the edge of the 6 % within which one default would have been the better trade -- and the headline of
+ * every earlier round was measured on the 12-slot kernel.  Callers that want the reference's bits say so: mode 1, the
  * CLI's --encoder reference (its default), or the environment variable M6A_ENCODER=general16|csite12|walk16, which preselects
  * 1 / 2 / 3 in every context the process creates. */
 int m6a_set_encoder_variant(m6a_ctx *ctx, int mode);
