@@ -14,7 +14,11 @@ _lib = None
 
 
 class M6AIOError(RuntimeError):
-    pass
+    """`code` = the M6A_IO_E* value the call returned (include/m6a_io.h: -1 EINVAL, -2 ENOMEM, -3 EIO, -4 EFORMAT)."""
+
+    def __init__(self, msg, code=None):
+        super().__init__(msg)
+        self.code = code
 
 
 def load():
@@ -74,7 +78,7 @@ def usable_cpus():
 
 def _chk(rc):
     if rc != 0:
-        raise M6AIOError("m6a_io error %d: %s" % (rc, load().m6a_io_last_error().decode()))
+        raise M6AIOError("m6a_io error %d: %s" % (rc, load().m6a_io_last_error().decode()), rc)
 
 
 def dataprep(eventalign, out_dir, n_threads=0, readcount_min=1, readcount_max=1000, min_segment_count=20,

@@ -1382,6 +1382,14 @@ static int dataprep_impl(const char *eventalign_path, const char *out_dir, int n
                          int readcount_min, int readcount_max, int min_segment_count, int n_neighbors,
                          int compress, int skip_index);
 
+// Test hook (tests/test_dataprep.py): M6A_IO_TEST_THROW=index|transcript|index_file makes that phase run out of memory once,
+// on whichever thread gets there first -- what the try/catch blocks below are for cannot be provoked reliably otherwise.
+static void test_throw(const char *where)
+{
+    static const char *want = getenv("M6A_IO_TEST_THROW");
+    if (want && !strcmp(want, where)) throw std::bad_alloc();
+}
+
 // No exception crosses the C ABI: the files this targets run to hundreds of GB, and the index (32 B per read run), the
 // per-transcript buffers and the writers' text can all exhaust memory -- that is M6A_IO_ENOMEM, not an aborted interpreter.
 extern "C" int m6a_io_dataprep(const char *eventalign_path, const char *out_dir, int n_threads,
@@ -1475,7 +1483,7 @@ static int dataprep_impl(const char *eventalign_path, const char *out_dir, int n
             cut[(size_t)k] = nl ? nl + 1 : end;
         }
         std::vector<IndexChunk> chunks((size_t)NC);
-        on_threads(nw, NC, [&](int k) { index_range(base, cut[(size_t)k], cut[(size_t)k + 1], chunks[(size_t)k]); });
+        on_threads(nw, NC, [&](int k) { if (k == NC / 2) test_throw("index"); index_range(base, cut[(size_t)k], cut[(size_t)k + 1], chunks[(size_t)k]); });
         trace.mark("dataprep: index ranges");
         for (const auto &c : chunks)
             if (c.rc) return fail(c.rc, "%s: short line at byte %lld", eventalign_path, (long long)c.bad_at);
@@ -1534,6 +1542,7 @@ static int dataprep_impl(const char *eventalign_path, const char *out_dir, int n
         const int nbg = std::max(1, nw / 4);
         idx_writer.th = std::thread([&idx, &tx_names, &idx_writer, fd, nbg, bounds = std::move(bounds)]() {
           try {
+            test_throw("index_file");
             static const char kIdxHeader[] = "transcript_id,read_index,pos_start,pos_end\n";
             int64_t file_off = (int64_t)sizeof(kIdxHeader) - 1;
             bool io_ok = ::pwrite(fd, kIdxHeader, sizeof(kIdxHeader) - 1, 0) == (ssize_t)(sizeof(kIdxHeader) - 1);
@@ -1642,6 +1651,7 @@ static int dataprep_impl(const char *eventalign_path, const char *out_dir, int n
                 if (failed) break;
             }
             std::unique_ptr<TxOut> o(new TxOut);
+            if (t == NT / 2) test_throw("transcript");
             preprocess_transcript(base, ev.n, tx_names[(size_t)t], idx, tx_rows[(size_t)t], readcount_min, readcount_max,
                                   min_segment_count, n_neighbors, compress, *o);
             std::vector<uint32_t>().swap(tx_rows[(size_t)t]);

@@ -270,3 +270,28 @@ def test_dataprep_edge_files(tmp_path):
     for tag in ("nonl", "crlf"):
         got, want = res[tag][1], res["nl"][1]
         assert got[1] == want[1] and all(np.array_equal(got[0][k][1], want[0][k][1]) for k in want[0])
+
+
+@pytest.mark.parametrize("phase", ["index", "transcript", "index_file"])
+def test_out_of_memory_on_any_thread_is_an_error_code_not_an_abort(eventalign, tmp_path, phase):
+    """ADVICE r4: m6a_io_dataprep runs its phases on std::threads; an exception on a worker would be std::terminate, one on the
+    calling thread would unwind through the C ABI.  M6A_IO_TEST_THROW makes the named phase throw std::bad_alloc once (the
+    index pass on a pool thread, the transcript pass on a worker, the index file on its background writer): the call must
+    return M6A_IO_ENOMEM, the process must live, and the library must work again afterwards."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from m6anet_amd import _io\n"
+            "try:\n"
+            "    _io.dataprep(%r, %r, n_threads=4)\n"
+            "    print('NO ERROR')\n"
+            "except _io.M6AIOError as e:\n"
+            "    print('RC', e.code)\n" % (repo, eventalign, str(tmp_path)))
+    env = dict(os.environ, M6A_IO_TEST_THROW=phase, M6A_IO_INDEX_RANGE_KB="16")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.returncode, r.stderr[-500:])           # alive: no std::terminate, no abort
+    assert r.stdout.strip() == "RC -2", (r.stdout, r.stderr[-500:])     # M6A_IO_ENOMEM
+    env.pop("M6A_IO_TEST_THROW")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip() == "NO ERROR", (r.stdout, r.stderr[-500:])
