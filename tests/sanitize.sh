@@ -2,13 +2,13 @@
 # SURVEY.md section 5 / VERDICT r3 item 8: AddressSanitizer + UndefinedBehaviorSanitizer builds of the host-side native code --
 # libm6a_io.so (loader, writers, dataprep), the oracle, tools/feed_probe, and the HOST half of libm6a_hip.so (device code is
 # not instrumented: -fno-gpu-sanitize) -- and the whole CPU test suite run against them.
-#   tests/sanitize.sh            -> profiles/r04_sanitizers.txt   (under tests/: it builds and runs the oracle, which is test infrastructure)
+#   tests/sanitize.sh            -> profiles/r05_sanitizers.txt (SAN_OUT overrides)   (under tests/: it builds and runs the oracle, which is test infrastructure)
 set -u
 cd "$(dirname "$0")/.."
 B=build/sanitize
 mkdir -p $B
 SAN="-fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer -g -O1"
-OUT=profiles/r04_sanitizers.txt
+OUT=${SAN_OUT:-profiles/r05_sanitizers.txt}
 {
 echo "== build ($(date -u +%Y-%m-%dT%H:%MZ), $(gcc --version | head -1))"
 set -x
