@@ -86,6 +86,12 @@ int m6a_set_host_offsets(m6a_ctx *ctx, const int64_t *off_host);
  * (copy threads + DMA); buffers the caller has page-locked (hipHostMalloc / hipHostRegister, torch's pin_memory()) are recognised
  * with hipPointerGetAttributes and DMA'd in place, chunk by chunk, in both directions -- same chunks, same kernels, same bits. */
 int m6a_prepare_host_io(m6a_ctx *ctx);
+/* Page-locked host memory (hipHostMalloc / hipHostFree) for callers with no other way to get it -- plain C, Python without
+ * torch: buffers from m6a_host_alloc are DMA'd in place by the host-pointer calls above.  No context needed (the HIP runtime
+ * must see a device).  Returns M6A_OK, M6A_ENOMEM or M6A_EHIP.  The reference's counterpart: DataLoader(pin_memory=...) is not
+ * used by m6anet/utils/data_utils.py -- its batches are pageable. */
+int m6a_host_alloc(size_t bytes, void **out);
+int m6a_host_free(void *p);
 
 /* Read encoder.  Replaces, for one batch of sites,
  *     model.get_read_representation({'X','kmer'}) + model.pooling_filter.probability_layer(.)

@@ -1291,6 +1291,25 @@ int m6a_prepare_host_io(m6a_ctx *c)
     return ensure_staging(c);
 }
 
+// Page-locked host memory for callers that have no other way to get it (plain C, Python without torch): buffers allocated here
+// are the ones the host-pointer calls DMA in place (m6a_host_ring.hip is_pinned_host).
+int m6a_host_alloc(size_t bytes, void **out)
+{
+    if (!out) return M6A_EINVAL;
+    *out = nullptr;
+    if (bytes == 0) return M6A_OK;
+    const hipError_t e = hipHostMalloc(out, bytes, hipHostMallocDefault);
+    if (e != hipSuccess) { (void)hipGetLastError(); *out = nullptr; return e == hipErrorOutOfMemory ? M6A_ENOMEM : M6A_EHIP; }
+    return M6A_OK;
+}
+
+int m6a_host_free(void *p)
+{
+    if (!p) return M6A_OK;
+    if (hipHostFree(p) != hipSuccess) { (void)hipGetLastError(); return M6A_EHIP; }
+    return M6A_OK;
+}
+
 int m6a_encode_reads(m6a_ctx *c, const float *X, const uint8_t *km, const int64_t *off, int64_t S, float *rp)
 {
     settle(c);

@@ -75,6 +75,22 @@ def _is_torch(x):
     return type(x).__module__.startswith("torch")
 
 
+def pinned_empty(shape, dtype=np.float32):
+    """A NumPy array in page-locked host memory (m6a_host_alloc): what the host-pointer calls DMA in place instead of copying
+    through the staging ring -- for callers without torch.  Freed when the array (and every view of it) is gone."""
+    import weakref
+    L = _lib.load()
+    dt = np.dtype(dtype)
+    n = int(np.prod(shape)) * dt.itemsize
+    p = C.c_void_p()
+    rc = L.m6a_host_alloc(max(n, 1), C.byref(p))
+    if rc != 0:
+        raise _lib.M6AError(rc, "m6a_host_alloc(%d bytes)" % n)
+    buf = (C.c_char * max(n, 1)).from_address(p.value)
+    weakref.finalize(buf, L.m6a_host_free, C.c_void_p(p.value))
+    return np.frombuffer(buf, dtype=dt, count=int(np.prod(shape))).reshape(shape)
+
+
 class _Arg:
     """Pointer + keep-alive for one array argument."""
 

@@ -904,6 +904,28 @@ def test_pinned_host_buffers_skip_the_staging_copy_same_bits(engines):
     assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
 
 
+def test_pinned_numpy_arrays_without_torch(engines):
+    """engine.pinned_empty (m6a_host_alloc): page-locked NumPy arrays for callers without torch -- the same in-place DMA path, the
+    same bits; freeing follows the array's lifetime."""
+    from m6anet_amd.engine import pinned_empty
+    eng = engines["hct116"]
+    eng.prepare_host_io()
+    d = synthetic.make_sites(40_000, (20, 60), seed=13)
+    R, S = int(d["off"][-1]), 40_000
+    want = eng.infer(d["X"], d["site_kmers"], d["off"], 30)
+    X, km, off = pinned_empty((R, 9), np.float32), pinned_empty((S, 3), np.uint8), pinned_empty(S + 1, np.int64)
+    X[:], km[:], off[:] = d["X"], d["site_kmers"], d["off"]
+    outs = (pinned_empty(R, np.float32), pinned_empty(S, np.float32), pinned_empty(S, np.float64))
+    for o in outs:
+        o[:] = -1
+    got = eng.infer(X, km, off, 30, out=outs)
+    assert all(np.array_equal(g, w) for g, w in zip(got, want))
+    view = outs[0][10:20]
+    del outs, got                                                   # the view keeps the allocation alive
+    assert np.array_equal(view, want[0][10:20])
+    assert pinned_empty(0, np.float32).size == 0
+
+
 def test_infer_equals_encode_then_pool_for_every_pooling_kernel(engines):
     """m6a_infer sets the pooling up on a side stream while the encoder runs (a dry launch_pool); whatever kernel the
     pooling takes -- forced scan drivers, index tables, both uniform-bag kernels -- the fused call must give what
