@@ -115,8 +115,9 @@ def launch(args, weights):
     dirs = [str(d) for d in args.input_dir]
     if st is not None and (st["world"] != world or st["input_dirs"] != dirs or st["out_dir"] != str(args.out_dir)
                            or st["argv"] != _early.strip_command(sys.argv[1:])):
-        # the hand-parsed command line of the early start is not what argparse made of it (abbreviated options, `=` forms
-        # it does not know): those ranks would run another job -- end them, start again from the parsed arguments
+        # the hand-parsed command line of the early start is not what argparse made of it (an option given twice: argparse keeps
+        # the last, the hand parser saw the first; the CLI called as a function with another argv): those ranks wait for a store
+        # nobody will write, or run another job -- end them, start again from the parsed arguments
         _early.cleanup()
         st = None
     if st is None:
