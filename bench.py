@@ -38,8 +38,8 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC for RC
 
 ENC_FLOP_PER_READ = 14164      # 2*(15*150 + 150*32 + 32)           SURVEY.md section 8(d)
 ENC_BYTES_PER_READ = 40        # 9 f32 in + 1 f32 out               SURVEY.md section 8(d)
-# what the kernels EXECUTE per read: v_mfma_f32_32x32x2_f32 = 4096 FLOP for a tile of 32 reads; the 12-slot kernel issues 106 of
-# them per tile (30 layer 1 + 76 layer 2), the two 16-slot kernels 116 (40 + 76) -- padding of 150 hidden units to 160 rows included,
+# what the kernels EXECUTE per read: v_mfma_f32_32x32x2_f32 = 4096 FLOP for a tile of 32 reads; the two 16-slot kernels (auto) issue
+# 116 of them per tile (40 layer 1 + 76 layer 2), the opt-in 12-slot kernel 106 (30 + 76) -- padding of 150 hidden units to 160 rows included,
 # the 32 -> 1 layer and the embedding fold (VALU) not
 ENC_MFMA_PER_TILE = {"enc_csite_kernel": 106, "enc_site16_kernel": 116, "enc_kernel": 116}
 PEAK_F32_TFLOPS = 157.3        # MI355X_MICROARCH.md: f32 MFMA = f32 vector peak
@@ -74,6 +74,29 @@ def pool_roofline(variant, draws, avg_ms, launches):
             "draws_per_launch": draws}
 
 
+NOMINAL_GHZ = 2.4
+
+
+def at_measured_clock(roof, clk):
+    """`peak` assumes the 2.4 GHz maximum clock; a kernel that draws enough power makes the part clock lower,
+    and `frac` then mixes that with issue loss.  clk = the shader clock the kernel's own waves lived at (s_memtime over
+    s_memrealtime, stamped by lane 0 of up to 64 workgroups of the last profiled launch: m6a_profile_clock).  Adds the clock,
+    the peak at that clock and the fraction of THAT peak; `peak` / `frac` stay nominal (comparable across rounds)."""
+    if not clk or not roof.get("achieved"):
+        roof["clock_ghz_measured"] = None
+        return roof
+    g = clk["ghz"]
+    roof["clock_ghz_measured"] = g
+    roof["clock_detail"] = dict(clk, nominal_ghz=NOMINAL_GHZ,
+                                source="in-kernel: s_memtime / s_memrealtime of %d stamped waves of the last profiled launch "
+                                       "(median; span_ms = first start to last end of those waves)" % clk["waves"])
+    roof["peak_at_measured_clock"] = roof["peak"] * g / NOMINAL_GHZ
+    roof["frac_at_measured_clock"] = roof["achieved"] / roof["peak_at_measured_clock"]
+    if "achieved_executed" in roof:
+        roof["frac_executed_at_measured_clock"] = roof["achieved_executed"] / roof["peak_at_measured_clock"]
+    return roof
+
+
 WORKLOADS = {
     "uniform": dict(model="HCT116_RNA002", sites=1_000_000, bag=20, config="BASELINE.json configs[2]"),
     "ragged": dict(model="HEK293T_RNA004", sites=125_000, bag=(50, 500), config="BASELINE.json configs[4] per-GPU shape"),
@@ -97,7 +120,7 @@ def measured_traffic(S, bag):
     return best
 
 
-def live_traffic(workload, kernel_name, pool_kernel_name=None, timeout_s=240):
+def live_traffic(workload, kernel_name, pool_kernel_name=None, timeout_s=240, enc_variant=0):
     """HBM bytes per encoder launch measured NOW: two short re-runs of this script under
     `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, --kernel-trace only, as
     MI355X_MICROARCH.md prescribes), read back from the rocpd database.  FETCH_SIZE x2: gfx950 tallies the 128-byte
@@ -113,7 +136,8 @@ def live_traffic(workload, kernel_name, pool_kernel_name=None, timeout_s=240):
         d = tempfile.mkdtemp(prefix="m6a_pmc_")
         try:
             cmd = ["rocprofv3", "--pmc", ctr, "--kernel-trace", "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
-                   "--workload", workload, "--steps", "3", "--warmup", "1", "--min-seconds", "0", "--no-cpu-baseline", "--no-live-traffic", "--no-ragged-extra"]
+                   "--workload", workload, "--steps", "3", "--warmup", "1", "--min-seconds", "0", "--no-cpu-baseline", "--no-live-traffic", "--no-ragged-extra",
+                   "--enc-variant", str(enc_variant)]
             subprocess.run(cmd, capture_output=True, timeout=timeout_s, env=dict(os.environ, TMPDIR=os.environ.get("TMPDIR", "/tmp")))
             dbs = glob.glob(os.path.join(d, "**", "*_results.db"), recursive=True)
             if not dbs:
@@ -598,9 +622,11 @@ class Bench:
             gather_ms, _ = self.gather.exchange_ms()
             self.gather.timing = False
         enc_ms, enc_n = eng.profile_read(0)
+        enc_clk = eng.profile_clock(0)                       # in-kernel stamps of the region's last encoder launch
         eng.profile("pooling")
         self.timed(min(steps, 10))
         pool_ms, pool_n = eng.profile_read(1)
+        pool_clk = eng.profile_clock(1)
         eng.profile(False)
         eng.sync()
         sustained = None
@@ -624,6 +650,7 @@ class Bench:
             sustained = {"seconds": t_all, "steps": n_done, "ms_per_step": t_all / n_done * 1e3, "rocm_smi_under_load": smi}
         dt, first_call_ms = self.max_over_ranks(dt, first_call_ms)
         return {"dt": dt, "first_call_ms": first_call_ms, "second_call_ms": second_call_ms, "enc_ms": enc_ms, "enc_n": enc_n, "pool_ms": pool_ms, "pool_n": pool_n,
+                "enc_clk": enc_clk, "pool_clk": pool_clk,
                 "sustained": sustained, "own_ms_per_step": own_dt / steps * 1e3, "gather_ms_per_step": gather_ms}
 
     def certify(self, r, local_ms):
@@ -705,7 +732,7 @@ class Bench:
         if world == 1 and traffic:
             default_shape = S == spec["sites"] and T == 1000 and (self.workload == "ragged" or bag == spec["bag"])
             if default_shape and not args.no_live_traffic:
-                tr = live_traffic(self.workload, enc_kernel, pool_kernel)
+                tr = live_traffic(self.workload, enc_kernel, pool_kernel, enc_variant=args.enc_variant)
             if tr is None:
                 tr = measured_traffic(S, bag)
                 if tr is not None:
@@ -756,11 +783,12 @@ class Bench:
                          "algorithmic_flop_per_read": ENC_FLOP_PER_READ, "reads_per_launch": R,
                          "hbm_view": {"achieved": enc_gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                                       "frac": enc_gbps / PEAK_HBM_GBPS, "algorithmic_bytes_per_read": ENC_BYTES_PER_READ}},
-            "pool_roofline": proof,
+            "pool_roofline": at_measured_clock(proof, r.get("pool_clk")),
             "kernels": {enc_kernel: {"avg_ms": enc_avg_ms, "launches": r["enc_n"]},
                         pool_kernel: {"avg_ms": pool_avg_ms, "launches": r["pool_n"], "timed_in": "extra steps after the timed region",
                                       "Gdraws_per_s": draws / (pool_avg_ms * 1e-3) / 1e9 if pool_avg_ms else None}},
         }
+        at_measured_clock(out["roofline"], r.get("enc_clk"))
         if r["sustained"]:
             su = r["sustained"]
             out["value_sustained"] = total_sites * su["steps"] / su["seconds"]
@@ -779,8 +807,14 @@ class Bench:
                 "bag_statistics": "host copy of off[] per step, device-checked (m6a_set_host_offsets)" if self.host_offsets else "read back per step",
                 "pool_kernel": self.eng.last_pool_variant, "encoder_kernel": self.eng.last_encoder_variant,
                 "encoder_kernel_function": self.eng.last_encoder_kernel,
-                "cli_default_encoder": "general16 (`m6anet_amd inference --encoder reference`: enc_site16_kernel on bags >= 16 reads, enc_kernel "
-                                       "otherwise; --encoder fast = the library's automatic choice, which this line's headline runs)",
+                # ONE encoder for the product and the headline: the library's automatic choice, the CLI's default
+                # and this line's timed region are the same kernel -- tests/test_gpu_stream.py asserts it
+                "library_auto_encoder": "general16 (m6a_set_encoder_variant 0: enc_site16_kernel on bags >= 16 reads, enc_kernel otherwise)",
+                "cli_default_encoder": "general16 (`m6anet_amd inference`, = --encoder reference: the library's automatic choice; the reference's "
+                                       "float32 operations in its order, read probabilities bit-identical to the oracle; --encoder fast = "
+                                       "the opt-in 12-slot kernel, key fast_encoder_optin)",
+                "encoder_selected_by": {0: "auto (library default)", 1: "--enc-variant 1", 2: "--enc-variant 2 (12-slot, opt-in)",
+                                        3: "--enc-variant 3", 4: "--enc-variant 4 (fast, opt-in)"}[self.args.enc_variant],
                 "sharding": "contiguous flush-group-aligned site shards balanced by reads, 1 gather of site_prob + mod_ratio to rank 0 per step "
                             "over %s" % self.gather_kind if self.gather is not None else "none"}
 
@@ -804,7 +838,9 @@ def main():
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="do not re-run under rocprofv3 for roofline.traffic; quote the committed profiles/*_enc_traffic.json instead")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--enc-variant", type=int, default=0, help="0 auto, 1 general 16-slot, 2 12-slot encoder kernel")
+    ap.add_argument("--enc-variant", type=int, default=0,
+                    help="m6a_set_encoder_variant: 0 auto = the 16-slot kernels (the reference's bits; what the CLI runs), 1 the same, "
+                         "2 the 12-slot kernel, 3 16-slot per-lane walk, 4 fast (12-slot where it applies)")
     ap.add_argument("--scan-driver", type=int, default=0, help="ragged bags: 0 auto, 1 per group, 2 per site, 3 index tables")
     ap.add_argument("--verify", action="store_true",
                     help="after the timed steps rank 0 recomputes the WHOLE job unsharded on its GPU and checks that the gathered "
@@ -961,11 +997,12 @@ def run(args, line, rank, world, local_rank, S, bag, T):
                 except Exception as e:                      # noqa: BLE001
                     line[name + "_error"] = "%s: %s" % (type(e).__name__, str(e)[:300])
 
-            def leg_product_default():
-                # the same workload on the 16-slot encoder -- the kernel whose read probabilities are the reference's bit for bit:
-                # what `m6anet_amd inference` and INTEGRATION.md's stub run by default (the timed region above used the library's
-                # automatic choice, the 12-slot kernel) -- with its own roofline from HIP events around its launches
-                b.eng.set_encoder_variant(1)
+            def leg_fast_encoder():
+                # the same workload on the OPT-IN 12-slot encoder (m6a_set_encoder_variant(4), `--encoder fast`): 106 MFMAs per
+                # tile instead of 116, read probabilities within rtol 1e-5 of the reference instead of its bits.  The headline
+                # above is the library's automatic choice -- the kernel the CLI, INTEGRATION.md's stub and every caller that
+                # sets nothing run; this key says what the opt-in buys, with its own roofline from HIP events around its launches
+                b.eng.set_encoder_variant(4)
                 for _ in range(3):
                     b.compute()
                 legs = []
@@ -981,26 +1018,26 @@ def run(args, line, rank, world, local_rank, S, bag, T):
                 for _ in range(10):
                     b.compute()
                 k_ms, k_n = b.eng.profile_read(0)
+                k_clk = b.eng.profile_clock(0)
                 b.eng.profile(False)
                 kern = b.eng.last_encoder_kernel
                 k_avg = k_ms / max(k_n, 1)
                 ex = ENC_MFMA_PER_TILE[kern] * 4096 // 32
                 tf, tfx = (f * b.R / (k_avg * 1e-3) / 1e12 for f in (ENC_FLOP_PER_READ, ex))
-                line["reference_order_encoder"] = {
+                line["fast_encoder_optin"] = {
                     "encoder_kernel": b.eng.last_encoder_variant, "kernel": kern, "ms_per_step": ms, "value": b.Sr / (ms * 1e-3), "steps": 10, "warmup": 3,
                     "ms_per_step_of_each_leg": legs,
-                    "note": "same workload, m6a_set_encoder_variant(1): every float32 operation of the reference's encoder in the "
-                            "reference's order (DESIGN.md section 2) -- read and site probabilities bit-identical to the reference's on "
-                            "this workload's bags; the headline above runs the 12-slot kernel (within 1e-5 relative)"}
-                line["roofline_product_default"] = {
-                    "kernel": "read encoder (%s: %s) -- what `m6anet_amd inference` (--encoder reference, its default) and "
-                              "INTEGRATION.md's stub launch on this workload" % (b.eng.last_encoder_variant, kern),
-                    "bound": "mfma", "achieved": tf, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_F32_TFLOPS,
-                    "traffic": None, "avg_launch_ms": k_avg, "launches": k_n, "algorithmic_flop_per_read": ENC_FLOP_PER_READ,
-                    "executed_flop_per_read": ex, "mfma_per_32_read_tile": ENC_MFMA_PER_TILE[kern], "achieved_executed": tfx,
-                    "frac_executed": tfx / PEAK_F32_TFLOPS, "reads_per_launch": b.R,
-                    "timed_in": "10 extra steps after reference_order_encoder's, HIP events around every launch"}
-                b.eng.set_encoder_variant(0)
+                    "note": "same workload, m6a_set_encoder_variant(4) / `m6anet_amd inference --encoder fast` / M6A_ENCODER=fast: the 12-slot "
+                            "kernel (per-site constants pre-summed, plain 32 -> 1 sum; within rtol 1e-5 of the reference, not its bits). "
+                            "NOT the headline: `value` above runs the automatic choice, the 16-slot kernel",
+                    "roofline": at_measured_clock({
+                        "kernel": "read encoder (%s: %s), opt-in" % (b.eng.last_encoder_variant, kern),
+                        "bound": "mfma", "achieved": tf, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_F32_TFLOPS,
+                        "traffic": None, "avg_launch_ms": k_avg, "launches": k_n, "algorithmic_flop_per_read": ENC_FLOP_PER_READ,
+                        "executed_flop_per_read": ex, "mfma_per_32_read_tile": ENC_MFMA_PER_TILE[kern], "achieved_executed": tfx,
+                        "frac_executed": tfx / PEAK_F32_TFLOPS, "reads_per_launch": b.R,
+                        "timed_in": "10 extra steps after the three legs, HIP events around every launch"}, k_clk)}
+                b.eng.set_encoder_variant(args.enc_variant)
 
             def leg_ragged():
                 # the path real data takes (bags are never uniform), in the same record: configs[4]'s per-GPU shape
@@ -1016,8 +1053,8 @@ def run(args, line, rank, world, local_rank, S, bag, T):
                 line["ragged"] = rg
                 rb.eng.close()
 
-            optional("roofline_product_default", leg_product_default)
-            b.eng.set_encoder_variant(0)
+            optional("fast_encoder_optin", leg_fast_encoder)
+            b.eng.set_encoder_variant(args.enc_variant)
             line["with_h2d"] = with_h2d(b, T)
             optional("ragged", leg_ragged)
         if world == 1 and not args.no_cpu_baseline:

@@ -40,7 +40,13 @@ enum {
     M6A_EUNSUPPORTED = -6
 };
 
-enum { M6A_RNG_NUMPY = 0 /* exact replay of the reference's NumPy stream */ };
+/* rng_mode of m6a_site_pool / m6a_infer / m6a_job_begin.  M6A_RNG_NUMPY is the ONLY value: exact replay of the reference's
+ * NumPy MT19937 stream -- the only sampler the reference has (np.random.choice at m6anet/utils/inference_utils.py:85, seeded at
+ * scripts/inference.py:86).  The parameter stays in the three signatures because SURVEY.md section 8(b) fixed them; any other
+ * value is M6A_EINVAL (a bad argument, not a missing feature: no counter-based mode is planned -- it could not meet the 1e-5
+ * bar against the reference's draws, and indices are table reads in both pooling kernels, so it would not be faster either;
+ * DESIGN.md section 8). */
+enum { M6A_RNG_NUMPY = 0 };
 
 #define M6A_N_WEIGHTS 7997
 #define M6A_N_FEATURES 9     /* [dwell, std, mean] x {-1,0,+1}: DeaggregateNanopolish, blocks.py:113 */
@@ -256,21 +262,34 @@ int m6a_random_stream(m6a_ctx *ctx, uint32_t seed, int64_t n_words, uint32_t *wo
  * timed launch cost ~5 us each on the stream).  m6a_profile_read synchronises the stream. */
 int m6a_profile_enable(m6a_ctx *ctx, int on);
 int m6a_profile_read(m6a_ctx *ctx, int kind, double *total_ms, int64_t *n_launches);
-/* Tuning knob for the read encoder: 0 = auto (default), 1 = the 16-slot kernels (any bags), 2 = 12-slot kernel (per-site
- * constants folded; requires every bag >= 16 reads -- a call that violates this reports M6A_EINVAL at the next sync), 3 = the
- * 16-slot arithmetic behind the per-lane walk of off[] even where the scalar site chain would do (A/B and tests).  Results agree
- * to float32 rounding: the 16-slot kernels perform the reference's float32 operations in the reference's order all the way (their
- * read probabilities are those of torch on an AVX-512 host, bit for bit, for every read of a 20-read-bag job); the 12-slot kernel
- * adds a site's six embedding terms and b1 pre-summed and sums the 32 -> 1 layer in register order.
- * Why auto is still the 12-slot kernel for bags >= 16 reads: it issues 106 MFMAs per 32-read tile against
- * 116, and both kernels now sit at the same 0.83-0.85 of the matrix peak in executed work, so the gap IS the instruction count --
- * 2.07 vs 2.21 ms per 20 M reads, 2.46-2.48 vs 2.61-2.63 ms per step (profiles/r05_step_by_encoder.json, r05_bench_default.json):
- * 5.7-6.3 % per step, at the edge of the 6 % within which one default would have been the better trade -- and the headline of
- * every earlier round was measured on the 12-slot kernel.  Callers that want the reference's bits say so: mode 1, the
- * CLI's --encoder reference (its default), or the environment variable M6A_ENCODER=general16|csite12|walk16, which preselects
- * 1 / 2 / 3 in every context the process creates. */
+/* The shader clock the LAST profiled launch of `kind` ran at, from inside the kernel: while profiling is on, lane 0 of up to
+ * 64 workgroups spread over the grid (and over the 8 XCDs) stamps s_memtime (shader cycles) and s_memrealtime (constant
+ * 100 MHz) at its start and end; GHz = cycles / real time of each such wave.  bench.py prices the rooflines at this clock
+ * beside the nominal 2.4 GHz (a kernel that makes the part clock down is not an issue-limited kernel).  span_ms = first start
+ * to last end among the stamped waves (a cross-check of the HIP-event duration).  Any out pointer may be NULL; n_waves = 0
+ * when nothing was stamped (no profiled launch yet; kernels without stamps: the scan and LDS-table pooling fallbacks).
+ * Launches outside profiling carry a null stamp pointer. */
+int m6a_profile_clock(m6a_ctx *ctx, int kind, double *ghz_median, double *ghz_min, double *ghz_max, double *span_ms, int *n_waves);
+/* Which read-encoder kernel runs.  0 = auto (default) = the REFERENCE'S BITS on every input: the 16-slot kernels perform the
+ * reference's float32 operations in the reference's order all the way (layer sums as fma chains over k then the bias, batch
+ * norm as one fma, the 32 -> 1 layer in the capture machine's sgemv order, Sleef's expf: blocks.py:249-254, pooling_blocks.py:52
+ * as torch executes them on an AVX-512 host) -- enc_site16_kernel when every bag has >= 16 reads and the job fits 32-bit
+ * indices, enc_kernel otherwise; same operations, same bits.  This is what the CLI (`--encoder reference`, its default),
+ * INTEGRATION.md's stub, bench.py's headline and every caller that sets nothing get: ONE kernel family for the product and
+ * the quoted number.
+ *   1 = the same, said explicitly;   3 = the 16-slot arithmetic behind enc_kernel's per-lane walk even where the scalar site
+ *   chain would do (A/B and tests);
+ *   2 = the 12-slot kernel, strictly (every bag must have >= 16 reads: a call that violates this reports M6A_EINVAL at the
+ *   next sync);   4 = "fast": the 12-slot kernel where every bag has >= 16 reads, the 16-slot kernels elsewhere.
+ * The 12-slot kernel (enc_csite_kernel) is OPT-IN: it issues 106 MFMAs per 32-read tile instead of 116 (2.07 vs 2.21 ms per
+ * 20 M reads, 5-6 % per step) by adding a site's six embedding terms and b1 pre-summed and summing the 32 -> 1 layer in
+ * register order -- two departures from the reference's order.  Its read probabilities are within the reference test's
+ * rtol 1e-5 / atol 1e-8 (m6anet/tests/test_inference.py:32) on every fixture and on 218 M reads of the full-size configs; a
+ * random fuzz found 4 reads of 20 G at up to 1.005 x that bar (all far inside north_star's absolute 1e-5).
+ * The environment variable M6A_ENCODER=auto|reference|general16|csite12|walk16|fast preselects 0 / 0 / 1 / 2 / 3 / 4 in every
+ * context the process creates; any other value makes m6a_create fail with M6A_EINVAL. */
 int m6a_set_encoder_variant(m6a_ctx *ctx, int mode);
-const char *m6a_last_encoder_variant(const m6a_ctx *ctx);   /* "general16" | "csite12" */
+const char *m6a_last_encoder_variant(const m6a_ctx *ctx);   /* "general16" (auto, 1, 3) | "csite12" (2, 4 where it applies) */
 /* The __global__ function the last encode launched: "enc_site16_kernel" (16 slots, scalar 32-bit site chain: every bag
  * >= 16 reads), "enc_kernel" (16 slots, per-lane 64-bit walk: any bags; mode 3 forces it), "enc_csite_kernel" (12 slots).
  * The two 16-slot kernels perform the same float32 operations: same bits. */

@@ -683,17 +683,20 @@ int launch_encode(m6a_ctx *c, const float *X, const uint8_t *km, const int64_t *
     a.X = X; a.site_kmers = km; a.off = off; a.wfrag = c->d_wfrag; a.emb = c->d_emb; a.read_prob = rp;
     a.wfrag2 = c->d_wfrag2; a.w1e_tab = c->d_w1e; a.bn = c->d_w1e + M6A_W1E_FLOATS; a.err = c->d_err;
     a.n_sites = S; a.n_reads = R; a.n_tiles = (R + 31) / 32; a.b3 = c->b3;
+    a.clk = c->prof.clk_for(0);
     const int64_t max_waves = (int64_t)c->n_cu * 8;        // 2 blocks/CU x 4 waves
     a.tiles_per_wave = (a.n_tiles + max_waves - 1) / max_waves;
     const int64_t waves = (a.n_tiles + a.tiles_per_wave - 1) / a.tiles_per_wave;
     const unsigned blocks = (unsigned)((waves + 3) / 4);
     // every bag >= 16 reads: a 32-read tile spans <= 3 sites, and the site lookup is the scalar 32-bit chain of
-    // enc_csite_kernel (12-slot layer 1, 106 MFMAs per tile) / enc_site16_kernel (the reference's 16 slots, 116);
-    // otherwise enc_kernel: the same 16-slot arithmetic behind a per-lane 64-bit walk of off[]
+    // enc_site16_kernel (the reference's 16 slots, 116 MFMAs per tile: auto) / enc_csite_kernel (12-slot layer 1, 106: opt-in);
+    // otherwise enc_kernel: the same 16-slot arithmetic behind a per-lane 64-bit walk of off[].
+    // auto (0) and mode 1 are the reference's float32 operations in the reference's order on EVERY input; the 12-slot kernel runs
+    // only for callers that asked for it: mode 2 (strict: every bag must have >= 16 reads) or mode 4 ("fast": where it applies).
     const bool fits32 = S < 0x7ffffff0LL && a.n_tiles < 0x7ffffff0LL;
     if (c->enc_variant == 2 && !fits32) return fail(c, M6A_EUNSUPPORTED, "12-slot encoder: more than 2^31 sites or tiles");
     const bool scalar_chain = c->bag_min >= M6A_CSITE_MIN_BAG && fits32;
-    const bool csite = c->enc_variant ? c->enc_variant == 2 : scalar_chain;
+    const bool csite = c->enc_variant == 2 || (c->enc_variant == 4 && scalar_chain);
     const bool site16 = !csite && c->enc_variant != 3 && scalar_chain;
     c->enc_variant_used = csite ? "csite12" : "general16";
     c->enc_kernel_used = csite ? "enc_csite_kernel" : site16 ? "enc_site16_kernel" : "enc_kernel";
@@ -798,6 +801,7 @@ int launch_pool(m6a_ctx *c, const float *rp, const int64_t *off, int64_t S, int 
     memset(&a, 0, sizeof a);
     a.read_prob = rp; a.off = off; a.goff = (const int64_t *)c->goff.p; a.site_prob = site; a.mod_ratio = mod;
     a.err = c->d_err; a.n_groups = c->goff_key.G; a.n_sites = S; a.T = T; a.K = K; a.thr = thr;
+    a.clk = dry ? nullptr : c->prof.clk_for(1);
     const int64_t gmax = c->goff_key.gmax;
 
     rc = ensure_mean_plan(c, T);
@@ -997,7 +1001,7 @@ int check_pool_args(m6a_ctx *c, int64_t S, int T, int K, int rng_mode, int64_t b
     if (T < 1) return fail(c, M6A_EINVAL, "n_iters must be >= 1");
     if (K < 1 || K > M6A_MAX_SAMPLES) return fail(c, M6A_EINVAL, "n_samples must be in 1..%d", M6A_MAX_SAMPLES);
     if ((int64_t)T * K > 0x3fffffff) return fail(c, M6A_EINVAL, "n_iters*n_samples too large");
-    if (rng_mode != M6A_RNG_NUMPY) return fail(c, M6A_EUNSUPPORTED, "rng_mode %d not supported", rng_mode);
+    if (rng_mode != M6A_RNG_NUMPY) return fail(c, M6A_EINVAL, "rng_mode %d: M6A_RNG_NUMPY (0) is the only value (include/m6a.h)", rng_mode);
     if (bs < 1 || spb < 1) return fail(c, M6A_EINVAL, "batch_size and save_per_batch must be >= 1");
     return M6A_OK;
 }
@@ -1100,6 +1104,18 @@ int m6a_create(m6a_ctx **out, const float *weights, size_t n_floats, int device_
     for (int i = O_W2; i < O_W3; i++)
         if (std::isfinite(weights[i]) && std::fabs(weights[i]) >= 0x1p+63f)
             return fail(nullptr, M6A_EUNSUPPORTED, "layer-2 weight %d is %g: beyond 2^63 in magnitude", i - O_W2, (double)weights[i]);
+    // M6A_ENCODER=general16 | csite12 | walk16 | fast: the context starts with that encoder selected (m6a_set_encoder_variant
+    // 1 / 2 / 3 / 4) -- for callers that cannot be changed.  A value that is none of these is refused, not ignored: a typo must
+    // not silently select another kernel.
+    int env_enc = 0;
+    if (const char *ev = getenv("M6A_ENCODER")) {
+        if (!*ev || !strcmp(ev, "auto") || !strcmp(ev, "reference")) env_enc = 0;
+        else if (!strcmp(ev, "general16")) env_enc = 1;
+        else if (!strcmp(ev, "csite12")) env_enc = 2;
+        else if (!strcmp(ev, "walk16")) env_enc = 3;
+        else if (!strcmp(ev, "fast")) env_enc = 4;
+        else return fail(nullptr, M6A_EINVAL, "M6A_ENCODER=%s: must be auto, reference, general16, csite12, walk16 or fast", ev);
+    }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
         (void)hipGetLastError();
@@ -1156,13 +1172,7 @@ int m6a_create(m6a_ctx **out, const float *weights, size_t n_floats, int device_
     CRCHK(hipHostMalloc((void **)&c->h_ctl, kCtlWords * 4, hipHostMallocDefault));
     for (int n = 0; n <= M6A_RTAB_MAX_N; n++) c->rt.slot_of_n[n] = -1;
 #undef CRCHK
-    // M6A_ENCODER=general16 | csite12: the context starts with that encoder kernel selected (m6a_set_encoder_variant 1 / 2)
-    // -- for callers that cannot be changed, e.g. to run the CLI on the 16-slot kernel, whose layers 1-2 are the reference's bits
-    if (const char *ev = getenv("M6A_ENCODER")) {
-        if (!strcmp(ev, "general16")) c->enc_variant = 1;
-        else if (!strcmp(ev, "csite12")) c->enc_variant = 2;
-        else if (!strcmp(ev, "walk16")) c->enc_variant = 3;
-    }
+    c->enc_variant = env_enc;
     const char *w = getenv("M6A_WARMUP");
     if (!(w && w[0] == '0')) {
         try { c->warm = std::thread(warm_default, c); } catch (...) { /* no thread: the first call sets up what it needs */ }
@@ -1193,6 +1203,7 @@ void m6a_destroy(m6a_ctx *c)
     }
     for (DevBuf *b : {&c->raw, &c->tab, &c->goff, &c->rp_scratch, &c->off_scratch, &c->start_pos, &c->plan_dev, &c->tab_reg, &c->val_idx, &c->val_y, &c->val_avg, &c->sX, &c->sK, &c->sOff,
                       &c->sP, &c->sSite, &c->sMod}) b->release();
+    if (c->prof.d_clk) (void)hipFree(c->prof.d_clk);
     if (c->d_wfrag) (void)hipFree(c->d_wfrag);
     if (c->d_wfrag2) (void)hipFree(c->d_wfrag2);
     if (c->d_w1e) (void)hipFree(c->d_w1e);
@@ -1250,8 +1261,8 @@ int m6a_set_job_offset(m6a_ctx *c, int64_t first_site)
 int m6a_set_encoder_variant(m6a_ctx *c, int mode)
 {
     if (!c) return M6A_EINVAL;
-    if (mode < 0 || mode > 3)
-        return fail(c, M6A_EINVAL, "encoder variant must be 0 (auto), 1 (16-slot), 2 (12-slot) or 3 (16-slot, per-lane walk)");
+    if (mode < 0 || mode > 4)
+        return fail(c, M6A_EINVAL, "encoder variant must be 0 (auto: 16-slot), 1 (16-slot), 2 (12-slot), 3 (16-slot, per-lane walk) or 4 (fast: 12-slot where every bag has >= 16 reads)");
     c->enc_variant = mode;
     return M6A_OK;
 }
@@ -1534,6 +1545,11 @@ int m6a_device_count(void)
 int m6a_profile_enable(m6a_ctx *c, int on)
 {
     if (!c) return M6A_EINVAL;
+    if (on && !c->prof.d_clk) {
+        HIPCHK(c, hipSetDevice(c->device));
+        HIPCHK(c, hipMalloc((void **)&c->prof.d_clk, (size_t)2 * M6A_CLK_SLOTS * 4 * sizeof(unsigned long long)));
+    }
+    if (on) HIPCHK(c, hipMemsetAsync(c->prof.d_clk, 0, (size_t)2 * M6A_CLK_SLOTS * 4 * sizeof(unsigned long long), c->stream));
     c->prof.on = on != 0;
     c->prof.mask = on == 2 ? 1 : on == 3 ? 2 : 3;
     c->prof.used[0] = c->prof.used[1] = 0;
@@ -1555,6 +1571,34 @@ int m6a_profile_read(m6a_ctx *c, int kind, double *total_ms, int64_t *n_launches
     }
     *total_ms = tot;
     *n_launches = c->prof.used[kind];
+    return M6A_OK;
+}
+
+int m6a_profile_clock(m6a_ctx *c, int kind, double *ghz_median, double *ghz_min, double *ghz_max, double *span_ms, int *n_waves)
+{
+    settle(c);
+    if (!c || kind < 0 || kind > 1) return M6A_EINVAL;
+    if (!c->prof.d_clk) return fail(c, M6A_EINVAL, "m6a_profile_clock: profiling was never enabled on this context");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    unsigned long long h[M6A_CLK_SLOTS * 4];
+    HIPCHK(c, hipMemcpy(h, c->prof.d_clk + (size_t)kind * M6A_CLK_SLOTS * 4, sizeof h, hipMemcpyDeviceToHost));
+    std::vector<double> ghz;
+    unsigned long long r_first = ~0ull, r_last = 0;
+    for (int i = 0; i < M6A_CLK_SLOTS; i++) {
+        const unsigned long long c0 = h[4 * i], r0 = h[4 * i + 1], c1 = h[4 * i + 2], r1 = h[4 * i + 3];
+        if (!r0 || r1 <= r0 || c1 <= c0) continue;                // slot unused, or its end stamp is an older launch's
+        ghz.push_back((double)(c1 - c0) / (double)(r1 - r0) * 0.1);   // cycles per 10 ns tick
+        r_first = std::min(r_first, r0);
+        r_last = std::max(r_last, r1);
+    }
+    std::sort(ghz.begin(), ghz.end());
+    const bool any = !ghz.empty();
+    if (ghz_median) *ghz_median = any ? ghz[ghz.size() / 2] : 0.0;
+    if (ghz_min) *ghz_min = any ? ghz.front() : 0.0;
+    if (ghz_max) *ghz_max = any ? ghz.back() : 0.0;
+    if (span_ms) *span_ms = any ? (double)(r_last - r_first) * 1e-5 : 0.0;
+    if (n_waves) *n_waves = (int)ghz.size();
     return M6A_OK;
 }
 

@@ -51,6 +51,8 @@ struct DevBuf {
 constexpr int kMaxProfiled = 8192;
 
 struct Profiler {
+    unsigned long long *d_clk = nullptr;      // [2 kinds][M6A_CLK_SLOTS][4] clock stamps of the last profiled launch of each kind
+    unsigned long long *clk_for(int kind) const { return on && (mask >> kind & 1) ? d_clk + (size_t)kind * M6A_CLK_SLOTS * 4 : nullptr; }
     bool on = false;
     int mask = 3;                             // bit 0: time the encoder launches, bit 1: the pooling launches
     std::vector<hipEvent_t> start[2], stop[2];
@@ -208,7 +210,7 @@ struct m6a_ctx {
     struct { int64_t S, bs, spb, base, G, gmax; bool valid; } goff_key = {0, 0, 0, 0, 0, 0, false};
     int64_t job_offset = 0;
     int64_t bag_min = 0, bag_max = 0, n_reads = 0;   // last query_bags()
-    int enc_variant = 0;                              // 0 auto, 1 16-slot, 2 12-slot (bags >= 16), 3 16-slot per-lane walk
+    int enc_variant = 0;                              // 0 auto (= the 16-slot kernels), 1 16-slot, 2 12-slot (bags >= 16), 3 16-slot per-lane walk, 4 fast (12-slot where it applies)
     const char *enc_variant_used = "none";
     const char *enc_kernel_used = "none";             // the __global__ function the last encode launched
     int scan_driver = 0;                              // 0 auto, 1 per group, 2 counting pass + per site

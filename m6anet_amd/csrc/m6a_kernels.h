@@ -28,6 +28,23 @@ __host__ __device__ inline unsigned long long m6a_bin_weight(int i)
     return z ^ (z >> 31);
 }
 
+// Clock stamps (bench.py's "clock the kernel ran at"): with a non-null `clk`, lane 0 of <= 64 workgroups
+// spread over the grid (an odd stride: block b runs on XCD b % 8, so the samples rotate through the XCDs) stores s_memtime
+// (shader cycles) and s_memrealtime (the constant 100 MHz clock) when the workgroup starts and when it ends: clk[slot][4] =
+// {cycles0, real0, cycles1, real1}; (cycles1 - cycles0) / (real1 - real0) x 100 MHz is the shader clock THAT wave lived at.
+// Null in every launch that is not being profiled (m6a_profile_enable): the product path never stamps.
+#define M6A_CLK_SLOTS 64
+__device__ __forceinline__ void m6a_clk_stamp(unsigned long long *clk, int which)
+{
+    if (!clk) return;
+    const unsigned stride = (gridDim.x >> 6) | 1u, b = blockIdx.x;
+    if (threadIdx.x == 0 && b % stride == 0 && b / stride < M6A_CLK_SLOTS) {
+        unsigned long long *p = clk + (size_t)(b / stride) * 4 + which * 2;
+        p[0] = __builtin_amdgcn_s_memtime();
+        p[1] = __builtin_amdgcn_s_memrealtime();
+    }
+}
+
 struct EncArgs {
     const float *X;               // [R][9]
     const uint8_t *site_kmers;    // [S][3]
@@ -41,6 +58,7 @@ struct EncArgs {
     int *err;
     int64_t n_sites, n_reads, n_tiles, tiles_per_wave;
     float b3;
+    unsigned long long *clk;      // clock stamps of a profiled launch, else null (m6a_clk_stamp)
 };
 
 struct PoolArgs {
@@ -66,6 +84,7 @@ struct PoolArgs {
     int64_t n_groups, n_sites, raw_len;
     int T, K, uniform_n, jmax, bag_cap;
     float thr;
+    unsigned long long *clk;      // clock stamps of a profiled launch, else null (m6a_clk_stamp)
 };
 
 // per-bag-size index tables (m6a_pool_rtab.hip): slot k holds C (accepted draws of the whole stream as u16 byte

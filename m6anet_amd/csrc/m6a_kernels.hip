@@ -241,6 +241,7 @@ struct EncTile {
 __global__ __launch_bounds__(256, 2) void enc_kernel(EncArgs a)
 {
     clamp_keeps_nan();
+    m6a_clk_stamp(a.clk, 0);
     __shared__ float s_emb[132];
     __shared__ __attribute__((aligned(16))) float s_bn[M6A_BN_FLOATS];
     for (int i = threadIdx.x; i < 132; i += 256) s_emb[i] = a.emb[i];
@@ -378,6 +379,7 @@ __global__ __launch_bounds__(256, 2) void enc_kernel(EncArgs a)
 #pragma unroll
         for (int i = 0; i < 8; i++) f[i] = fn[i];
     }
+    m6a_clk_stamp(a.clk, 1);
 }
 
 // =====================================================================================
@@ -399,6 +401,7 @@ __global__ __launch_bounds__(256, 2) void enc_kernel(EncArgs a)
 __global__ __launch_bounds__(256, 2) void enc_site16_kernel(EncArgs a)
 {
     clamp_keeps_nan();
+    m6a_clk_stamp(a.clk, 0);
     __shared__ float s_emb[132];
     __shared__ __attribute__((aligned(16))) float s_bn[M6A_BN_FLOATS];
     for (int i = threadIdx.x; i < 132; i += 256) s_emb[i] = a.emb[i];
@@ -538,6 +541,7 @@ __global__ __launch_bounds__(256, 2) void enc_site16_kernel(EncArgs a)
         for (int i = 0; i < 8; i++) f[i] = fn[i];
     }
     if (too_small && lane == 0) atomicExch(a.err, 2);
+    m6a_clk_stamp(a.clk, 1);
 }
 
 // =====================================================================================
@@ -566,6 +570,7 @@ __global__ __launch_bounds__(256, 2) void enc_site16_kernel(EncArgs a)
 __global__ __launch_bounds__(256, 2) void enc_csite_kernel(EncArgs a)
 {
     clamp_keeps_nan();
+    m6a_clk_stamp(a.clk, 0);
     __shared__ float s_emb[132];
     __shared__ float s_w1e[35 * 32];             // [m*7 + e][col]: W1[u][9+e] (e<6), b1[u] (e=6), u = the unit of row col of tile m
     for (int i = threadIdx.x; i < 132; i += 256) s_emb[i] = a.emb[i];
@@ -760,6 +765,7 @@ __global__ __launch_bounds__(256, 2) void enc_csite_kernel(EncArgs a)
         for (int i = 0; i < 4; i++) f[i] = fn[i];
     }
     if (too_small && lane == 0) atomicExch(a.err, 2);
+    m6a_clk_stamp(a.clk, 1);
 }
 
 // =====================================================================================

@@ -126,6 +126,7 @@ __global__ __launch_bounds__(64) void pool_reg_kernel(PoolArgs a)
     const unsigned per = gridDim.x >> 3;                                   // the host launches 8 * per workgroups
     const unsigned item = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
     if (item >= (unsigned)a.reg_items) return;
+    m6a_clk_stamp(a.clk, 0);                                               // profiled launches only (a.clk null otherwise)
     const int j = (int)(item % (unsigned)a.jmax);
     const int64_t g0 = (int64_t)(item / (unsigned)a.jmax) * 256;
     int64_t site[4];
@@ -405,6 +406,7 @@ __global__ __launch_bounds__(64) void pool_reg_kernel(PoolArgs a)
             a.mod_ratio[site[q]] = (double)cge[q] / (double)a.uniform_n;
         }
     }
+    m6a_clk_stamp(a.clk, 1);
 }
 
 // An empty kernel per translation unit: HIP maps a code object on the first launch of any kernel in it (0.3-1.2 ms, measured

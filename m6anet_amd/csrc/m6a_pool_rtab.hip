@@ -557,6 +557,7 @@ __global__ __launch_bounds__(64) void pool_rtab_kernel(PoolArgs a, RtabUse u)
     const uint32_t chunk = gridDim.x >> 3;                 // gridDim.x is a multiple of 8
     const int64_t si = (int64_t)(blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
     if (si >= (int64_t)u.si_count) return;
+    m6a_clk_stamp(a.clk, 0);                               // profiled launches only (a.clk null otherwise)
     const int64_t s = (int64_t)(uint32_t)uni((int)u.order[(int64_t)u.si_base + si]);
     const int64_t r0 = uni64(a.off[s]);
     const int n = uni((int)(a.off[s + 1] - r0));
@@ -634,6 +635,7 @@ __global__ __launch_bounds__(64) void pool_rtab_kernel(PoolArgs a, RtabUse u)
         wave_fence();
     }
     if (lane == 0) a.site_prob[s] = stack[0] / (float)T;
+    m6a_clk_stamp(a.clk, 1);
 }
 
 template __global__ void pool_rtab_kernel<20>(PoolArgs, RtabUse);

@@ -161,8 +161,9 @@ class M6ANetEngine:
         self._chk(self._L.m6a_set_job_offset(self._h, int(first_site)))
 
     def set_encoder_variant(self, mode):
-        """0 auto, 1 16-slot kernel (the reference's operation order), 2 12-slot kernel (needs every bag >= 16 reads),
-        3 the 16-slot kernel behind the per-lane walk of off[] even when the scalar site chain would do (A/B, tests)."""
+        """0 auto = the 16-slot kernels (the reference's operation order, its bits), 1 the same said explicitly, 2 the 12-slot
+        kernel (opt-in; needs every bag >= 16 reads), 3 the 16-slot arithmetic behind the per-lane walk of off[] even when the
+        scalar site chain would do (A/B, tests), 4 fast: the 12-slot kernel where every bag has >= 16 reads, 16-slot elsewhere."""
         self._chk(self._L.m6a_set_encoder_variant(self._h, int(mode)))
 
     @property
@@ -265,6 +266,15 @@ class M6ANetEngine:
         ms, n = C.c_double(), C.c_int64()
         self._chk(self._L.m6a_profile_read(self._h, kind, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def profile_clock(self, kind):
+        """The shader clock the last PROFILED launch of `kind` (0 encoder, 1 pooling) ran at, from in-kernel stamps of up to 64
+        waves (m6a_profile_clock): {'ghz': median, 'ghz_min', 'ghz_max', 'span_ms', 'waves'}; None if nothing was stamped."""
+        g, lo, hi, span, n = C.c_double(), C.c_double(), C.c_double(), C.c_double(), C.c_int32()
+        self._chk(self._L.m6a_profile_clock(self._h, kind, C.byref(g), C.byref(lo), C.byref(hi), C.byref(span), C.byref(n)))
+        if n.value == 0:
+            return None
+        return {"ghz": g.value, "ghz_min": lo.value, "ghz_max": hi.value, "span_ms": span.value, "waves": n.value}
 
     @property
     def last_pool_variant(self):

@@ -40,28 +40,40 @@ def argparser():
     parser.add_argument("--gpus", default=1, type=int,
                         help="GPUs of this node to split the job's sites over: one process per GPU, flush-group-aligned shards, "
                              "every rank writes the rows of its own sites; the output does not depend on it.")
-    parser.add_argument("--encoder", default="reference", choices=["reference", "fast"],
-                        help="read encoder kernel.  reference (default): the 16-slot kernel, which performs the reference's float32 "
-                             "operations in the reference's order all the way to the sigmoid -- on the host configuration it was "
-                             "validated against (torch + MKL on AVX-512) read probabilities are bit-identical to `m6anet inference` "
-                             "wherever MKL groups a batch's rows in fours (every read of 20-read bags, > 99.9 %% of ragged ones); "
-                             "activations beyond 2^64 saturate and a -inf pre-activation becomes NaN (DESIGN.md).  fast: the "
-                             "library's automatic choice, for bags of >= 16 reads a 12-slot kernel 6 %% faster per step and within 1e-5 "
-                             "relative of the reference.  The encoder is under 1 %% of this command's wall time either way.  "
-                             "The environment variable M6A_ENCODER, if set, decides instead.")
+    parser.add_argument("--encoder", default=None, choices=["reference", "fast"],
+                        help="read encoder kernel.  reference (the default, and the library's own default): the 16-slot kernels, which "
+                             "perform the reference's float32 operations in the reference's order all the way to the sigmoid -- on the "
+                             "host configuration it was validated against (torch + MKL on AVX-512) read probabilities are bit-identical "
+                             "to `m6anet inference` wherever MKL groups a batch's rows in fours (every read of 20-read bags, > 99.9 %% "
+                             "of ragged ones); activations beyond 2^64 saturate and a -inf pre-activation becomes NaN (DESIGN.md).  "
+                             "fast: opt-in, for jobs whose bags all have >= 16 reads a 12-slot kernel 5-6 %% faster per step and within "
+                             "rtol 1e-5 of the reference on every fixture (a random fuzz: 4 reads of 20 G at up to 1.005 x that bar).  "
+                             "The encoder is under 1 %% of this command's wall time either way.  Without this flag the environment "
+                             "variable M6A_ENCODER (auto|reference|general16|csite12|walk16|fast), if set, decides; an unknown value is an error.")
     parser.add_argument("--drop_unflushed_tail", action="store_true",
                         help="reference-compatible output: omit the batches after the reference's last flush, which "
                              "`m6anet inference` never writes (its flush test is inverted); default: write every site.")
     return parser
 
 
+ENCODER_MODES = {"reference": 1, "fast": 4}           # m6a_set_encoder_variant (include/m6a.h)
+ENCODER_ENV_VALUES = ("", "auto", "reference", "general16", "csite12", "walk16", "fast")
+
+
 def make_engine_for(args, weights, device):
     """The context of one `inference` process with --encoder applied to IT (m6a_set_encoder_variant), not to the process's
-    environment: a library caller's other contexts keep the automatic choice.  M6A_ENCODER, if the user set it, was read
-    by m6a_create and stays."""
+    environment: a library caller's other contexts keep their own choice.  An explicit --encoder always wins; without the
+    flag M6A_ENCODER decides if set (m6a_create reads it and refuses values it does not know -- checked here first, so the
+    message names the variable), else `reference`, which is also what the library does when nobody says anything."""
+    env = os.environ.get("M6A_ENCODER")
+    if env is not None and env not in ENCODER_ENV_VALUES:
+        raise ValueError("M6A_ENCODER=%s: must be one of %s" % (env, "|".join(v for v in ENCODER_ENV_VALUES if v)))
     engine = M6ANetEngine(weights=weights, device=device)
-    if args.encoder == "reference" and "M6A_ENCODER" not in os.environ:
-        engine.set_encoder_variant(1)
+    choice = getattr(args, "encoder", None)
+    if choice is not None:
+        engine.set_encoder_variant(ENCODER_MODES[choice])
+    elif env is None:
+        engine.set_encoder_variant(ENCODER_MODES["reference"])
     return engine
 
 

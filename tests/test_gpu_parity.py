@@ -90,11 +90,15 @@ def test_encoder_golden_all_models(golden, engines):
     [1] * 200 + [40] + [1] * 50, [662, 20, 21, 500, 33], list(range(1, 70)),
 ])
 def test_encoder_vs_oracle_shapes(eng, orc, weights, bags):
+    """The library's automatic choice (nothing set: what the CLI, INTEGRATION.md's stub and bench.py's headline run) is the
+    16-slot arithmetic on every input -- the oracle's BITS, not a tolerance."""
     X, km, off = rand_sites(len(bags) * 7 + 1, bags)
     got = eng.get_read_probability(X, km, off)
+    assert eng.last_encoder_variant == "general16"
+    assert eng.last_encoder_kernel == ("enc_site16_kernel" if min(bags) >= 16 else "enc_kernel")
     want = orc.encode_reads(weights["hct116"], X, km, off)
     assert got.shape == want.shape
-    assert np.allclose(got, want, rtol=1e-5, atol=1e-8)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
 
 
 def test_encoder_ragged_large_vs_oracle(engines, orc, weights):
@@ -104,7 +108,14 @@ def test_encoder_ragged_large_vs_oracle(engines, orc, weights):
     for name in ("hek293t_glori", "arabidopsis"):
         got = engines[name].get_read_probability(X, km, off)
         want = orc.encode_reads(weights[name], X, km, off, n_threads=8)
-        assert np.allclose(got, want, rtol=1e-5, atol=1e-8), name
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), name          # auto = the oracle's bits
+        engines[name].set_encoder_variant(4)                                            # the opt-in 12-slot kernel: the reference test's bar
+        try:
+            fast = engines[name].get_read_probability(X, km, off)
+            assert engines[name].last_encoder_kernel == "enc_csite_kernel"
+        finally:
+            engines[name].set_encoder_variant(0)
+        assert np.allclose(fast, want, rtol=1e-5, atol=1e-8), name
 
 
 def test_encoder_extreme_inputs(eng, orc, weights):
@@ -115,7 +126,7 @@ def test_encoder_extreme_inputs(eng, orc, weights):
     got = eng.get_read_probability(X, km, off)
     want = orc.encode_reads(weights["hct116"], X, km, off)
     assert np.all(np.isfinite(got))
-    assert np.allclose(got, want, rtol=1e-5, atol=1e-8)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
 
 
 @pytest.mark.parametrize("bags", [[1], [20] * 64, [3] * 100, list(range(1, 70)), [662, 20, 21, 500, 33], [0, 5, 0, 0, 7, 0],
@@ -184,7 +195,7 @@ def test_encoder_site16_needs_bags_of_16(eng):
         eng.set_encoder_variant(0)
 
 
-@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("variant", [0, 1, 2, 4])
 def test_encoder_nan_and_huge_features(eng, orc, weights, variant):
     """Layer 1's ReLU is the clamp modifier of the batch-norm fma (m6a_kernels.hip bn_relu): a NaN feature must still come
     out as a NaN probability for THAT read only (the reference propagates it; the hardware's default clamp would have
@@ -229,27 +240,49 @@ def test_encoder_variants_vs_oracle(engines, orc, weights, variant, name, bags):
 
 
 def test_encoder_variant_from_the_environment(weights, monkeypatch):
-    """M6A_ENCODER preselects the kernel for callers that cannot call m6a_set_encoder_variant (the CLI)."""
+    """M6A_ENCODER preselects the kernel for callers that cannot call m6a_set_encoder_variant; a value the library does not
+    know makes m6a_create FAIL (a typo must not silently select another kernel)."""
+    from m6anet_amd._lib import M6AError
     from m6anet_amd.engine import M6ANetEngine
     X, km, off = rand_sites(5, [20] * 40)
-    for value, want in (("general16", "general16"), ("csite12", "csite12"), ("nonsense", "csite12")):
+    for value, want in (("general16", "enc_site16_kernel"), ("csite12", "enc_csite_kernel"), ("fast", "enc_csite_kernel"),
+                        ("walk16", "enc_kernel"), ("reference", "enc_site16_kernel"), ("auto", "enc_site16_kernel"), ("", "enc_site16_kernel")):
         monkeypatch.setenv("M6A_ENCODER", value)
         e = M6ANetEngine(weights=weights["hct116"])
         try:
             e.get_read_probability(X, km, off)
-            assert e.last_encoder_variant == want, value
+            assert e.last_encoder_kernel == want, value
         finally:
             e.close()
+    for value in ("nonsense", "general", "General16", "csite"):
+        monkeypatch.setenv("M6A_ENCODER", value)
+        with pytest.raises(M6AError, match="M6A_ENCODER"):
+            M6ANetEngine(weights=weights["hct116"])
+    monkeypatch.delenv("M6A_ENCODER")
+    e = M6ANetEngine(weights=weights["hct116"])
+    try:
+        e.get_read_probability(X, km, off)
+        assert e.last_encoder_kernel == "enc_site16_kernel"
+    finally:
+        e.close()
 
 
 def test_encoder_variant_selection_and_precondition(eng):
     from m6anet_amd._lib import M6AError
     X, km, off = rand_sites(1, [20] * 40)
     eng.get_read_probability(X, km, off)
-    assert eng.last_encoder_variant == "csite12"
-    X, km, off = rand_sites(2, [20] * 40 + [15])
-    eng.get_read_probability(X, km, off)
-    assert eng.last_encoder_variant == "general16"            # one bag of 15 reads: general kernel
+    assert eng.last_encoder_variant == "general16" and eng.last_encoder_kernel == "enc_site16_kernel"    # auto: the reference's bits
+    X15, km15, off15 = rand_sites(2, [20] * 40 + [15])
+    eng.get_read_probability(X15, km15, off15)
+    assert eng.last_encoder_variant == "general16" and eng.last_encoder_kernel == "enc_kernel"   # one bag of 15 reads: the walk
+    eng.set_encoder_variant(4)                                # fast: the 12-slot kernel where it applies, 16 slots elsewhere
+    try:
+        eng.get_read_probability(X, km, off)
+        assert eng.last_encoder_variant == "csite12" and eng.last_encoder_kernel == "enc_csite_kernel"
+        eng.get_read_probability(X15, km15, off15)
+        assert eng.last_encoder_variant == "general16" and eng.last_encoder_kernel == "enc_kernel"
+    finally:
+        eng.set_encoder_variant(0)
     X, km, off = rand_sites(3, [3] * 200)
     eng.set_encoder_variant(2)                                # forcing the 12-slot kernel on small bags
     try:
@@ -598,6 +631,19 @@ def test_bad_arguments(eng):
         eng.calculate_site_proba(p, off, 10, batch_size=0)
     with pytest.raises(M6AError):
         eng.calculate_site_proba(p, np.array([0, 30, 20], np.int64), 10)
+    # rng_mode: M6A_RNG_NUMPY (0) is the only value the three signatures take (include/m6a.h): anything else is a
+    # bad ARGUMENT (M6A_EINVAL = -1), on every entry point that carries the parameter, and leaves the context usable
+    import ctypes as C
+    L, h = eng._L, eng._h
+    site, mod = np.empty(2, np.float32), np.empty(2, np.float64)
+    X, km = np.zeros((40, 9), np.float32), np.zeros((2, 3), np.uint8)
+    for bad in (1, -1, 7):
+        assert L.m6a_site_pool(h, p.ctypes.data, off.ctypes.data, 2, 10, 20, C.c_float(0.5), 0, bad, 16, 2, site.ctypes.data, mod.ctypes.data) == -1
+        assert b"M6A_RNG_NUMPY" in L.m6a_last_error(h)
+        assert L.m6a_infer(h, X.ctypes.data, km.ctypes.data, off.ctypes.data, 2, 10, 20, C.c_float(0.5), 0, bad, 16, 2, None, site.ctypes.data,
+                           mod.ctypes.data) == -1
+        assert L.m6a_job_begin(h, 10, 20, C.c_float(0.5), 0, bad, 16, 2, 0, 0) == -1
+    assert L.m6a_site_pool(h, p.ctypes.data, off.ctypes.data, 2, 10, 20, C.c_float(0.5), 0, 0, 16, 2, site.ctypes.data, mod.ctypes.data) == 0
     for knob in (eng.set_table_variant, eng.set_scan_driver, eng.set_encoder_variant):
         with pytest.raises(M6AError):
             knob(7)
@@ -758,7 +804,7 @@ def test_soak_repeated_runs_are_bit_identical(engines):
         try:
             ref = None
             for i in range(40):
-                eng.set_encoder_variant(1 + (i & 1) if bag == 20 else 0)
+                eng.set_encoder_variant((2 if i & 1 else 0) if bag == 20 else 0)
                 rp, site, mod = eng.infer(X, km, off, 300)
                 eng.sync()
                 cur = (rp.clone(), site.clone(), mod.clone())
@@ -1190,7 +1236,7 @@ def test_beyond_4GiB_of_features(eng, orc, weights):
         eng.sync()
     finally:
         eng.set_stream(None)
-    assert eng.last_encoder_variant == "csite12" and eng.last_pool_variant == "ragged-table"   # n = 37 > 32: no uniform-bag kernel
+    assert eng.last_encoder_kernel == "enc_site16_kernel" and eng.last_pool_variant == "ragged-table"   # n = 37 > 32: no uniform-bag kernel
     rp, site, mod = rp.cpu().numpy(), site.cpu().numpy(), mod.cpu().numpy()
     del tX
     n_groups = (S - 16) // 32
@@ -1199,7 +1245,7 @@ def test_beyond_4GiB_of_features(eng, orc, weights):
         b = min(S, 16 if grp == 0 else 16 + 32 * grp)
         sl = slice(a * n, b * n)
         p = orc.encode_reads(weights["hct116"], X[sl], km[a:b], off[a:b + 1] - a * n)
-        assert np.allclose(rp[sl], p, rtol=1e-5, atol=1e-8), grp
+        assert np.array_equal(rp[sl].view(np.uint32), p.view(np.uint32)), grp           # auto = the oracle's bits, beyond 4 GiB of features too
         w_site, w_mod = orc.site_pool(rp[sl], off[a:b + 1] - a * n, T, THR, batch_size=b - a, save_per_batch=2)
         assert same_sites(site[a:b], w_site), grp
         assert np.array_equal(mod[a:b], w_mod), grp

@@ -53,7 +53,7 @@ def feed_in_batches(eng, d, batch, **begin):
 @pytest.mark.parametrize("batch", [16, 1, 999, 10**9])
 def test_job_stream_equals_infer(eng, bag, S, T, batch):
     """The reference's batch loop fed batch by batch == ONE m6a_infer over the whole job, bit for bit (every bag has
-    >= 16 reads, so both pick the 12-slot encoder), whatever the batch size -- 16 like the reference's DataLoader, single
+    >= 16 reads, so both pick enc_site16_kernel), whatever the batch size -- 16 like the reference's DataLoader, single
     sites, batches that straddle chunks, the whole job at once."""
     d = synthetic.make_sites(S, bag, seed=S + T)
     want = eng.infer(d["X"], d["site_kmers"], d["off"], T, read_proba_threshold=THR, seed=3, batch_size=16, save_per_batch=2)
@@ -100,9 +100,9 @@ def test_job_feed_collated_is_the_collate_layout(eng):
 
 
 def test_job_stream_small_and_empty_bags(eng, orc, weights):
-    """Bags below 16 reads, single reads and empty sites among the batches: a chunk then takes the general encoder
-    where the whole-job call might not, so read probabilities are held to the oracle's bar and the pooling to
-    bit-equality with m6a_site_pool of the job's own read probabilities; with the encoder pinned, to m6a_infer."""
+    """Bags below 16 reads, single reads and empty sites among the batches: a chunk may take enc_site16_kernel where the
+    whole-job call takes enc_kernel -- the same float32 operations, so (with the automatic encoder choice, round 6) the
+    streamed job is the oracle's BITS and bit-equal to m6a_infer without pinning anything."""
     g = np.random.Generator(np.random.PCG64(77))
     bags = g.integers(0, 40, size=4000)
     bags[::97] = 0
@@ -110,7 +110,10 @@ def test_job_stream_small_and_empty_bags(eng, orc, weights):
     kw = dict(n_iters=120, read_proba_threshold=THR, seed=0, batch_size=7, save_per_batch=3)
     rp, site, mod = feed_in_batches(eng, d, 16, **kw)
     want_rp = orc.encode_reads(weights["hct116"], d["X"], d["site_kmers"], d["off"], n_threads=8)
-    assert np.allclose(rp, want_rp, rtol=1e-5, atol=1e-8)
+    assert np.array_equal(rp.view(np.uint32), want_rp.view(np.uint32))
+    whole = eng.infer(d["X"], d["site_kmers"], d["off"], 120, 20, THR, 0, 7, 3)
+    for x, y in zip((rp, site, mod), whole):
+        assert np.array_equal(x, y, equal_nan=True)
     s2, m2 = eng.calculate_site_proba(rp, d["off"], 120, 20, THR, 0, 7, 3)
     assert np.array_equal(site, s2, equal_nan=True) and np.array_equal(mod, m2, equal_nan=True)
     o_site, o_mod = orc.site_pool(rp, d["off"], 120, THR, batch_size=7, save_per_batch=3)
@@ -516,7 +519,7 @@ def test_read_probability_tail_at_full_size(engines, orc, weights):
     for name, e in engines.items():
         want = orc.encode_reads(weights[name], X, km, off, n_threads=threads)
         tol = 1e-8 + 1e-5 * np.abs(want.astype(np.float64))
-        for variant, kernel in ((1, "general16"), (2, "csite12")):
+        for variant, kernel in ((0, "general16"), (2, "csite12")):       # 0 = the automatic choice: what the product runs
             e.set_encoder_variant(variant)
             try:
                 got = e.get_read_probability(X, km, off)
@@ -607,15 +610,15 @@ def test_validation_sampler_walk_and_parallel_shuffles(eng, orc, monkeypatch):
 
 def test_configs1_at_full_size(eng, orc, weights):
     """BASELINE.json configs[1] at its full size -- 100 000 synthetic DRACH sites x 20 reads, HCT116 weights,
-    num_iterations = 100 -- every read and every site against the oracle: read probabilities within rtol 1e-5, site
-    probabilities and mod_ratio of ALL sites bit-identical given the same read probabilities."""
+    num_iterations = 100 -- every read and every site against the oracle, on the library's automatic kernels: read
+    probabilities, site probabilities and mod_ratio of ALL sites bit-identical."""
     d = synthetic.make_sites(100_000, 20, seed=20250328)
     rp, site, mod = eng.infer(d["X"], d["site_kmers"], d["off"], 100, 20, THR, 0, 16, 2)
-    assert eng.last_pool_variant == "table-reg" and eng.last_encoder_variant == "csite12"
+    assert eng.last_pool_variant == "table-reg" and eng.last_encoder_kernel == "enc_site16_kernel"
     threads = os.cpu_count() or 8
     want_rp = orc.encode_reads(weights["hct116"], d["X"], d["site_kmers"], d["off"], n_threads=threads)
-    assert np.allclose(rp, want_rp, rtol=1e-5, atol=1e-8)
-    want_site, want_mod = orc.site_pool(rp, d["off"], 100, THR, n_threads=threads)
+    assert np.array_equal(rp.view(np.uint32), want_rp.view(np.uint32))
+    want_site, want_mod = orc.site_pool(want_rp, d["off"], 100, THR, n_threads=threads)
     assert np.array_equal(site, want_site) and np.array_equal(mod, want_mod)
 
 
@@ -641,11 +644,13 @@ def test_bench_world_8_rehearsal_on_one_gpu(workload, sites):
     assert d["rccl"]["ranks_seen"] is None and "gloo" in d["rccl"]["communicator"] and d["efficiency"] > 0
 
 
-def test_bench_default_line_has_the_contract_and_the_round_5_keys():
-    """The line the driver reads (default shape, no flags but shorter legs): the contract's keys, the roofline with the executed-work
-    fraction, the product-default encoder's own roofline (what `m6anet_amd inference` launches), the host-input leg, the ragged
-    shape -- every extra leg is optional in bench.py, so a leg that broke would silently vanish from the record: this test is where
-    it fails loudly."""
+def test_bench_default_line_has_the_contract_and_one_encoder_for_product_and_headline(eng):
+    """The line the driver reads (default shape, no flags but shorter legs): the contract's keys, and VERDICT r5 item 1 -- ONE
+    encoder kernel for the product and the headline: the kernel the timed region ran (`config.encoder_kernel_function`, the one
+    `roofline` prices) is the library's automatic choice AND what the CLI selects by default (asserted against the CLI's own code,
+    not a string in bench.py).  The opt-in 12-slot kernel, the host-input leg and the ragged shape are extra keys -- every extra
+    leg is optional in bench.py, so a leg that broke would silently vanish from the record: this test is where it fails loudly."""
+    from m6anet_amd.scripts import inference as cli
     out, lines = run_bench(["--steps", "3", "--warmup", "1", "--min-seconds", "0", "--no-cpu-baseline", "--no-live-traffic"], {}, timeout=600)
     assert out.returncode == 0 and len(lines) == 1, out.stderr[-2000:]
     d = lines[0]
@@ -655,23 +660,42 @@ def test_bench_default_line_has_the_contract_and_the_round_5_keys():
     assert 2.0e8 < d["value"] < 6.0e8 and abs(d["value"] - 1e6 / (d["ms_per_step"] * 1e-3)) < 1e-3 * d["value"]
     r = d["roofline"]
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.7 < r["frac"] < 1.0
-    assert r["executed_flop_per_read"] == 13568 and r["mfma_per_32_read_tile"] == 106 and 0.7 < r["frac_executed"] < r["frac"]
-    assert "enc_csite_kernel" in r["kernel"] and d["config"]["encoder_kernel_function"] == "enc_csite_kernel" and "general16" in d["config"]["cli_default_encoder"]
-    pd = d["roofline_product_default"]
-    assert "enc_site16_kernel" in pd["kernel"] and pd["executed_flop_per_read"] == 14848 and pd["mfma_per_32_read_tile"] == 116
-    assert 0.7 < pd["frac"] < 1.0, pd
-    assert pd["frac"] < pd["frac_executed"] < 1.0, pd
-    assert pd["launches"] == 10, pd
-    ro = d["reference_order_encoder"]
+    assert r["executed_flop_per_read"] == 14848 and r["mfma_per_32_read_tile"] == 116 and 0.7 < r["frac"] < r["frac_executed"] < 1.0
+    # one kernel: headline == library auto == CLI default
+    assert "enc_site16_kernel" in r["kernel"] and d["config"]["encoder_kernel_function"] == "enc_site16_kernel"
+    assert d["config"]["encoder_kernel"] == "general16" and d["config"]["encoder_selected_by"] == "auto (library default)"
+    assert "general16" in d["config"]["cli_default_encoder"] and "general16" in d["config"]["library_auto_encoder"]
+    assert cli.argparser().parse_args(["--input_dir", "x", "--out_dir", "y"]).encoder is None       # the CLI's default: nothing chosen ...
+    assert cli.ENCODER_MODES["reference"] == 1                                                       # ... = `reference` = the 16-slot kernels
+    try:
+        ds = synthetic.make_sites(64, 20, seed=1)
+        for mode in (0, cli.ENCODER_MODES["reference"]):
+            eng.set_encoder_variant(mode)
+            eng.get_read_probability(ds["X"], ds["site_kmers"], ds["off"])
+            assert eng.last_encoder_kernel == d["config"]["encoder_kernel_function"], mode
+    finally:
+        eng.set_encoder_variant(0)
+    # the clock the kernels ran at, from inside them
+    assert 1.2 < r["clock_ghz_measured"] <= 2.45 and r["clock_detail"]["waves"] >= 16, r.get("clock_detail")
+    assert abs(r["peak_at_measured_clock"] - r["peak"] * r["clock_ghz_measured"] / 2.4) < 1e-6
+    assert r["frac"] <= r["frac_at_measured_clock"] * 1.001 and r["frac_executed_at_measured_clock"] < 1.02
+    assert abs(r["clock_detail"]["span_ms"] - r["avg_launch_ms"]) < 0.25 * r["avg_launch_ms"], r["clock_detail"]
+    fo = d["fast_encoder_optin"]
+    assert fo["kernel"] == "enc_csite_kernel" and len(fo["ms_per_step_of_each_leg"]) == 3 and 2.0 < fo["ms_per_step"] < 4.0
+    fr = fo["roofline"]
+    assert "enc_csite_kernel" in fr["kernel"] and fr["executed_flop_per_read"] == 13568 and fr["mfma_per_32_read_tile"] == 106
+    assert 0.7 < fr["frac_executed"] < fr["frac"] < 1.0 and fr["launches"] == 10, fr
     # (no relation between the two kernels' times is asserted: three timed steps right after the cold call are clock-ramp noise)
-    assert ro["kernel"] == "enc_site16_kernel" and len(ro["ms_per_step_of_each_leg"]) == 3 and 2.0 < ro["ms_per_step"] < 4.0
     h = d["with_h2d"]
     assert "error" not in h and h["pageable"]["sites_per_s"] > 2e7 and h["pinned"]["sites_per_s"] > 2e7 and h["bytes_in_per_step"] == 731000008
+    assert h["encoder_kernel"] == "enc_site16_kernel"
     assert d["value"] > 3 * h["pinned"]["sites_per_s"]                      # PCIe-inclusive rates are never the headline
     p = d["pool_roofline"]
     assert p["bound"] == "valu" and 0.5 < p["frac"] < 1.0 and (p["measured_ceiling"] is None or p["measured_ceiling"]["frac"] < 1.05)
+    assert 1.2 < p["clock_ghz_measured"] <= 2.45 and p["frac"] <= p["frac_at_measured_clock"] * 1.001 < 1.05, p.get("clock_detail")
     g = d["ragged"]
     assert g["value"] > 1e7 and g["config"]["pool_kernel"] == "ragged-table" and 0.7 < g["roofline"]["frac"] < 1.0
+    assert g["config"]["encoder_kernel_function"] == "enc_site16_kernel" and g["pool_roofline"]["clock_ghz_measured"] is not None
 
 
 def test_bench_sustained_leg_with_two_ranks():

@@ -137,7 +137,7 @@ def engines(weights):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant", [(1, "general16"), (2, "csite12")])
+@pytest.mark.parametrize("variant", [(0, "general16"), (2, "csite12")])      # 0 = the library's automatic choice, what the product runs
 @pytest.mark.parametrize("tag", list(SHAPES))
 def test_hip_read_probabilities_vs_reference_at_scale(golden, engines, tag, variant):
     """Every one of the 2.1 M reads x 4 checkpoints x 2 kernels inside rtol 1e-5 / atol 1e-8 of the reference's value --
@@ -165,19 +165,16 @@ def test_hip_read_probabilities_vs_reference_at_scale(golden, engines, tag, vari
 
 
 @pytest.mark.gpu
-def test_hip_general16_site_rows_are_the_references(golden, engines):
-    """With the 16-slot kernel the whole path is the reference's arithmetic: on the 20-read-bag job probability_modified and
+def test_hip_default_path_site_rows_are_the_references(golden, engines):
+    """With the automatic kernels (16-slot encoder: nothing set) the whole path is the reference's arithmetic: on the 20-read-bag job probability_modified and
     mod_ratio of every site come out bit-identical to the reference's (10 000 sites x 4 checkpoints, T = 1000)."""
     d, G, _, keep_sites = job(golden, "uniform")
     off = d["off"][:keep_sites + 1]
     R = int(off[-1])
     for name in MODELS:
         e = engines[name]
-        e.set_encoder_variant(1)
-        try:
-            rp, site, mod = e.infer(d["X"][:R], d["site_kmers"][:keep_sites], off, 1000)
-        finally:
-            e.set_encoder_variant(0)
+        rp, site, mod = e.infer(d["X"][:R], d["site_kmers"][:keep_sites], off, 1000)
+        assert e.last_encoder_kernel == "enc_site16_kernel" and np.array_equal(rp, G[f"uniform_{name}_readprob"][:R]), name
         assert np.array_equal(site, G[f"uniform_{name}_site_T1000"]) and np.array_equal(mod, G[f"uniform_{name}_mod"]), name
 
 
