@@ -98,6 +98,11 @@ int m6a_prepare_host_io(m6a_ctx *ctx);
  * used by m6anet/utils/data_utils.py -- its batches are pageable. */
 int m6a_host_alloc(size_t bytes, void **out);
 int m6a_host_free(void *p);
+/* 1 if the WHOLE range [p, p + bytes) lies inside ONE page-locked host allocation the DMA engines can address (hipHostMalloc,
+ * hipHostRegister, torch's pin_memory(), m6a_host_alloc) -- exactly the test the host-pointer calls apply to decide between
+ * in-place DMA and the staging ring; 0 otherwise (pageable memory, device memory, a range that leaves its allocation or spans
+ * two registrations, no HIP runtime).  Never an error: a buffer that is not recognised simply goes through the ring. */
+int m6a_host_is_pinned(const void *p, size_t bytes);
 
 /* Read encoder.  Replaces, for one batch of sites,
  *     model.get_read_representation({'X','kmer'}) + model.pooling_filter.probability_layer(.)

@@ -90,6 +90,15 @@ def dataprep(eventalign, out_dir, n_threads=0, readcount_min=1, readcount_max=10
                                 1 if skip_index else 0))
 
 
+def _weakrefable(x):
+    try:
+        import weakref
+        weakref.ref(x)
+        return True
+    except TypeError:
+        return False
+
+
 class NativeSites:
     """Owns an m6a_sites handle; exposes its arrays as zero-copy numpy views."""
 
@@ -138,6 +147,7 @@ class NativeSites:
         _chk(self._L.m6a_io_save_store(self._h, os.fsencode(path), tag.encode()[:63]))
 
     def write_csv(self, out_dir, read_prob, site_prob, mod_ratio, write_header=False, n_threads=0, n_sites=None):
+        self._drop_shard_kept()
         rp = np.ascontiguousarray(read_prob, np.float32)
         sp = np.ascontiguousarray(site_prob, np.float32)
         mr = np.ascontiguousarray(mod_ratio, np.float64)
@@ -152,25 +162,38 @@ class NativeSites:
         assert sp.size == mr.size == b - a and rp.size == int(self.off[b] - self.off[a])
         return rp, sp, mr
 
+    def _drop_shard_kept(self):
+        self._shard_kept = None
+
     def csv_shard_size(self, a, b, read_prob, site_prob, mod_ratio, n_threads=0):
         """Bytes the rows of sites [a, b) take in (data.site_proba.csv, data.indiv_proba.csv); the arrays hold that range only."""
+        import weakref
+        self._drop_shard_kept()                      # an earlier size call that was never followed by its write
         rp, sp, mr = self._shard_args(a, b, read_prob, site_prob, mod_ratio)
-        # the library keeps the text it formats for the csv_shard_write that follows, keyed on the arrays' addresses (and a
-        # checksum): converted temporaries are kept alive until then, together with the caller's objects they were made from
-        self._shard_kept = ((a, b, read_prob, site_prob, mod_ratio), (rp, sp, mr))
         ns, ni = C.c_int64(), C.c_int64()
         _chk(self._L.m6a_io_csv_shard_size(self._h, rp.ctypes.data, sp.ctypes.data, mr.ctypes.data, int(a), int(b), int(n_threads),
-                                           C.byref(ns), C.byref(ni)))
+                                           C.byref(ns), C.byref(ni)))        # raises: nothing is kept
+        # The library keeps the text it formatted for the csv_shard_write that follows, keyed on the arrays' addresses (and a
+        # checksum).  Kept here until then: CONVERTED temporaries (strongly -- nobody else holds them, and the write must pass the
+        # same addresses), and only weak references to the caller's own objects (ADVICE r5: read_prob is 4 bytes per read and
+        # can reach GBs; a size call that is never followed by its write must not pin it for the life of this handle).  If a
+        # caller array is gone by then, or another csv_* call came between, the write formats again -- correct, just slower.
+        def keep(conv, orig):
+            return (weakref.ref(orig), None) if conv is orig else (weakref.ref(orig) if _weakrefable(orig) else None, conv)
+        self._shard_kept = ((int(a), int(b)), tuple(keep(c_, o_) for c_, o_ in zip((rp, sp, mr), (read_prob, site_prob, mod_ratio))))
         return ns.value, ni.value
 
     def csv_shard_write(self, out_dir, a, b, read_prob, site_prob, mod_ratio, site_offset, indiv_offset, header_and_totals=None, n_threads=0):
         """pwrite()s the rows of sites [a, b) at the given byte offsets; `header_and_totals` = (site_total, indiv_total) on the
         one rank that also writes the header lines and sets the files' final sizes."""
         kept, self._shard_kept = getattr(self, "_shard_kept", None), None
-        if kept is not None and kept[0][:2] == (a, b) and all(x is y for x, y in zip(kept[0][2:], (read_prob, site_prob, mod_ratio))):
-            rp, sp, mr = kept[1]                     # the very arrays csv_shard_size formatted: the kept text is reused
-        else:
-            rp, sp, mr = self._shard_args(a, b, read_prob, site_prob, mod_ratio)
+        arrs = None
+        if kept is not None and kept[0] == (int(a), int(b)):
+            same = [r is not None and r() is o for (r, _), o in zip(kept[1], (read_prob, site_prob, mod_ratio))]
+            if all(same):                            # the very arrays csv_shard_size formatted: the kept text is reused
+                arrs = tuple(conv if conv is not None else o for (_, conv), o in zip(kept[1], (read_prob, site_prob, mod_ratio)))
+        del kept
+        rp, sp, mr = arrs if arrs is not None else self._shard_args(a, b, read_prob, site_prob, mod_ratio)
         st, it = header_and_totals if header_and_totals is not None else (-1, -1)
         _chk(self._L.m6a_io_csv_shard_write(self._h, os.fsencode(out_dir), rp.ctypes.data, sp.ctypes.data, mr.ctypes.data, int(a), int(b),
                                             int(n_threads), int(site_offset), int(indiv_offset), 1 if header_and_totals is not None else 0,
@@ -180,6 +203,7 @@ class NativeSites:
         return int(self._L.m6a_io_csv_header_bytes(0)), int(self._L.m6a_io_csv_header_bytes(1))
 
     def close(self):
+        self._shard_kept = None
         if getattr(self, "_h", None):
             for name in ("X", "site_kmers", "off", "tx_pos", "read_id_values", "read_rep"):
                 setattr(self, name, None)

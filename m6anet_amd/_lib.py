@@ -12,7 +12,7 @@ ERRORS = {-1: "M6A_EINVAL", -2: "M6A_ENOMEM", -3: "M6A_EHIP", -4: "M6A_ESTREAM",
 RNG_NUMPY = 0
 
 # every symbol include/m6a.h declares (tests check the .so exports exactly these)
-SYMBOLS = ["m6a_create", "m6a_destroy", "m6a_last_error", "m6a_set_stream", "m6a_set_job_offset", "m6a_set_scan_driver", "m6a_set_table_variant", "m6a_set_encoder_variant", "m6a_last_encoder_variant", "m6a_last_encoder_kernel", "m6a_sync", "m6a_set_host_offsets", "m6a_prepare_host_io", "m6a_host_alloc", "m6a_host_free",
+SYMBOLS = ["m6a_create", "m6a_destroy", "m6a_last_error", "m6a_set_stream", "m6a_set_job_offset", "m6a_set_scan_driver", "m6a_set_table_variant", "m6a_set_encoder_variant", "m6a_last_encoder_variant", "m6a_last_encoder_kernel", "m6a_sync", "m6a_set_host_offsets", "m6a_prepare_host_io", "m6a_host_alloc", "m6a_host_free", "m6a_host_is_pinned",
            "m6a_encode_reads", "m6a_site_pool", "m6a_infer", "m6a_job_begin", "m6a_job_feed", "m6a_job_feed_collated", "m6a_job_size", "m6a_job_end", "m6a_job_abort", "m6a_bag_forward", "m6a_validate_pool", "m6a_validate", "m6a_flush_groups",
            "m6a_reference_written_sites",
            "m6a_shard_plan", "m6a_comm_unique_id", "m6a_comm_init", "m6a_gather", "m6a_gather_reads", "m6a_device_count", "m6a_random_stream", "m6a_comm_destroy", "m6a_comm_count", "m6a_comm_info", "m6a_device_link", "m6a_profile_enable", "m6a_profile_read", "m6a_profile_clock", "m6a_last_pool_variant",
@@ -80,6 +80,7 @@ def load():
     L.m6a_last_encoder_variant.restype = C.c_char_p
     L.m6a_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
     L.m6a_host_free.argtypes = [vp]
+    L.m6a_host_is_pinned.argtypes = [vp, C.c_size_t]
     L.m6a_last_encoder_kernel.argtypes = [vp]
     L.m6a_last_encoder_kernel.restype = C.c_char_p
     L.m6a_encode_reads.argtypes = [vp, vp, vp, vp, i64, vp]

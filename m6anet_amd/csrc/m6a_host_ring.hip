@@ -51,13 +51,50 @@ void release_staging(m6a_ctx *c)
 
 // Caller memory the DMA engines can address directly: page-locked by hipHostMalloc / hipHostRegister (torch's pin_memory()).
 // Such buffers skip the staging copy in both directions -- the chunks are still cut and overlapped the same way.
-bool is_pinned_host(const void *p)
+// The WHOLE range [p, p + bytes) must lie inside ONE page-locked allocation (probing the first and the last byte
+// accepts a buffer that starts in one registration and ends in another with pageable pages between, and the in-place DMA
+// would then run over pageable memory): the runtime is asked for the allocation's base and size.  If this runtime cannot
+// say (the range attributes fail), the buffer is treated as pageable -- the ring path is always correct.
+bool is_pinned_host(const void *p, size_t bytes)
 {
-    if (!p) return false;
+    if (!p || !bytes) return false;
     hipPointerAttribute_t at;
     if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }
-    return at.type == hipMemoryTypeHost;
+    if (at.type != hipMemoryTypeHost) return false;
+    void *base = nullptr;
+    size_t size = 0;
+    if (hipPointerGetAttribute(&base, HIP_POINTER_ATTRIBUTE_RANGE_START_ADDR, (hipDeviceptr_t)p) != hipSuccess ||
+        hipPointerGetAttribute(&size, HIP_POINTER_ATTRIBUTE_RANGE_SIZE, (hipDeviceptr_t)p) != hipSuccess || !base || !size) {
+        (void)hipGetLastError();
+        return false;
+    }
+    // hipHostRegister'ed memory may report the DEVICE-side alias of the range: compare offsets inside the allocation, not addresses
+    const char *host_base = (const char *)base;
+    if ((const char *)p < host_base || (const char *)p >= host_base + size) {
+        if (!at.devicePointer || !at.hostPointer) return false;
+        host_base = (const char *)base - ((const char *)at.devicePointer - (const char *)at.hostPointer);
+        if ((const char *)p < host_base || (const char *)p >= host_base + size) return false;
+    }
+    return (const char *)p + bytes <= host_base + size;
 }
+
+// An error exit of a host-pointer call that DMAs caller memory in place must not leave copies in flight: they read X and
+// write rp_host, and a caller that recycles those buffers after the error (torch's pinned caching allocator does exactly
+// that) would see stale D2H writes land in reused memory.  The pageable path never exposes caller memory to
+// asynchronous DMA -- the ring's slots are the library's own.
+struct DrainOnError {
+    m6a_ctx *c;
+    bool armed;
+    ~DrainOnError()
+    {
+        if (!armed) return;
+        Staging &g = c->stg;
+        if (g.s_h2d) (void)hipStreamSynchronize(g.s_h2d);
+        if (g.s_d2h) (void)hipStreamSynchronize(g.s_d2h);
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipGetLastError();
+    }
+};
 
 // Encodes a job whose X / site_kmers / off live in HOST memory: the job is cut at site boundaries into chunks of
 // <= chunk_reads reads; chunk k is copied by the host threads into a pinned slot, DMA'd on its own stream and
@@ -88,9 +125,10 @@ int staged_encode(m6a_ctx *c, const float *X, const uint8_t *km, const int64_t *
         return M6A_OK;
     }
     const size_t slot_bytes = (size_t)g.chunk_reads * 9 * 4;
-    // pinned caller buffers (the first and the last byte are looked up: one allocation) go straight onto the link
-    const bool x_pinned = is_pinned_host(X) && is_pinned_host((const char *)(X + R * 9) - 1);
-    const bool rp_pinned = rp_host && is_pinned_host(rp_host) && is_pinned_host((const char *)(rp_host + R) - 1);
+    // pinned caller buffers (the whole range inside one page-locked allocation) go straight onto the link
+    const bool x_pinned = is_pinned_host(X, (size_t)R * 9 * 4);
+    const bool rp_pinned = rp_host && is_pinned_host(rp_host, (size_t)R * 4);
+    DrainOnError drain{c, x_pinned || rp_pinned};             // every `return rc` / HIPCHK exit below waits for the in-place DMA first
     // ring item 0: the CSR offsets and the k-mer ids, through a pinned slot like everything else
     const size_t off_bytes = (size_t)(S + 1) * 8, km_bytes = (size_t)S * 3;
     int item = 0;
@@ -158,6 +196,7 @@ int staged_encode(m6a_ctx *c, const float *X, const uint8_t *km, const int64_t *
     if (rp_pinned) HIPCHK(c, hipStreamSynchronize(g.s_d2h));         // the contract: the read probabilities are in rp_host on return
     // the caller may reuse X as soon as the call returns: its last chunk must have left it
     if (x_pinned) HIPCHK(c, hipStreamSynchronize(g.s_h2d));
+    drain.armed = false;                                      // success: the two waits above are the contract, the encoders stay queued
     return M6A_OK;
 }
 
@@ -167,7 +206,7 @@ int staged_outputs(m6a_ctx *c, int64_t S, float *site, double *mod)
 {
     Staging &g = c->stg;
     const size_t slot_bytes = g.ready ? (size_t)g.chunk_reads * 9 * 4 : 0;
-    const bool direct = is_pinned_host(site) && is_pinned_host(mod);
+    const bool direct = is_pinned_host(site, (size_t)S * 4) && is_pinned_host(mod, (size_t)S * 8);
     if (direct || (size_t)S * 8 > slot_bytes) {
         HIPCHK(c, hipMemcpyAsync(site, c->sSite.p, (size_t)S * 4, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipMemcpyAsync(mod, c->sMod.p, (size_t)S * 8, hipMemcpyDeviceToHost, c->stream));
@@ -218,3 +257,8 @@ int d2h_through_ring(m6a_ctx *c, void *host, const void *dev, size_t bytes)
 
 
 }  // namespace m6a_detail
+
+extern "C" int m6a_host_is_pinned(const void *p, size_t bytes)
+{
+    return m6a_detail::is_pinned_host(p, bytes) ? 1 : 0;
+}

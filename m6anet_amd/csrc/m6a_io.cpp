@@ -1382,13 +1382,46 @@ static int dataprep_impl(const char *eventalign_path, const char *out_dir, int n
                          int readcount_min, int readcount_max, int min_segment_count, int n_neighbors,
                          int compress, int skip_index);
 
-// Test hook (tests/test_dataprep.py): M6A_IO_TEST_THROW=index|transcript|index_file makes that phase run out of memory once,
-// on whichever thread gets there first -- what the try/catch blocks below are for cannot be provoked reliably otherwise.
+// Test hook (tests/test_dataprep.py): M6A_IO_TEST_THROW=index|transcript|index_file|bookkeeping makes that phase run out of memory
+// once, on whichever thread gets there first -- what the try/catch blocks below are for cannot be provoked reliably otherwise.
+// Compiled ONLY into test builds (-DM6A_IO_TEST_HOOKS: tests/test_dataprep.py and tests/sanitize.sh build their own copy); the
+// shipped libm6a_io.so reads no such variable.
+#ifdef M6A_IO_TEST_HOOKS
 static void test_throw(const char *where)
 {
     static const char *want = getenv("M6A_IO_TEST_THROW");
     if (want && !strcmp(want, where)) throw std::bad_alloc();
 }
+#else
+static inline void test_throw(const char *) {}
+#endif
+
+// What dataprep holds open while code that can throw runs (std::bad_alloc in its bookkeeping, std::system_error from a
+// std::thread constructor): closed on every exit path, the stdio streams BEFORE the buffers setvbuf gave them go away (a guard is
+// declared after what it must outlive), and outputs a failed run leaves half-written are removed -- a truncated data.json next
+// to a data.info that indexes into it is worse than no output.
+struct FileCloser {
+    FILE *f = nullptr;
+    explicit FileCloser(FILE *f_) : f(f_) {}
+    FileCloser(const FileCloser &) = delete;
+    FileCloser &operator=(const FileCloser &) = delete;
+    int close() { FILE *g = f; f = nullptr; return g ? fclose(g) : 0; }
+    ~FileCloser() { (void)close(); }
+};
+struct FdCloser {
+    int fd = -1;
+    explicit FdCloser(int fd_) : fd(fd_) {}
+    FdCloser(const FdCloser &) = delete;
+    FdCloser &operator=(const FdCloser &) = delete;
+    int release() { const int g = fd; fd = -1; return g; }
+    ~FdCloser() { if (fd >= 0) (void)::close(fd); }
+};
+struct PartialOutputs {
+    std::vector<std::string> paths;
+    bool keep = false;
+    void add(const std::string &p) { paths.push_back(p); }
+    ~PartialOutputs() { if (!keep) for (const std::string &p : paths) (void)::unlink(p.c_str()); }
+};
 
 // No exception crosses the C ABI: the files this targets run to hundreds of GB, and the index (32 B per read run), the
 // per-transcript buffers and the writers' text can all exhaust memory -- that is M6A_IO_ENOMEM, not an aborted interpreter.
@@ -1439,6 +1472,9 @@ static int dataprep_impl(const char *eventalign_path, const char *out_dir, int n
         return id;
     };
     const std::string idx_path = dir + "/eventalign.index";
+    // declared before the index writer and the stream guards: destroyed after them, i.e. after the writer thread has been joined
+    // and every stream closed -- then, unless the run succeeded, the files this call created are removed
+    PartialOutputs partial;
     // eventalign.index is written BEHIND the transcript pass: nothing downstream reads the file (the pass works from `idx`), and
     // writing 2.6 GB of it was 1.1 s of a 7.2 s run with every worker waiting at two barriers per batch (format, then pwrite).
     // Declared after `idx` / `tx_names`, which it reads: its destructor joins the thread before they go, on every return path.
@@ -1451,6 +1487,7 @@ static int dataprep_impl(const char *eventalign_path, const char *out_dir, int n
     if (skip_index) {
         FILE *f = fopen(idx_path.c_str(), "r");
         if (!f) return fail(M6A_IO_EIO, "--skip_index but %s does not exist", idx_path.c_str());
+        FileCloser fc(f);                                  // idx.push_back / intern can throw
         char line[4096];
         bool first = true;
         while (fgets(line, sizeof line, f)) {
@@ -1464,7 +1501,7 @@ static int dataprep_impl(const char *eventalign_path, const char *out_dir, int n
             r.tx = intern(line, strlen(line));
             idx.push_back(r);
         }
-        fclose(f);
+        (void)fc.close();
     } else {
         const char *body = (const char *)memchr(base, '\n', ev.n);
         if (!body) return fail(M6A_IO_EFORMAT, "%s: no header line", eventalign_path);
@@ -1537,6 +1574,9 @@ static int dataprep_impl(const char *eventalign_path, const char *out_dir, int n
         // the workers, then every range pwrite()s its own text at its offset, while the transcript pass runs on all of them
         const int fd = ::open(idx_path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
         if (fd < 0) return fail(M6A_IO_EIO, "cannot write %s", idx_path.c_str());
+        FdCloser fd_guard(fd);                             // until the writer thread exists and owns it (std::thread's constructor can throw)
+        partial.add(idx_path);
+        test_throw("bookkeeping");
         std::vector<size_t> bounds((size_t)NC + 1, total);
         for (int k = 0; k < NC; k++) bounds[(size_t)k] = chunks[(size_t)k].out;
         const int nbg = std::max(1, nw / 4);
@@ -1590,6 +1630,7 @@ static int dataprep_impl(const char *eventalign_path, const char *out_dir, int n
             idx_writer.oom = true;
           }
         });
+        (void)fd_guard.release();                          // the thread closes it
     }
     trace.mark("dataprep: index file handed to its writer");
     if (ev.p && ev.n) (void)madvise((void *)ev.p, ev.n, MADV_NORMAL);       // the transcript pass jumps between a read's runs
@@ -1608,9 +1649,13 @@ static int dataprep_impl(const char *eventalign_path, const char *out_dir, int n
     trace.mark("dataprep: rows per transcript");
     // ---- per transcript on all threads, written in transcript order AS SOON AS every earlier one is written: memory holds a
     // bounded window of finished transcripts, not the whole data.json
+    std::vector<char> jbuf(4 << 20), ibuf(1 << 20);     // before the streams that use them: the guards below close first
     FILE *fj = fopen((dir + "/data.json").c_str(), "w"), *fi = fopen((dir + "/data.info").c_str(), "w"), *fl = fopen((dir + "/data.log").c_str(), "w");
-    if (!fj || !fi || !fl) { if (fj) fclose(fj); if (fi) fclose(fi); if (fl) fclose(fl); return fail(M6A_IO_EIO, "cannot write into %s", out_dir); }
-    std::vector<char> jbuf(4 << 20), ibuf(1 << 20);
+    FileCloser cj(fj), ci(fi), cl(fl);
+    if (fj) partial.add(dir + "/data.json");
+    if (fi) partial.add(dir + "/data.info");
+    if (fl) partial.add(dir + "/data.log");
+    if (!fj || !fi || !fl) return fail(M6A_IO_EIO, "cannot write into %s", out_dir);
     setvbuf(fj, jbuf.data(), _IOFBF, jbuf.size());
     setvbuf(fi, ibuf.data(), _IOFBF, ibuf.size());
     fputs("transcript_id,transcript_position,start,end,n_reads\n", fi);
@@ -1702,7 +1747,7 @@ static int dataprep_impl(const char *eventalign_path, const char *out_dir, int n
         for (auto &t : th) t.join();
     }
     int bad = 0;
-    bad |= fclose(fj); bad |= fclose(fi); bad |= fclose(fl);
+    bad |= cj.close(); bad |= ci.close(); bad |= cl.close();
     if (failed) return fail(fail_rc, "%s", fail_msg.c_str());
     if (written != NT) return fail(M6A_IO_EIO, "internal: %lld of %lld transcripts written", (long long)written, (long long)NT);
     if (bad) return fail(M6A_IO_EIO, "cannot close outputs in %s", out_dir);
@@ -1712,5 +1757,6 @@ static int dataprep_impl(const char *eventalign_path, const char *out_dir, int n
     if (!idx_writer.ok) return fail(M6A_IO_EIO, "cannot write %s", idx_path.c_str());
     trace.mark("dataprep: index file finished behind them");
     if (trace.on) fprintf(stderr, "m6a_io: dataprep peak of finished-but-unwritten json: %.1f MB (budget %.0f MB, window %lld transcripts)\n", peak_pending / 1e6, pending_budget / 1e6, (long long)window);
+    partial.keep = true;
     return M6A_IO_OK;
 }

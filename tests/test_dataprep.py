@@ -272,26 +272,56 @@ def test_dataprep_edge_files(tmp_path):
         assert got[1] == want[1] and all(np.array_equal(got[0][k][1], want[0][k][1]) for k in want[0])
 
 
-@pytest.mark.parametrize("phase", ["index", "transcript", "index_file"])
-def test_out_of_memory_on_any_thread_is_an_error_code_not_an_abort(eventalign, tmp_path, phase):
+@pytest.fixture(scope="module")
+def io_lib_with_test_hooks(tmp_path_factory):
+    """The fault-injection hook (M6A_IO_TEST_THROW) is compiled only into test builds (-DM6A_IO_TEST_HOOKS; ADVICE r5: the shipped
+    libm6a_io.so reads no such variable).  tests/sanitize.sh hands over its own sanitized hook build in M6A_IO_LIB_HOOKS."""
+    import subprocess
+    given = os.environ.get("M6A_IO_LIB_HOOKS")
+    if given:
+        return given
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path_factory.mktemp("iolib") / "libm6a_io_hooks.so")
+    subprocess.check_call([os.environ.get("CXX", "g++"), "-O1", "-std=c++17", "-fPIC", "-shared", "-pthread", "-DM6A_IO_TEST_HOOKS",
+                           "-I" + os.path.join(repo, "include"), "-I" + os.path.join(repo, "m6anet_amd", "csrc"),
+                           os.path.join(repo, "m6anet_amd", "csrc", "m6a_io.cpp"), "-o", out])
+    return out
+
+
+def test_shipped_io_library_has_no_fault_injection_hook():
+    assert b"M6A_IO_TEST_THROW" not in open(_io.LIB_PATH, "rb").read() or "M6A_IO_LIB" in os.environ
+
+
+@pytest.mark.parametrize("phase", ["index", "transcript", "index_file", "bookkeeping"])
+def test_out_of_memory_on_any_thread_is_an_error_code_not_an_abort(eventalign, tmp_path, phase, io_lib_with_test_hooks):
     """ADVICE r4: m6a_io_dataprep runs its phases on std::threads; an exception on a worker would be std::terminate, one on the
     calling thread would unwind through the C ABI.  M6A_IO_TEST_THROW makes the named phase throw std::bad_alloc once (the
-    index pass on a pool thread, the transcript pass on a worker, the index file on its background writer): the call must
-    return M6A_IO_ENOMEM, the process must live, and the library must work again afterwards."""
+    index pass on a pool thread, the transcript pass on a worker, the index file on its background writer, `bookkeeping` on the
+    CALLING thread right after the index file was opened): the call must return M6A_IO_ENOMEM, the process must live, no
+    half-written output may stay behind (streams and descriptors are closed by guards, partial files removed), and
+    the library must work again afterwards."""
     import subprocess
     import sys
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = ("import sys; sys.path.insert(0, %r)\n"
+    code = ("import sys, os; sys.path.insert(0, %r)\n"
             "from m6anet_amd import _io\n"
             "try:\n"
             "    _io.dataprep(%r, %r, n_threads=4)\n"
             "    print('NO ERROR')\n"
             "except _io.M6AIOError as e:\n"
-            "    print('RC', e.code)\n" % (repo, eventalign, str(tmp_path)))
-    env = dict(os.environ, M6A_IO_TEST_THROW=phase, M6A_IO_INDEX_RANGE_KB="16")
+            "    print('RC', e.code)\n"
+            "print('FDS', len(os.listdir('/proc/self/fd')))\n" % (repo, eventalign, str(tmp_path)))
+    outputs = ("data.json", "data.info", "data.log", "eventalign.index")
+    env = dict(os.environ, M6A_IO_TEST_THROW=phase, M6A_IO_INDEX_RANGE_KB="16", M6A_IO_LIB=io_lib_with_test_hooks)
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, (r.returncode, r.stderr[-500:])           # alive: no std::terminate, no abort
-    assert r.stdout.strip() == "RC -2", (r.stdout, r.stderr[-500:])     # M6A_IO_ENOMEM
+    lines = r.stdout.split()
+    assert lines[:2] == ["RC", "-2"], (r.stdout, r.stderr[-500:])       # M6A_IO_ENOMEM
+    fds_after_failure = int(lines[3])
+    assert [f for f in outputs if os.path.exists(os.path.join(str(tmp_path), f))] == [], phase   # nothing half-written stays
     env.pop("M6A_IO_TEST_THROW")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0 and r.stdout.strip() == "NO ERROR", (r.stdout, r.stderr[-500:])
+    lines = r.stdout.split()
+    assert r.returncode == 0 and lines[:2] == ["NO", "ERROR"], (r.stdout, r.stderr[-500:])
+    assert all(os.path.getsize(os.path.join(str(tmp_path), f)) > 0 for f in outputs if f != "data.log")
+    assert fds_after_failure == int(lines[3]), "a failed dataprep leaked descriptors"     # same count as after a clean run

@@ -972,6 +972,42 @@ def test_pinned_numpy_arrays_without_torch(engines):
     assert pinned_empty(0, np.float32).size == 0
 
 
+def test_host_is_pinned_checks_the_whole_range(eng):
+    """m6a_host_is_pinned = the test the host-pointer calls apply before they DMA caller memory in place: the WHOLE
+    range must lie inside ONE page-locked allocation -- not just its first and last byte."""
+    import ctypes as C
+    import torch
+    from m6anet_amd.engine import pinned_empty
+    L = eng._L
+    a, b = pinned_empty(1 << 20, np.uint8), pinned_empty(1 << 20, np.uint8)
+    pa, pb = a.ctypes.data, b.ctypes.data
+    assert L.m6a_host_is_pinned(pa, 1 << 20) == 1 and L.m6a_host_is_pinned(pa + 4096, (1 << 20) - 4096) == 1
+    assert L.m6a_host_is_pinned(pa + 12345, 1000) == 1
+    assert L.m6a_host_is_pinned(pa, 1 << 30) == 0                       # runs out of its allocation
+    lo, hi = min(pa, pb), max(pa, pb)
+    assert L.m6a_host_is_pinned(lo, hi - lo + (1 << 20)) == 0           # first and last byte page-locked, two allocations
+    page = np.zeros(1 << 20, np.uint8)
+    assert L.m6a_host_is_pinned(page.ctypes.data, page.nbytes) == 0     # pageable
+    t = torch.empty(1 << 18, dtype=torch.float32).pin_memory()
+    assert L.m6a_host_is_pinned(t.data_ptr(), t.numel() * 4) == 1       # torch's pinned allocator (hipHostMalloc blocks, sub-allocated)
+    dev = torch.empty(1024, dtype=torch.float32, device="cuda")
+    assert L.m6a_host_is_pinned(dev.data_ptr(), 4096) == 0              # device memory is not host memory
+    assert L.m6a_host_is_pinned(None, 10) == 0 and L.m6a_host_is_pinned(pa, 0) == 0
+    # hipHostRegister'ed pageable memory: one registration is in; a range over two registrations with a pageable page between is out
+    hip = C.CDLL("libamdhip64.so")
+    big = np.zeros(3 << 20, np.uint8)
+    base = (big.ctypes.data + 4095) & ~4095
+    assert hip.hipHostRegister(C.c_void_p(base), C.c_size_t(1 << 20), 0) == 0
+    assert hip.hipHostRegister(C.c_void_p(base + (1 << 20) + 4096), C.c_size_t(1 << 20), 0) == 0
+    try:
+        assert L.m6a_host_is_pinned(base, 1 << 20) == 1
+        assert L.m6a_host_is_pinned(base + (1 << 20) + 4096, 1 << 20) == 1
+        assert L.m6a_host_is_pinned(base, (2 << 20) + 4096) == 0
+    finally:
+        hip.hipHostUnregister(C.c_void_p(base))
+        hip.hipHostUnregister(C.c_void_p(base + (1 << 20) + 4096))
+
+
 def test_infer_equals_encode_then_pool_for_every_pooling_kernel(engines):
     """m6a_infer sets the pooling up on a side stream while the encoder runs (a dry launch_pool); whatever kernel the
     pooling takes -- forced scan drivers, index tables, both uniform-bag kernels -- the fused call must give what

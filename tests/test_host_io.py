@@ -364,3 +364,37 @@ def test_sharded_csv_writer_never_writes_stale_text(tmp_path):
         if what == "same":
             assert (len(got[0]), len(got[1])) == (head[0] + sizes[0], head[1] + sizes[1])
     nat.close()
+
+
+def test_sharded_csv_size_call_does_not_pin_the_callers_arrays():
+    """csv_shard_size keeps what the csv_shard_write that follows needs -- but only weak references to the CALLER's
+    arrays (read_prob is 4 bytes per read: GBs) and strong ones to its own converted temporaries; a size call that raises, is
+    never followed by its write, or is followed by another csv_* call or close() must leave nothing alive."""
+    import gc
+    import weakref
+    from m6anet_amd import _io
+    nat = _io.NativeSites([DATA], 20, data_utils.load_norm_factors("norm_hct116.npz"), 2)
+    S, R = nat.tx_pos.size, nat.X.shape[0]
+    g = np.random.Generator(np.random.PCG64(3))
+
+    def arrays():
+        return g.random(R, dtype=np.float32), g.random(S, dtype=np.float32), g.random(S)
+
+    rp, sp, mr = arrays()
+    refs = [weakref.ref(x) for x in (rp, sp, mr)]
+    nat.csv_shard_size(0, S, rp, sp, mr)
+    del rp, sp, mr
+    gc.collect()
+    assert all(r() is None for r in refs), "a size call without its write pinned the caller's arrays"
+    # converted temporaries (float64 read_prob -> float32) are the handle's own: dropped by the next size call, write_csv or close()
+    rp, sp, mr = arrays()
+    nat.csv_shard_size(0, S, rp.astype(np.float64), sp, mr)
+    kept = nat._shard_kept
+    assert kept is not None and kept[1][0][1] is not None and kept[1][0][1].dtype == np.float32 and kept[1][1][1] is None
+    nat.csv_shard_size(0, S, rp, sp, mr)
+    assert nat._shard_kept is not kept and all(conv is None for _, conv in nat._shard_kept[1])
+    with pytest.raises(_io.M6AIOError):
+        nat.csv_shard_size(5, S + 1, rp[:0], sp[:0], mr[:0]) if False else _io._chk(_io.load().m6a_io_csv_shard_size(nat._h, None, None, None, 5, S + 1, 1, None, None))
+    nat.csv_shard_size(0, S, rp, sp, mr)
+    nat.close()
+    assert nat._shard_kept is None

@@ -69,7 +69,7 @@ def main():
             if k in c:
                 print("   %-28s / SQ_WAVE_CYCLES %6.3f" % (k, c[k] / wc))
         if "GRBM_GUI_ACTIVE" in c and 4 in t:
-            print("   effective clock, pass 4               %8.3f GHz (GRBM_GUI_ACTIVE / avg duration)" % (c["GRBM_GUI_ACTIVE"] / (t[4][1] * 1e3)))
+            print("   effective clock, pass 4               %8.3f GHz (GRBM_GUI_ACTIVE / 8 XCDs / avg duration)" % (c["GRBM_GUI_ACTIVE"] / 8.0 / (t[4][1] * 1e3)))
 
 
 if __name__ == "__main__":
