@@ -85,6 +85,12 @@ def ranks_may_share_a_gpu():
     return os.environ.get("M6A_SHARE_GPU") == "1" or os.environ.get("M6A_EXCHANGE") == "host"
 
 
+def rccl_is_a_standin():
+    """M6A_RCCL_STANDIN=1: the library named by M6A_RCCL_LIB is not RCCL but a stand-in transport that accepts several ranks on
+    one device (tests/stub_rccl: how a one-GPU box executes the M6A_EXCHANGE=rccl leg).  A real RCCL refuses two ranks on a device."""
+    return os.environ.get("M6A_RCCL_STANDIN") == "1" and bool(os.environ.get("M6A_RCCL_LIB"))
+
+
 def strip_command(argv):
     """argv without the sub-command word: what start_ranks was given by maybe_start."""
     return list(argv[1:]) if argv and argv[0] == "inference" else list(argv)
@@ -119,6 +125,11 @@ def cleanup():
 
 def maybe_start(argv):
     """Called by `python -m m6anet_amd` before any other import: `inference ... --gpus N` with N > 1, not itself a rank."""
+    # The CLI's own process (launcher, and the ranks it starts: they inherit it): multi-process GPU work -- RCCL's P2P set-up --
+    # exchanges memory handles, and the host driver of these boxes supports dmabuf IPC only; without this hipIpcGetMemHandle fails
+    # with "invalid argument".  Set HERE, for this command's processes, before any HIP runtime is mapped -- not in the library
+    # binding, which must not edit the environment of a host application that imports it (ADVICE r5).
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     try:
         if not argv or argv[0] != "inference" or "M6A_RANK" in os.environ or "-h" in argv or "--help" in argv:
             return

@@ -33,10 +33,10 @@ def _preload_hip_runtime():
     map ITS runtime before libm6a_hip.so so both bind to the same one, whichever is imported
     first.  (torch itself is not imported here.)"""
     import importlib.util
-    # multi-process GPU work (RCCL's P2P set-up, the ranks of `inference --gpus N` and bench.py) exchanges memory handles: the
-    # host driver of these boxes supports dmabuf IPC only, and without this hipIpcGetMemHandle fails with "invalid argument".
-    # The boxes export it already; a process started from a scrubbed environment gets it here, before the runtime is mapped.
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # (HSA_ENABLE_IPC_MODE_LEGACY=0, which multi-process RCCL work needs on these boxes, is NOT set here any more: the library
+    # binding must not edit the environment of whatever application imports it (ADVICE r5).  The package's own multi-process
+    # entry points set it for their processes -- `python -m m6anet_amd` (m6anet_amd/_early.py) and bench.py; a host application
+    # that drives m6a_comm_* itself exports it, as INTEGRATION.md says.)
     try:
         spec = importlib.util.find_spec("torch")
     except (ImportError, ValueError):

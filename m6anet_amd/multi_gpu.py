@@ -26,7 +26,8 @@ that gather every step.
 M6A_EXCHANGE = none (default) | rccl | host.  rccl: the 128-byte RCCL id travels through the exchange directory (rank 0
 writes it, the others wait for it).  host is a debugging aid like bench.py's M6A_BENCH_BACKEND=gloo: the gather goes
 through files in the exchange directory instead of RCCL.  M6A_SHARE_GPU=1 (implied by host) lets ranks share a GPU
-(rank % devices; RCCL refuses two ranks on one device), which is how the one-GPU test box checks that N = 2..8 ranks give
+(rank % devices; RCCL refuses two ranks on one device, so rccl + M6A_SHARE_GPU is accepted only with M6A_RCCL_STANDIN=1 and the
+stand-in transport named in M6A_RCCL_LIB: tests/test_gpu_comm_stub.py), which is how the one-GPU test box checks that N = 2..8 ranks give
 the CSV bytes of one.
 """
 import os
@@ -80,7 +81,9 @@ def exchange_mode(world):
     if mode not in ("none", "rccl", "host"):
         raise ValueError("M6A_EXCHANGE must be 'none', 'rccl' or 'host'")
     share = _early.ranks_may_share_a_gpu()
-    if mode == "rccl" and share:
+    if mode == "rccl" and share and not _early.rccl_is_a_standin():
+        # a real RCCL refuses two ranks on one device; M6A_RCCL_STANDIN=1 + M6A_RCCL_LIB name a stand-in transport that does
+        # not -- tests/test_gpu_comm_stub.py runs this leg that way on a one-GPU box
         raise ValueError("M6A_EXCHANGE=rccl needs one GPU per rank (M6A_SHARE_GPU is set)")
     if not share and device_count() < world:
         raise RuntimeError("--gpus %d but only %d HIP device(s) visible (M6A_SHARE_GPU=1 lets ranks share a GPU for debugging)"

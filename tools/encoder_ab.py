@@ -1,0 +1,101 @@
+#!/usr/bin/env python3
+"""A/B of encoder-kernel builds on the bench shape (20 M reads): HIP-event time per launch of the two scalar-chain kernels, per build,
+legs interleaved A B C A B C ... so clock drift hits every build alike.
+
+    python tools/encoder_ab.py --build          (here: cross-compiles the variants into tools/ko/, which travels to the GPU box)
+    python tools/encoder_ab.py [legs]           (GPU box: one JSON line)
+
+Variants = the product source with ONE macro each (m6a_kernels.hip, `#ifdef M6A_AB_*`):
+  base               the product
+  csite_scalar_fma   VERDICT r5 item 3(a): link3's 30 v_pk_fma_f32 as 60 plain v_fma_f32, in place between the MFMA groups (same bits)
+  csite_pin          the 30 v_pk_fma_f32 kept where they are written (hipcc otherwise sinks them behind the epilogue; same bits)
+  no_epilogue        knock-out, WRONG results: the 32 -> 1 layer + sigmoid removed from enc_site16_kernel (what the epilogue costs in
+                     place = the most that hiding it under the next tile's MFMAs could buy)
+"""
+import json
+import os
+import subprocess
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+KO = os.path.join(REPO, "tools", "ko")
+VARIANTS = {"base": [], "csite_scalar_fma": ["-DM6A_AB_CSITE_SCALAR_FMA"], "csite_pin": ["-DM6A_AB_CSITE_PIN"], "no_epilogue": ["-DM6A_AB_NO_EPILOGUE"]}
+EXTRA = [a for a in sys.argv[1:] if a.startswith("+")]       # +name=-DMACRO adds a variant from the command line
+
+
+def lib(name):
+    return os.path.join(KO, "libm6a_ab_%s.so" % name)
+
+
+def build():
+    from m6anet_amd import build as B
+    os.makedirs(KO, exist_ok=True)
+    jump = os.path.join(B.PKG, "assets", "mt19937_jump.bin")
+    for name, flags in VARIANTS.items():
+        cmd = [os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+               '-DM6A_MT_JUMP_PATH="%s"' % jump, "-I" + B.INCLUDE, "-I" + B.CSRC] + flags + [os.path.join(B.CSRC, s) for s in B.SOURCES] + ["-o", lib(name)]
+        subprocess.check_call(cmd)
+        print("built", lib(name))
+
+
+def one(legs_unused):
+    import torch
+    from m6anet_amd import synthetic
+    from m6anet_amd.engine import M6ANetEngine, load_weights
+    eng = M6ANetEngine(weights=load_weights("HCT116_RNA002"))
+    d = synthetic.make_sites(1_000_000, 20, seed=20250328)
+    X, km, off = (torch.from_numpy(d[k]).cuda() for k in ("X", "site_kmers", "off"))
+    rp = torch.empty(int(d["off"][-1]), dtype=torch.float32, device="cuda")
+    out = {}
+    for mode, label in ((0, "enc_site16_kernel"), (2, "enc_csite_kernel")):
+        eng.set_encoder_variant(mode)
+        for _ in range(5):
+            eng.get_read_probability(X, km, off, out=rp)
+        eng.sync()
+        eng.profile("encoder")
+        for _ in range(40):
+            eng.get_read_probability(X, km, off, out=rp)
+        ms, n = eng.profile_read(0)
+        clk = eng.profile_clock(0)
+        eng.profile(False)
+        assert eng.last_encoder_kernel == label
+        out[label] = [round(ms / n, 5), round(clk["ghz"], 4) if clk else None]
+    print(json.dumps(out))
+
+
+def main():
+    if "--build" in sys.argv:
+        for a in EXTRA:
+            n, f = a[1:].split("=", 1)
+            VARIANTS[n] = f.split(",")
+        build()
+        return
+    if "--one" in sys.argv:
+        one(0)
+        return
+    nums = [a for a in sys.argv[1:] if a.isdigit()]
+    legs = int(nums[0]) if nums else 4
+    names = [n for n in list(VARIANTS) + [a[1:].split("=")[0] for a in EXTRA] if os.path.exists(lib(n))]
+    res = {n: {} for n in names}
+    for leg in range(legs):
+        for n in names:
+            o = subprocess.run([sys.executable, os.path.abspath(__file__), "--one"], env=dict(os.environ, M6A_HIP_LIB=lib(n)), capture_output=True, text=True, timeout=600)
+            try:
+                r = json.loads(o.stdout.strip().splitlines()[-1])
+            except (ValueError, IndexError):
+                res[n].setdefault("error", []).append((o.stderr or o.stdout)[-300:])
+                continue
+            for k, v in r.items():
+                res[n].setdefault(k, []).append(v)
+    summary = {}
+    for n, r in res.items():
+        summary[n] = {k: {"median_ms": sorted(x[0] for x in v)[len(v) // 2], "ms_of_each_leg": [x[0] for x in v], "ghz_of_each_leg": [x[1] for x in v]}
+                      for k, v in r.items() if k != "error"}
+        if "error" in r:
+            summary[n]["error"] = r["error"]
+    print(json.dumps({"legs": legs, "launches_per_leg": 40, "workload": "20 M reads (1 M sites x 20), HCT116", "builds": summary}))
+
+
+if __name__ == "__main__":
+    main()
