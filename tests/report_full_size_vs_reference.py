@@ -35,10 +35,10 @@ def main():
         w = np.fromfile(asset_path("weights_%s.bin" % name), np.float32)
         e = M6ANetEngine(weights=w)
         row = {}
-        for mode, label in ((1, "general16"), (2, "csite12")):
+        for mode, label in ((0, "auto (general16)"), (2, "csite12 (opt-in)")):       # 0 = nothing set: what the product runs
             e.set_encoder_variant(mode)
             u = use(e.get_read_probability(d["X"], d["site_kmers"], d["off"]), ref)
-            row[label] = {"worst_use": float(u.max()), "reads_beyond_bar": int((u > 1).sum()), "p99.9999_use": float(np.quantile(u, 0.999999)),
+            row[label] = {"kernel": e.last_encoder_kernel, "worst_use": float(u.max()), "reads_beyond_bar": int((u > 1).sum()), "p99.9999_use": float(np.quantile(u, 0.999999)),
                           "reads_not_bit_identical": int((u > 0).sum())}
         u = use(orc.encode_reads(w, d["X"], d["site_kmers"], d["off"], n_threads=16), ref)
         row["oracle"] = {"worst_use": float(u.max()), "reads_beyond_bar": int((u > 1).sum())}
@@ -49,7 +49,7 @@ def main():
             ex = np.load(exact)
             u = use(ref, ex)
             row["reference_vs_float64"] = {"worst_use": float(u.max()), "reads_beyond_bar": int((u > 1).sum()), "rms_use": float(np.sqrt((u * u).mean()))}
-            for mode, label in ((1, "general16"), (2, "csite12")):
+            for mode, label in ((0, "auto (general16)"), (2, "csite12 (opt-in)")):
                 e.set_encoder_variant(mode)
                 u = use(e.get_read_probability(d["X"], d["site_kmers"], d["off"]), ex)
                 row[label + "_vs_float64"] = {"worst_use": float(u.max()), "reads_beyond_bar": int((u > 1).sum()), "rms_use": float(np.sqrt((u * u).mean()))}

@@ -17,8 +17,8 @@ SHORT="python bench.py --min-seconds 0 --steps 6 --warmup 2 --no-cpu-baseline --
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/${T}_pmc_fetch -o pmc -- $SHORT > /dev/null 2> $O/${T}_pmc_fetch.err
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/${T}_pmc_write -o pmc -- $SHORT > /dev/null 2> $O/${T}_pmc_write.err
 timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT --kernel-trace -d $O/${T}_pmc_sq -o pmc -- $SHORT > /dev/null 2> $O/${T}_pmc_sq.err
-# the product's default encoder (16 slots, the reference's order): the same trace with it selected
-M6A_ENCODER=general16 timeout 600 rocprofv3 --kernel-trace --stats -d $O/${T}_trace_general16 -o bench -- $CMD > $O/${T}_trace_general16.json 2> $O/${T}_trace_general16.err
+# (the traces above run the library's automatic encoder = the product's: enc_site16_kernel.)  The opt-in 12-slot encoder: the same trace with it selected
+M6A_ENCODER=fast timeout 600 rocprofv3 --kernel-trace --stats -d $O/${T}_trace_fast -o bench -- $CMD > $O/${T}_trace_fast.json 2> $O/${T}_trace_fast.err
 RCMD="python bench.py --workload ragged --min-seconds 0 --no-cpu-baseline --no-live-traffic"
 timeout 600 rocprofv3 --kernel-trace --stats -d $O/${T}_trace_ragged -o bench -- $RCMD > $O/${T}_trace_ragged.json 2> $O/${T}_trace_ragged.err
 RSHORT="python bench.py --workload ragged --min-seconds 0 --steps 6 --warmup 2 --no-cpu-baseline --no-live-traffic"
@@ -41,6 +41,17 @@ python tools/stream_probe.py > $O/${T}_stream.json 2> $O/${T}_stream.err
 python tools/measure_misc.py > $O/${T}_misc.json 2> $O/${T}_misc.err
 python tools/measure_cli.py > $O/${T}_cli.json 2> $O/${T}_cli.err
 bash tools/measure_cli_gpus.sh > $O/${T}_cli_gpus.json 2>> $O/${T}_cli.err
+# where the encoder's SIMD cycles go (both kernels, four counter groups) and the A/B builds of tools/encoder_ab.py (if tools/ko/ travelled)
+bash tools/encoder_floor.sh ${T} > /dev/null 2>&1
+if ls tools/ko/libm6a_ab_*.so > /dev/null 2>&1; then python tools/encoder_ab.py 3 > $O/${T}_encoder_ab.json 2> $O/${T}_encoder_ab.err; fi
+# the rows either side of the path, on this box's host: rooflines, the dataprep run DESIGN.md quotes, the whole pipeline, the CLI's CSVs
+python tools/host_rooflines.py 4.0 300 > $O/${T}_host_rooflines.json 2> $O/${T}_host_rooflines.err
+python tools/measure_dataprep.py ${DATAPREP_GB:-22} --single > $O/${T}_dataprep.json 2> $O/${T}_dataprep.err
+python tools/measure_pipeline.py > $O/${T}_pipeline.json 2> $O/${T}_pipeline.err
+python tools/cli_csv_vs_reference.py > $O/${T}_cli_csv_vs_reference.txt 2>&1
+# HIP kernels against the REFERENCE's own read probabilities at full size, if tests/golden/_big travelled (.gpurunignore line taken out for this call)
+if ls tests/golden/_big/configs2_*.npy > /dev/null 2>&1; then python tests/report_full_size_vs_reference.py > $O/${T}_full_size_vs_reference.json 2> $O/${T}_full_size.err; fi
+if ls tests/golden/_big/configs4_*.npy > /dev/null 2>&1; then python tests/report_full_size_vs_reference.py --ragged > $O/${T}_full_size_vs_reference_ragged.json 2>> $O/${T}_full_size.err; fi
 find $O -name "*.db" -path "*${T}_*" -size +20M -delete
 find $O -path "*${T}_tl*" -size +10M -delete
 echo done
