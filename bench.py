@@ -228,11 +228,11 @@ def host_cpu_facts():
 def cpu_calibration():
     """tests/golden/calibrate_cpu_baseline.py (build container, imports the reference): oracle vs the reference's own NumPy / torch
     code on the same inputs, one thread.  BASELINE.md section 3: the port stands for the reference within +-10 % or this factor."""
-    path = os.path.join(REPO, "profiles", "r04_cpu_calibration.json")
+    path = os.path.join(REPO, "profiles", "r06_cpu_calibration.json")
     try:
         with open(path) as f:
             c = json.load(f)
-        return {"file": "profiles/r04_cpu_calibration.json", "oracle_over_reference": c["oracle_over_reference"],
+        return {"file": "profiles/r06_cpu_calibration.json", "oracle_over_reference": c["oracle_over_reference"],
                 "measured_on": c.get("host"), "note": c.get("note")}
     except (OSError, ValueError, KeyError):
         return None

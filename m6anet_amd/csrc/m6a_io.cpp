@@ -1068,6 +1068,32 @@ void py_repr(double v, std::string &out)
 // np.round(x, d): x * 10^d, rint (half to even), / 10^d
 inline double np_round(double x, double scale) { return std::nearbyint(x * scale) / scale; }
 
+// repr() of a value that np_round produced (k / scale, scale = 10 or 1000): its shortest round-trip digits ARE the decimal
+// k / scale with trailing zeros dropped -- no shortest-digits search needed (a third of data.json's numbers are means rounded
+// to one decimal; with --compress all of them have three).  Only where that is provably what repr gives: 0 < |v| < 1e9 (a
+// decimal step of 1/scale is then far above half an ulp, so no shorter string can round to the same double) and v is the
+// double nearest to k / scale; everything else takes py_repr.
+inline bool repr_rounded(double v, double scale, int digits, std::string &out)
+{
+    const double av = std::fabs(v);
+    if (!(av > 0 && av < 1e9)) return false;
+    const long long k = std::llrint(av * scale);
+    if (k == 0 || (double)k / scale != av) return false;
+    const long long sc = (long long)scale, ip = k / sc;
+    long long fr = k % sc;
+    char buf[40];
+    int n = 0;
+    if (v < 0) buf[n++] = '-';
+    n += format_i64(ip, buf + n);
+    buf[n++] = '.';
+    int nd = digits;
+    while (nd > 1 && fr % 10 == 0) { fr /= 10; --nd; }
+    for (int i = nd - 1; i >= 0; i--) { buf[n + i] = (char)('0' + fr % 10); fr /= 10; }
+    n += nd;
+    out.append(buf, (size_t)n);
+    return true;
+}
+
 // pandas groupby sum (pandas/_libs/groupby.pyx group_sum): Kahan-compensated
 struct Kahan {
     double sum = 0, comp = 0;
@@ -1080,91 +1106,150 @@ struct Kahan {
     }
 };
 
-struct Pos { long long position; std::string kmer; double dwell, sd, mean; };
+// k-mers are views into the mapped eventalign.txt (alive for the whole call): no allocation per event
+struct Pos { long long position; std::string_view kmer; double dwell, sd, mean; };
 
-const std::set<std::string> &drach18()
+// the 18 DRACH 5-mers (m6anet/utils/dataprep_utils.py: the centre must be one of them): [AGT][GA]AC[ACT]
+inline bool is_drach(std::string_view k)
 {
-    static const std::set<std::string> s = [] {
-        std::set<std::string> r;
-        for (char d : std::string("AGT")) for (char g : std::string("GA")) for (char h : std::string("ACT"))
-            r.insert(std::string{d, g, 'A', 'C', h});
-        return r;
-    }();
-    return s;
+    return k.size() == 5 && (k[0] == 'A' || k[0] == 'G' || k[0] == 'T') && (k[1] == 'G' || k[1] == 'A') && k[2] == 'A' && k[3] == 'C' &&
+           (k[4] == 'A' || k[4] == 'C' || k[4] == 'T');
 }
 
-// split one line into tab-separated fields (pointers into the mapping)
-inline int split_tabs(const char *p, const char *e, const char *(&b)[16], const char *(&en)[16])
+// One line: the offsets of its first 15 tab-separated fields and the line's end, in ONE pass over the bytes (round 6; rounds 3-5:
+// memchr for the newline, then a byte loop over the line for the tabs -- the parse was 40 % of the transcript pass).  16 bytes at a
+// time with SSE2 (baseline x86-64) while a whole vector fits before `safe` (the end of the mapping: a 16-byte load must not cross
+// it), byte by byte for the last few.  fe[i] = end of field i; returns the number of fields seen (<= 16) and sets le to the newline
+// (or e).  Fields beyond the 16th are not recorded.
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
+inline int scan_line(const char *p, const char *e, const char *safe, const char *(&fe)[16], const char *&le)
 {
     int n = 0;
     const char *q = p;
-    while (n < 16) {
-        b[n] = q;
-        while (q < e && *q != '\t') ++q;
-        en[n] = q;
-        ++n;
-        if (q >= e) break;
-        ++q;
+#if defined(__SSE2__)
+    const __m128i tab = _mm_set1_epi8('\t'), nl = _mm_set1_epi8('\n');
+    while (q + 16 <= safe && q < e) {
+        const __m128i v = _mm_loadu_si128((const __m128i *)q);
+        unsigned mt = (unsigned)_mm_movemask_epi8(_mm_cmpeq_epi8(v, tab)), mn = (unsigned)_mm_movemask_epi8(_mm_cmpeq_epi8(v, nl));
+        if (q + 16 > e) {                                  // the run ends inside this vector: ignore what lies beyond it
+            const unsigned keep = (1u << (unsigned)(e - q)) - 1u;
+            mt &= keep; mn &= keep;
+        }
+        if (mn) {
+            const unsigned first_nl = (unsigned)__builtin_ctz(mn);
+            mt &= (1u << first_nl) - 1u;
+            while (mt) { if (n < 16) fe[n++] = q + __builtin_ctz(mt); mt &= mt - 1; }
+            le = q + first_nl;
+            if (n < 16) fe[n++] = le;
+            return n;
+        }
+        while (mt) { if (n < 16) fe[n++] = q + __builtin_ctz(mt); mt &= mt - 1; }
+        q += 16;
     }
+#else
+    (void)safe;
+#endif
+    for (; q < e; ++q) {
+        if (*q == '\n') break;
+        if (*q == '\t' && n < 16) fe[n++] = q;
+    }
+    le = q;                                                // the newline, or e
+    if (n < 16) fe[n++] = q;
     return n;
 }
 
 // combine() for the lines of ONE (contig, read) run: per position the length-weighted means
-// (dataprep_utils.py:269-325).  Returns false on malformed input.
-bool combine_read(const char *p, const char *e, std::vector<Pos> &out)
+// (dataprep_utils.py:269-325).  Returns false on malformed input.  `safe` = end of the mapping.
+bool combine_read(const char *p, const char *e, const char *safe, std::vector<Pos> &out)
 {
-    struct Ev { long long position; std::string kmer; double mean, sd, len_s; long long length; };
-    std::vector<Ev> evs;
+    struct Ev { long long position; std::string_view kmer; double mean, sd, len_s; long long length; };
+    // scratch that keeps its capacity from run to run (one pair per worker thread): a run is tens of events, and
+    // allocating / freeing two vectors per run was visible in the profile
+    static thread_local std::vector<Ev> evs;
+    static thread_local std::vector<uint32_t> order;
+    evs.clear();
+    // position, start_idx, end_idx are integers in every eventalign.txt (pandas reads them as int64): plain digits
+    // take the integer path, anything else (a sign, a dot, an exponent) the general number parser
+    auto int_field = [](const char *p, const char *e, long long &out) {
+        if (p >= e || e - p > 18) return false;
+        long long v = 0;
+        for (const char *q = p; q < e; ++q) {
+            if (*q < '0' || *q > '9') return false;
+            v = v * 10 + (*q - '0');
+        }
+        out = v;
+        return true;
+    };
+    auto any_field = [&](const char *p, const char *e, long long &out) {
+        if (int_field(p, e, out)) return true;
+        double d;
+        Cursor c{p, e};
+        if (!c.num(d)) return false;
+        out = (long long)d;
+        return true;
+    };
+    // the three float fields: digits [. digits] with at most 15 digit characters is what nanopolish writes ("95.31", "0.00299") --
+    // mantissa / 10^frac, both exact doubles, one correctly rounded division (Clinger's fast path, as in Cursor::num, without its
+    // per-character case analysis); anything else (a sign, an exponent, more digits, a name) goes to Cursor::num, same result
+    auto float_field = [](const char *p, const char *e, double &out) {
+        static const double p10[] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15};
+        const char *q = p;
+        uint64_t mant = 0;
+        while (q < e && (unsigned)(*q - '0') < 10u) mant = mant * 10 + (uint64_t)(*q++ - '0');
+        int nd = (int)(q - p), frac = 0;
+        if (q < e && *q == '.') {
+            const char *f = ++q;
+            while (q < e && (unsigned)(*q - '0') < 10u) mant = mant * 10 + (uint64_t)(*q++ - '0');
+            frac = (int)(q - f);
+            nd += frac;
+        }
+        if (q != e || nd == 0 || nd > 15) {
+            Cursor c{p, e};
+            return c.num(out);
+        }
+        out = (double)mant / p10[frac];
+        return true;
+    };
+    bool sorted = true;
     while (p < e) {
-        const char *le = (const char *)memchr(p, '\n', (size_t)(e - p));
-        if (!le) le = e;
+        const char *fe[16], *le;
+        const int nf = scan_line(p, e, safe, fe, le);
         const char *eol = le;
         if (eol > p && eol[-1] == '\r') --eol;
         if (eol > p) {
-            const char *b[16], *en[16];
-            const int nf = split_tabs(p, eol, b, en);
             if (nf < 15) return false;
+            if (fe[nf - 1] > eol) fe[nf - 1] = eol;        // the last field ends before a '\r'
+            // field i = [fe[i-1] + 1, fe[i]); field 0 starts at p
+            const char *b2 = fe[1] + 1, *b9 = fe[8] + 1;
             // reference_kmer == model_kmer  (dataprep_utils.py:287)
-            if ((en[2] - b[2]) == (en[9] - b[9]) && memcmp(b[2], b[9], (size_t)(en[2] - b[2])) == 0) {
+            if ((fe[2] - b2) == (fe[9] - b9) && memcmp(b2, b9, (size_t)(fe[2] - b2)) == 0) {
                 Ev ev;
-                // position, start_idx, end_idx are integers in every eventalign.txt (pandas reads them as int64): plain digits
-                // take the integer path, anything else (a sign, a dot, an exponent) the general number parser
-                auto int_field = [](const char *p, const char *e, long long &out) {
-                    if (p >= e || e - p > 18) return false;
-                    long long v = 0;
-                    for (const char *q = p; q < e; ++q) {
-                        if (*q < '0' || *q > '9') return false;
-                        v = v * 10 + (*q - '0');
-                    }
-                    out = v;
-                    return true;
-                };
-                auto any_field = [&](const char *p, const char *e, long long &out) {
-                    if (int_field(p, e, out)) return true;
-                    double d;
-                    Cursor c{p, e};
-                    if (!c.num(d)) return false;
-                    out = (long long)d;
-                    return true;
-                };
                 long long st, ed;
-                Cursor c6{b[6], en[6]}, c7{b[7], en[7]}, c8{b[8], en[8]};
-                if (!any_field(b[1], en[1], ev.position) || !c6.num(ev.mean) || !c7.num(ev.sd) || !c8.num(ev.len_s) ||
-                    !any_field(b[13], en[13], st) || !any_field(b[14], en[14], ed)) return false;
+                if (!any_field(fe[0] + 1, fe[1], ev.position) || !float_field(fe[5] + 1, fe[6], ev.mean) || !float_field(fe[6] + 1, fe[7], ev.sd) ||
+                    !float_field(fe[7] + 1, fe[8], ev.len_s) ||
+                    !any_field(fe[12] + 1, fe[13], st) || !any_field(fe[13] + 1, fe[14], ed)) return false;
                 ev.length = ed - st;
-                ev.kmer.assign(b[2], en[2]);
-                evs.push_back(std::move(ev));
+                ev.kmer = std::string_view(b2, (size_t)(fe[2] - b2));
+                if (!evs.empty()) {
+                    const Ev &pv = evs.back();
+                    if (pv.position > ev.position || (pv.position == ev.position && pv.kmer > ev.kmer)) sorted = false;
+                }
+                evs.push_back(ev);
             }
         }
         p = le + 1;
     }
-    // groupby(['read_index','contig','position','reference_kmer']): sorted keys, rows in file order
-    std::vector<size_t> order(evs.size());
-    for (size_t i = 0; i < order.size(); i++) order[i] = i;
-    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b2) {
-        if (evs[a].position != evs[b2].position) return evs[a].position < evs[b2].position;
-        return evs[a].kmer < evs[b2].kmer;
-    });
+    // groupby(['read_index','contig','position','reference_kmer']): sorted keys, rows in file order.  A run that is already
+    // in key order (the usual case: nanopolish writes a read's events by position) needs no sort -- a stable sort keeps it as is.
+    order.resize(evs.size());
+    for (size_t i = 0; i < order.size(); i++) order[i] = (uint32_t)i;
+    if (!sorted)
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b2) {
+            if (evs[a].position != evs[b2].position) return evs[a].position < evs[b2].position;
+            return evs[a].kmer < evs[b2].kmer;
+        });
     size_t i = 0;
     while (i < order.size()) {
         size_t j = i;
@@ -1186,7 +1271,7 @@ bool combine_read(const char *p, const char *e, std::vector<Pos> &out)
         ps.mean = np_round(sm.sum / (double)total, 10.0);      // (sum_norm_mean/total_length).round(1)
         ps.sd = ss.sum / (double)total;
         ps.dwell = sd.sum / (double)total;
-        out.push_back(std::move(ps));
+        out.push_back(ps);
         i = j;
     }
     return true;
@@ -1223,7 +1308,7 @@ void preprocess_transcript(const char *base, size_t file_size, const std::string
         const IdxRun &r = idx[ri];
         if (r.start < 0 || r.end > (int64_t)file_size || r.start > r.end) { o.rc = M6A_IO_EFORMAT; o.err = "index row outside eventalign.txt"; return; }
         std::vector<Pos> ps;
-        if (!combine_read(base + r.start, base + r.end, ps)) { o.rc = M6A_IO_EFORMAT; o.err = "malformed eventalign line for " + tx; return; }
+        if (!combine_read(base + r.start, base + r.end, base + file_size, ps)) { o.rc = M6A_IO_EFORMAT; o.err = "malformed eventalign line for " + tx; return; }
         if (ps.size() > 1) {                          // `if data.size > 1`
             if (!by_read.count(r.read)) read_order.push_back(r.read);
             by_read[r.read] = std::move(ps);
@@ -1243,10 +1328,10 @@ void preprocess_transcript(const char *base, size_t file_size, const std::string
             while (b < ps.size() && ps[b].position == ps[b - 1].position + 1) ++b;
             if (b - a >= 2 * W + 1) {
                 for (size_t i = a + W; i + W < b; i++) {
-                    if (!drach18().count(ps[i].kmer)) continue;
+                    if (!is_drach(ps[i].kmer)) continue;
                     SiteRow sr;
                     sr.pos = ps[i].position + 2;      // centre of the 5-mer
-                    sr.kmer = ps[i - W].kmer;         // combine_sequence: first 5-mer + the last base of every later one
+                    sr.kmer.assign(ps[i - W].kmer);   // combine_sequence: first 5-mer + the last base of every later one
                     for (size_t k = i - W + 1; k <= i + W; k++) sr.kmer += ps[k].kmer.back();
                     sr.f = feat.size();
                     for (size_t k = i - W; k <= i + W; k++) {      // roll(): previous ..., centre, next ...; [dwell, sd, mean] each
@@ -1273,12 +1358,18 @@ void preprocess_transcript(const char *base, size_t file_size, const std::string
         }
         if ((int)(j - i) >= min_segment_count) {
             const size_t start = o.json.size();
+            o.json.reserve(start + (j - i) * (NF * 22 + 28) + tx.size() + 64);
             o.json += "{\"" + tx + "\":{\"" + std::to_string(sites[i].pos) + "\":{\"" + sites[i].kmer + "\":[";
             for (size_t k = i; k < j; k++) {
                 o.json += k == i ? "[" : ",[";
                 for (size_t c = 0; c < NF; c++) {
                     const double v = feat[sites[k].f + c];
-                    py_repr(compress ? np_round(v, 1000.0) : v, o.json);
+                    if (compress) {
+                        const double r = np_round(v, 1000.0);
+                        if (!repr_rounded(r, 1000.0, 3, o.json)) py_repr(r, o.json);
+                    } else if (c % 3 != 2 || !repr_rounded(v, 10.0, 1, o.json)) {    // c % 3 == 2: the mean, already rounded to one decimal
+                        py_repr(v, o.json);
+                    }
                     o.json += ',';
                 }
                 if (sites[k].read >= 0 && sites[k].read < (1LL << 53)) {      // repr(float(int)): the digits and ".0"

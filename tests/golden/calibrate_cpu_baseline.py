@@ -7,7 +7,7 @@ tests/golden/make_golden.py -- times both on the SAME inputs, one thread each, a
                get_read_representation + probability_layer per 16-site batch (:33-37), torch on one thread
     oracle     oracle/m6a_oracle.c through oracle/m6a_oracle.py, n_threads = 1
 
-    python tests/golden/calibrate_cpu_baseline.py        # -> profiles/r04_cpu_calibration.json
+    python tests/golden/calibrate_cpu_baseline.py        # -> profiles/r06_cpu_calibration.json
 
 bench.py's cpu_baseline carries the factor (`calibration`, `reference_equivalent_value` = oracle sites/s / factor).
 """
@@ -113,7 +113,7 @@ def main():
     out["note"] = ("one thread each, best of 3, same inputs, in the build container (the reference cannot travel to the GPU box); "
                    "oracle_over_reference > 1 means the C port is FASTER than the reference's NumPy/torch code, i.e. the cpu_baseline "
                    "in the bench line flatters the CPU by that factor; reference_equivalent_value = value / whole_path")
-    with open(os.path.join(REPO, "profiles", "r04_cpu_calibration.json"), "w") as f:
+    with open(os.path.join(REPO, "profiles", "r06_cpu_calibration.json"), "w") as f:
         json.dump(out, f, indent=1)
         f.write("\n")
     print(json.dumps(out["oracle_over_reference"]), "within 10%:", within)
