@@ -100,6 +100,11 @@ int m6a_io_format_f16(double v, char *buf336);
  * otherwise.  buf40 holds >= 40 bytes, NUL-terminated; returns the length.  Exported so the tests can pin it against
  * Python's own repr. */
 int m6a_io_py_repr(double v, char *buf40);
+/* The writer's fast path for values np.round produced -- the mean (one decimal, dataprep_utils.py:293) and, with --compress,
+ * every feature (three decimals): k / 10^digits written positionally with trailing zeros dropped, which IS repr() of such a
+ * double for 0 < |v| < 1e9; returns the length, or -1 where the fast path declines (zero, huge, not the double nearest to
+ * k / 10^digits, digits other than 1 or 3) and m6a_io_py_repr's general algorithm is used.  Exported for the tests. */
+int m6a_io_repr_rounded(double v, int digits, char *buf40);
 
 /* `m6anet dataprep` (m6anet/scripts/dataprep.py:54-70 -> m6anet/utils/dataprep_utils.py):
  * eventalign.txt -> <out_dir>/eventalign.index (parallel_index, :187-266), data.json + data.info +

@@ -8,7 +8,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("M6A_IO_LIB") or os.path.join(_PKG, "libm6a_io.so")   # M6A_IO_LIB: e.g. the sanitizer build (tests/sanitize.sh)
 SYMBOLS = ["m6a_io_last_error", "m6a_io_load_sites", "m6a_io_free", "m6a_io_n_sites", "m6a_io_n_reads",
            "m6a_io_n_replicates", "m6a_io_X", "m6a_io_site_kmers", "m6a_io_off", "m6a_io_tx_pos",
-           "m6a_io_read_ids", "m6a_io_read_rep", "m6a_io_tx_id", "m6a_io_kmer5", "m6a_io_write_csv", "m6a_io_write_csv_n", "m6a_io_csv_shard_size", "m6a_io_csv_shard_write", "m6a_io_csv_header_bytes", "m6a_io_format_f16", "m6a_io_py_repr",
+           "m6a_io_read_ids", "m6a_io_read_rep", "m6a_io_tx_id", "m6a_io_kmer5", "m6a_io_write_csv", "m6a_io_write_csv_n", "m6a_io_csv_shard_size", "m6a_io_csv_shard_write", "m6a_io_csv_header_bytes", "m6a_io_format_f16", "m6a_io_py_repr", "m6a_io_repr_rounded",
            "m6a_io_save_store", "m6a_io_open_store", "m6a_io_store_tag", "m6a_io_dataprep"]
 _lib = None
 
@@ -52,6 +52,8 @@ def load():
     L.m6a_io_format_f16.restype = i32
     L.m6a_io_py_repr.argtypes = [C.c_double, C.c_char_p]
     L.m6a_io_py_repr.restype = i32
+    L.m6a_io_repr_rounded.argtypes = [C.c_double, i32, C.c_char_p]
+    L.m6a_io_repr_rounded.restype = i32
     L.m6a_io_save_store.argtypes = [vp, C.c_char_p, C.c_char_p]
     L.m6a_io_open_store.argtypes = [C.c_char_p, C.POINTER(vp)]
     L.m6a_io_store_tag.argtypes = [vp]

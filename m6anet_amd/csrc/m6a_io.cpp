@@ -1469,6 +1469,17 @@ extern "C" int m6a_io_py_repr(double v, char *buf40)
     return (int)s.size();
 }
 
+// the fast path of the data.json writer for numbers np.round produced (repr_rounded above): the text, or -1 where it declines
+// and py_repr is used instead.  Exported so the tests can pin it against Python's repr(round(x, digits)).
+extern "C" int m6a_io_repr_rounded(double v, int digits, char *buf40)
+{
+    if (digits != 1 && digits != 3) return -1;
+    std::string s;
+    if (!repr_rounded(v, digits == 1 ? 10.0 : 1000.0, digits, s) || s.size() >= 40) return -1;
+    std::memcpy(buf40, s.c_str(), s.size() + 1);
+    return (int)s.size();
+}
+
 static int dataprep_impl(const char *eventalign_path, const char *out_dir, int n_threads,
                          int readcount_min, int readcount_max, int min_segment_count, int n_neighbors,
                          int compress, int skip_index);

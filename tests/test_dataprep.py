@@ -215,6 +215,33 @@ def test_float_text_is_pythons_repr():
     assert not bad, bad[:5]
 
 
+def test_rounded_numbers_fast_path_is_pythons_repr():
+    """Round 6: a third of data.json's numbers are means rounded to one decimal (all of them have three with --compress); the
+    writer prints those as k / 10^d with trailing zeros dropped instead of searching for the shortest digits.  Wherever the fast
+    path accepts a value its text must be Python's repr of it; where it declines (zero, huge, values that are not np.round
+    results) the general m6a_io_py_repr path is pinned by the test above."""
+    import ctypes as C
+    L = _io.load()
+    buf = C.create_string_buffer(40)
+    g = np.random.Generator(np.random.PCG64(7))
+    accepted = 0
+    for digits in (1, 3):
+        xs = np.concatenate([g.normal(100, 40, 120_000), g.random(60_000) * 0.05, g.random(40_000) * 10.0 ** g.integers(-6, 10, 40_000),
+                             -g.random(20_000) * 300, np.arange(-2000, 2000) / 8.0, [0.05, 0.15, 0.25, 0.35, 1e8 + 0.1, 999999999.9, 1e9, 1e12 + 0.5, 0.0, -0.0, 1e-7]])
+        for v in np.round(xs, digits):
+            v = float(v)
+            n = L.m6a_io_repr_rounded(v, digits, buf)
+            if n < 0:
+                assert v == 0 or abs(v) >= 1e9 or round(v, digits) != v, v       # declines only where it says it does
+                continue
+            accepted += 1
+            assert buf.value.decode() == repr(v), (v.hex(), digits, buf.value.decode(), repr(v))
+        for v in (g.random(20_000) * 100):                                        # NOT rounded: must decline (or, by luck, be exact)
+            n = L.m6a_io_repr_rounded(float(v), digits, buf)
+            assert n < 0 or buf.value.decode() == repr(float(v))
+    assert accepted > 400_000
+
+
 def test_workers_run_ahead_by_bytes_and_write_in_order(tmp_path, monkeypatch):
     """Transcripts are processed on all threads and written in index order as soon as their predecessors are; how far the
     workers run ahead is a budget of finished-but-unwritten JSON.  With the budget at its minimum (1 MB against ~12 MB of
@@ -235,6 +262,37 @@ def test_workers_run_ahead_by_bytes_and_write_in_order(tmp_path, monkeypatch):
     _io.dataprep(str(big), out, n_threads=8, readcount_min=1, readcount_max=1000, min_segment_count=5)
     for fn in ("eventalign.index", "data.json", "data.info", "data.log"):
         assert open(os.path.join(out, fn), "rb").read() == open(os.path.join(one, fn), "rb").read(), fn
+
+
+def test_line_scanner_extra_columns_and_a_file_that_ends_on_a_page_boundary(tmp_path):
+    """Round 6's one-pass field scanner reads 16 bytes at a time: it must never load across the end of the mapping (a file whose
+    size is a multiple of the page size has NOTHING mapped behind its last byte), must ignore columns beyond the 15 the reference
+    reads (nanopolish --samples / --signal-index add some), and must cope with lines of any length: the outputs are those of the
+    plain file."""
+    import mmap
+    text = gzip.open(os.path.join(REF, "eventalign.txt.gz"), "rt").read()
+    header, body = text.split("\n", 1)
+    lines = body.rstrip("\n").split("\n")[:4000]
+    plain = tmp_path / "plain.txt"
+    plain.write_text(header + "\n" + "\n".join(lines) + "\n")
+    want = str(tmp_path / "want")
+    _io.dataprep(str(plain), want, n_threads=2, readcount_min=1, readcount_max=1000, min_segment_count=1)
+    assert os.path.getsize(os.path.join(want, "data.json")) > 10_000
+    page = mmap.PAGESIZE
+    for tag, with_newline in (("page_nl", True), ("page_nonl", False)):
+        g = np.random.Generator(np.random.PCG64(5))
+        wide = [l + "\t" + "s" * int(g.integers(0, 40)) + ("\textra" if i % 3 == 0 else "") for i, l in enumerate(lines)]
+        blob = (header + "\tsamples\n" + "\n".join(wide)).encode()
+        tail = b"\n" if with_newline else b""
+        pad = (-(len(blob) + len(tail))) % page                  # grow the LAST line's extra column until the file ends on a page boundary
+        blob += b"x" * pad + tail
+        assert len(blob) % page == 0
+        f = tmp_path / (tag + ".txt")
+        f.write_bytes(blob)
+        out = str(tmp_path / tag)
+        _io.dataprep(str(f), out, n_threads=3, readcount_min=1, readcount_max=1000, min_segment_count=1)
+        for fn in ("data.json", "data.info"):
+            assert open(os.path.join(out, fn), "rb").read() == open(os.path.join(want, fn), "rb").read(), (tag, fn)
 
 
 def test_dataprep_edge_files(tmp_path):

@@ -76,6 +76,24 @@ def rand_probs(seed, off):
     return (g.random(int(off[-1]), dtype=np.float32) ** 4).astype(np.float32)
 
 
+# ------------------------------------------------------------------ the checker, checked where the kernels are checked ----
+def test_oracle_pinning_tests_pass_on_this_box_too():
+    """the driver's GPU run selects `-m gpu`, which deselects every test that holds the ORACLE to the
+    reference's captured vectors (tests/test_oracle_golden.py, tests/test_reference_at_scale.py: 53 CPU tests, 12 s) -- so the
+    evidence that the checker equals the reference lived in builder / judge runs only.  This gpu-marked test runs that subset
+    as it is, on the box whose HIP-vs-oracle results it vouches for (another CPU, another libm: the oracle is -ffp-contract=off
+    C with its own expf, so its bits must not depend on either)."""
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_oracle_golden.py", "tests/test_reference_at_scale.py", "-q", "-m", "not gpu",
+                        "-p", "no:cacheprovider"], cwd=repo, capture_output=True, text=True, timeout=900)
+    tail = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else ""
+    assert r.returncode == 0 and " passed" in tail and "failed" not in tail, (r.stdout[-1500:], r.stderr[-500:])
+    assert int(tail.split(" passed")[0].split()[-1]) >= 53, tail
+
+
 # ------------------------------------------------------------------ encoder -----------------
 def test_encoder_golden_all_models(golden, engines):
     b = golden("bundled_inputs.npz")
