@@ -498,6 +498,11 @@ __global__ __launch_bounds__(256, 2) void enc_site16_kernel(EncArgs a)
 
     BnPairs bnq;
     bn_pairs_load(bnq, bn_half);
+#ifdef M6A_AB_PRIO_HALF
+    // A/B build only (tools/encoder_ab.py): static priority for the second-dispatched workgroup of every CU (MI355X guide, two waves
+    // per SIMD, item 4) -- VALU issue is arbitrated by priority, then age
+    if (blockIdx.x >= (gridDim.x >> 1)) __builtin_amdgcn_s_setprio(1);
+#endif
     for (int tile = tile0; tile < tile1; ++tile) {
         // the chain always runs (for the last tile it refetches that tile): no guard, no merge
         const int tn = tile + 1 < tile1 ? tile + 1 : tile;
@@ -505,6 +510,9 @@ __global__ __launch_bounds__(256, 2) void enc_site16_kernel(EncArgs a)
         int64_t o[3];
         int reln, kidn;
         link0(s_base, o);
+#ifdef M6A_AB_PRIO_BODY
+        __builtin_amdgcn_s_setprio(1);               // A/B build only: the MFMA body outranks the partner wave's epilogue for VALU issue
+#endif
 
         f32x16 acc2, h1a, h1b;
 #pragma unroll
@@ -533,6 +541,9 @@ __global__ __launch_bounds__(256, 2) void enc_site16_kernel(EncArgs a)
             if (m == 3) layer2_with_bn<3>(acc2, cur, w2, bnq, bn_half);
             if (m == 4) layer2_with_bn<4>(acc2, cur, w2, bnq, bn_half);
         }
+#ifdef M6A_AB_PRIO_BODY
+        __builtin_amdgcn_s_setprio(0);
+#endif
 #ifdef M6A_AB_NO_EPILOGUE
         // knock-out build only (tools/encoder_ab.py): what the 32 -> 1 layer + sigmoid cost in place -- an upper bound on what
         // moving them under the next tile's MFMAs could buy.  WRONG results by construction; never the product.

@@ -9,6 +9,8 @@ Variants = the product source with ONE macro each (m6a_kernels.hip, `#ifdef M6A_
   base               the product
   csite_scalar_fma   VERDICT r5 item 3(a): link3's 30 v_pk_fma_f32 as 60 plain v_fma_f32, in place between the MFMA groups (same bits)
   csite_pin          the 30 v_pk_fma_f32 kept where they are written (hipcc otherwise sinks them behind the epilogue; same bits)
+  prio_half          enc_site16_kernel: s_setprio 1 for the second-dispatched workgroup of every CU (static priority, same bits)
+  prio_body          enc_site16_kernel: s_setprio 1 through a tile's MFMA body, 0 through its epilogue (same bits)
   no_epilogue        knock-out, WRONG results: the 32 -> 1 layer + sigmoid removed from enc_site16_kernel (what the epilogue costs in
                      place = the most that hiding it under the next tile's MFMAs could buy)
 """
@@ -20,7 +22,8 @@ import sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 KO = os.path.join(REPO, "tools", "ko")
-VARIANTS = {"base": [], "csite_scalar_fma": ["-DM6A_AB_CSITE_SCALAR_FMA"], "csite_pin": ["-DM6A_AB_CSITE_PIN"], "no_epilogue": ["-DM6A_AB_NO_EPILOGUE"]}
+VARIANTS = {"base": [], "csite_scalar_fma": ["-DM6A_AB_CSITE_SCALAR_FMA"], "csite_pin": ["-DM6A_AB_CSITE_PIN"], "no_epilogue": ["-DM6A_AB_NO_EPILOGUE"],
+            "prio_half": ["-DM6A_AB_PRIO_HALF"], "prio_body": ["-DM6A_AB_PRIO_BODY"]}
 EXTRA = [a for a in sys.argv[1:] if a.startswith("+")]       # +name=-DMACRO adds a variant from the command line
 
 
