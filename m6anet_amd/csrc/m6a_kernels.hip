@@ -84,6 +84,26 @@ __device__ __forceinline__ float relu2(float x)
 // The (alpha', beta') pairs sit in LDS as [unit tile][lane half][register]: 16 bytes = two hidden units per load, all 32
 // lanes of a half reading the same address (a broadcast, no conflicts) -- 38 ds_read_b128 per tile, whose latency
 // layer2_with_bn (below) hides behind blocks of MFMAs.
+// Wave priority through a tile (round 6).  Two waves share a SIMD, and between them VALU issue is arbitrated by priority, then age.
+// A tile is ~8 000 cycles of MFMAs with the batch-norm fmas woven in (the BODY: every instruction of it is on the matrix pipe's
+// critical path) followed by the 32 -> 1 layer and the sigmoid (the EPILOGUE: ~85 dependent VALU instructions, no MFMA).  With the
+// body at priority 3 and the epilogue at 0, a wave in its epilogue takes only the issue slots its partner's body leaves free, instead
+// of the two being served by age: enc_site16_kernel 2.238 -> 2.216 ms per 20 M reads over four interleaved legs (priority 1: 2.222;
+// a static priority for one of the two workgroups of a CU: nothing) -- profiles/r06_encoder_ab_priority_and_packed_bn.json.
+// Same instructions, same bits.  -DM6A_AB_NO_PRIO (tools/encoder_ab.py) builds without it.
+__device__ __forceinline__ void tile_body_priority()
+{
+#ifndef M6A_AB_NO_PRIO
+    __builtin_amdgcn_s_setprio(3);
+#endif
+}
+__device__ __forceinline__ void tile_epilogue_priority()
+{
+#ifndef M6A_AB_NO_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
+}
+
 __device__ __forceinline__ void clamp_keeps_nan()
 {
     __builtin_amdgcn_s_setreg(1 | (8 << 6) | (0 << 11), 0);      // hwreg(HW_REG_MODE, offset 8, size 1) = DX10_CLAMP
@@ -118,8 +138,18 @@ __device__ __forceinline__ void layer2_with_bn(f32x16 &acc2, f32x16 &cur, const 
 #pragma unroll
         for (int i = 0; i < BN_BLOCK / 2; i++) {
             const int q = b * BN_BLOCK + 2 * i;
+#ifdef M6A_AB_BN_PK
+            // A/B build only (tools/encoder_ab.py): two hidden units per VALU instruction -- v_pk_fma_f32 with the clamp modifier on the
+            // register pair (cur[q], cur[q+1]); the kernel's preamble stores the pairs as (alpha, alpha', beta, beta').  Same fmas, same bits.
+            f32x2 y = {cur[q], cur[q + 1]};
+            const f32x2 al = {pq.v[i].x, pq.v[i].y}, be = {pq.v[i].z, pq.v[i].w};
+            asm("v_pk_fma_f32 %0, %0, %1, %2 clamp" : "+v"(y) : "v"(al), "v"(be));
+            cur[q] = y.x;
+            cur[q + 1] = y.y;
+#else
             cur[q] = bn_relu(cur[q], pq.v[i].x, pq.v[i].y);
             cur[q + 1] = bn_relu(cur[q + 1], pq.v[i].z, pq.v[i].w);
+#endif
         }
         bn_pairs_load(pq, (b + 1) * BN_BLOCK < n ? bn_half + M * 64 + 2 * (b + 1) * BN_BLOCK : bn_half + m_next * 64);
         __builtin_amdgcn_sched_barrier(0);
@@ -245,7 +275,11 @@ __global__ __launch_bounds__(256, 2) void enc_kernel(EncArgs a)
     __shared__ float s_emb[132];
     __shared__ __attribute__((aligned(16))) float s_bn[M6A_BN_FLOATS];
     for (int i = threadIdx.x; i < 132; i += 256) s_emb[i] = a.emb[i];
+#ifdef M6A_AB_BN_PK
+    for (int i = threadIdx.x; i < M6A_BN_FLOATS; i += 256) s_bn[i] = a.bn[(i & ~3) | ((i & 1) << 1) | ((i & 2) >> 1)];   // (a, b, a', b') -> (a, a', b, b')
+#else
     for (int i = threadIdx.x; i < M6A_BN_FLOATS; i += 256) s_bn[i] = a.bn[i];
+#endif
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
@@ -341,6 +375,7 @@ __global__ __launch_bounds__(256, 2) void enc_kernel(EncArgs a)
         int64_t o[3], sn;
         int km[3];
         link0(s_base, o);
+        tile_body_priority();
 
         // Layer 1 of unit-tile m+1 is issued ahead of layer 2 of unit-tile m (ping-pong
         // accumulators).  Batch norm + ReLU of the finished tile and the layer-2 MFMAs that consume it go in blocks
@@ -371,6 +406,7 @@ __global__ __launch_bounds__(256, 2) void enc_kernel(EncArgs a)
             if (m == 3) layer2_with_bn<3>(acc2, cur, w2, bnq, bn_half);
             if (m == 4) layer2_with_bn<4>(acc2, cur, w2, bnq, bn_half);
         }
+        tile_epilogue_priority();
         const float z = gemv32_as_mkl(acc2, w3, half) + a.b3;
         const float p = 1.0f / (1.0f + sleef_expf_u10(-z));
         const int64_t r = tile * 32 + col;
@@ -405,7 +441,11 @@ __global__ __launch_bounds__(256, 2) void enc_site16_kernel(EncArgs a)
     __shared__ float s_emb[132];
     __shared__ __attribute__((aligned(16))) float s_bn[M6A_BN_FLOATS];
     for (int i = threadIdx.x; i < 132; i += 256) s_emb[i] = a.emb[i];
+#ifdef M6A_AB_BN_PK
+    for (int i = threadIdx.x; i < M6A_BN_FLOATS; i += 256) s_bn[i] = a.bn[(i & ~3) | ((i & 1) << 1) | ((i & 2) >> 1)];   // (a, b, a', b') -> (a, a', b, b')
+#else
     for (int i = threadIdx.x; i < M6A_BN_FLOATS; i += 256) s_bn[i] = a.bn[i];
+#endif
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
@@ -498,11 +538,6 @@ __global__ __launch_bounds__(256, 2) void enc_site16_kernel(EncArgs a)
 
     BnPairs bnq;
     bn_pairs_load(bnq, bn_half);
-#ifdef M6A_AB_PRIO_HALF
-    // A/B build only (tools/encoder_ab.py): static priority for the second-dispatched workgroup of every CU (MI355X guide, two waves
-    // per SIMD, item 4) -- VALU issue is arbitrated by priority, then age
-    if (blockIdx.x >= (gridDim.x >> 1)) __builtin_amdgcn_s_setprio(1);
-#endif
     for (int tile = tile0; tile < tile1; ++tile) {
         // the chain always runs (for the last tile it refetches that tile): no guard, no merge
         const int tn = tile + 1 < tile1 ? tile + 1 : tile;
@@ -510,9 +545,7 @@ __global__ __launch_bounds__(256, 2) void enc_site16_kernel(EncArgs a)
         int64_t o[3];
         int reln, kidn;
         link0(s_base, o);
-#ifdef M6A_AB_PRIO_BODY
-        __builtin_amdgcn_s_setprio(1);               // A/B build only: the MFMA body outranks the partner wave's epilogue for VALU issue
-#endif
+        tile_body_priority();
 
         f32x16 acc2, h1a, h1b;
 #pragma unroll
@@ -541,9 +574,7 @@ __global__ __launch_bounds__(256, 2) void enc_site16_kernel(EncArgs a)
             if (m == 3) layer2_with_bn<3>(acc2, cur, w2, bnq, bn_half);
             if (m == 4) layer2_with_bn<4>(acc2, cur, w2, bnq, bn_half);
         }
-#ifdef M6A_AB_PRIO_BODY
-        __builtin_amdgcn_s_setprio(0);
-#endif
+        tile_epilogue_priority();
 #ifdef M6A_AB_NO_EPILOGUE
         // knock-out build only (tools/encoder_ab.py): what the 32 -> 1 layer + sigmoid cost in place -- an upper bound on what
         // moving them under the next tile's MFMAs could buy.  WRONG results by construction; never the product.
@@ -593,7 +624,11 @@ __global__ __launch_bounds__(256, 2) void enc_csite_kernel(EncArgs a)
     for (int i = threadIdx.x; i < 132; i += 256) s_emb[i] = a.emb[i];
     for (int i = threadIdx.x; i < 35 * 32; i += 256) s_w1e[i] = a.w1e_tab[i];
     __shared__ __attribute__((aligned(16))) float s_bn[M6A_BN_FLOATS];
+#ifdef M6A_AB_BN_PK
+    for (int i = threadIdx.x; i < M6A_BN_FLOATS; i += 256) s_bn[i] = a.bn[(i & ~3) | ((i & 1) << 1) | ((i & 2) >> 1)];   // (a, b, a', b') -> (a, a', b, b')
+#else
     for (int i = threadIdx.x; i < M6A_BN_FLOATS; i += 256) s_bn[i] = a.bn[i];
+#endif
     // W3 in the order the layer-2 accumulator holds the 32 units: [half][q] (16 VGPRs the tile loop needs more)
     __shared__ float s_w3[32];
     if (threadIdx.x < 64) s_w3[(threadIdx.x >> 5) * 16 + (threadIdx.x & 15)] = a.wfrag[(120 + (threadIdx.x & 15)) * 64 + (threadIdx.x & 32)];
@@ -758,6 +793,7 @@ __global__ __launch_bounds__(256, 2) void enc_csite_kernel(EncArgs a)
         int64_t o[3];
         int reln, kidn;
         link0(s_base, o);
+        tile_body_priority();
 
         auto layer1 = [&](int m, f32x16 &acc) {
 #pragma unroll
@@ -788,6 +824,7 @@ __global__ __launch_bounds__(256, 2) void enc_csite_kernel(EncArgs a)
             if (m == 3) layer2_with_bn<3>(acc2, cur, w2, bnq, bn_half);
             if (m == 4) layer2_with_bn<4>(acc2, cur, w2, bnq, bn_half);
         }
+        tile_epilogue_priority();
         float z = 0.0f;
 #pragma unroll
         for (int q = 0; q < 16; q++) z = fmaf(relu2(acc2[q]), s_w3[half * 16 + q], z);

@@ -300,8 +300,8 @@ def test_integration_stub_as_written(golden, weights, monkeypatch):
             model.feed(f, k, n)
         rp, site, mod = model.end()
         assert np.allclose(rp, want_rp, rtol=1e-5, atol=1e-8), key
-        # the stub selects the 16-slot encoder: the reference's bits but for the handful of reads MKL computed outside its
-        # groups of four rows (4 of 5 595 in this capture)
+        # the stub selects nothing: the library's default IS the 16-slot encoder -- the reference's bits but for the handful of
+        # reads MKL computed outside its groups of four rows (4 of 5 595 in this capture)
         assert int((rp.view(np.uint32) != want_rp.view(np.uint32)).sum()) <= 10, key
         assert np.allclose(site, site_g[key + "_site"], rtol=0, atol=1e-5), key          # north_star's bar, end to end
         # the reference's site probabilities come from ITS read probabilities: pool those for the bit-exact comparison

@@ -9,8 +9,8 @@ Variants = the product source with ONE macro each (m6a_kernels.hip, `#ifdef M6A_
   base               the product
   csite_scalar_fma   VERDICT r5 item 3(a): link3's 30 v_pk_fma_f32 as 60 plain v_fma_f32, in place between the MFMA groups (same bits)
   csite_pin          the 30 v_pk_fma_f32 kept where they are written (hipcc otherwise sinks them behind the epilogue; same bits)
-  prio_half          enc_site16_kernel: s_setprio 1 for the second-dispatched workgroup of every CU (static priority, same bits)
-  prio_body          enc_site16_kernel: s_setprio 1 through a tile's MFMA body, 0 through its epilogue (same bits)
+  no_prio            the product WITHOUT its wave-priority split (s_setprio 3 through a tile's MFMA body, 0 through its epilogue; same bits)
+  bn_pk              batch norm + ReLU of two hidden units per instruction: 38 v_pk_fma_f32 ... clamp instead of 76 v_fma_f32 ... clamp (same bits)
   no_epilogue        knock-out, WRONG results: the 32 -> 1 layer + sigmoid removed from enc_site16_kernel (what the epilogue costs in
                      place = the most that hiding it under the next tile's MFMAs could buy)
 """
@@ -22,8 +22,8 @@ import sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 KO = os.path.join(REPO, "tools", "ko")
-VARIANTS = {"base": [], "csite_scalar_fma": ["-DM6A_AB_CSITE_SCALAR_FMA"], "csite_pin": ["-DM6A_AB_CSITE_PIN"], "no_epilogue": ["-DM6A_AB_NO_EPILOGUE"],
-            "prio_half": ["-DM6A_AB_PRIO_HALF"], "prio_body": ["-DM6A_AB_PRIO_BODY"]}
+VARIANTS = {"base": [], "no_prio": ["-DM6A_AB_NO_PRIO"], "csite_scalar_fma": ["-DM6A_AB_CSITE_SCALAR_FMA"], "csite_pin": ["-DM6A_AB_CSITE_PIN"],
+            "no_epilogue": ["-DM6A_AB_NO_EPILOGUE"], "bn_pk": ["-DM6A_AB_BN_PK"]}
 EXTRA = [a for a in sys.argv[1:] if a.startswith("+")]       # +name=-DMACRO adds a variant from the command line
 
 
@@ -51,7 +51,7 @@ def one(legs_unused):
     X, km, off = (torch.from_numpy(d[k]).cuda() for k in ("X", "site_kmers", "off"))
     rp = torch.empty(int(d["off"][-1]), dtype=torch.float32, device="cuda")
     out = {}
-    for mode, label in ((0, "enc_site16_kernel"), (2, "enc_csite_kernel")):
+    for mode, label in ((0, "enc_site16_kernel"), (2, "enc_csite_kernel"), (3, "enc_kernel")):
         eng.set_encoder_variant(mode)
         for _ in range(5):
             eng.get_read_probability(X, km, off, out=rp)

@@ -45,7 +45,7 @@ bash tools/measure_cli_gpus.sh > $O/${T}_cli_gpus.json 2>> $O/${T}_cli.err
 bash tools/encoder_floor.sh ${T} > /dev/null 2>&1
 if ls tools/ko/libm6a_ab_*.so > /dev/null 2>&1; then python tools/encoder_ab.py 3 > $O/${T}_encoder_ab.json 2> $O/${T}_encoder_ab.err; fi
 # the rows either side of the path, on this box's host: rooflines, the dataprep run DESIGN.md quotes, the whole pipeline, the CLI's CSVs
-python tools/host_rooflines.py 4.0 300 > $O/${T}_host_rooflines.json 2> $O/${T}_host_rooflines.err
+python tools/host_rooflines.py 4.0 1400 > $O/${T}_host_rooflines.json 2> $O/${T}_host_rooflines.err
 python tools/measure_dataprep.py ${DATAPREP_GB:-22} --single > $O/${T}_dataprep.json 2> $O/${T}_dataprep.err
 python tools/measure_pipeline.py > $O/${T}_pipeline.json 2> $O/${T}_pipeline.err
 python tools/cli_csv_vs_reference.py > $O/${T}_cli_csv_vs_reference.txt 2>&1
