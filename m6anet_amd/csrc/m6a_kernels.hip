@@ -91,18 +91,40 @@ __device__ __forceinline__ float relu2(float x)
 // of the two being served by age: enc_site16_kernel 2.238 -> 2.216 ms per 20 M reads over four interleaved legs (priority 1: 2.222;
 // a static priority for one of the two workgroups of a CU: nothing) -- profiles/r06_encoder_ab_priority_and_packed_bn.json.
 // Same instructions, same bits.  -DM6A_AB_NO_PRIO (tools/encoder_ab.py) builds without it.
+#ifndef M6A_AB_PRIO_BODY
+#define M6A_AB_PRIO_BODY 3
+#define M6A_AB_PRIO_EPI 0
+#endif
 __device__ __forceinline__ void tile_body_priority()
 {
 #ifndef M6A_AB_NO_PRIO
-    __builtin_amdgcn_s_setprio(3);
+    __builtin_amdgcn_s_setprio(M6A_AB_PRIO_BODY);
 #endif
 }
 __device__ __forceinline__ void tile_epilogue_priority()
 {
 #ifndef M6A_AB_NO_PRIO
-    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_setprio(M6A_AB_PRIO_EPI);
 #endif
 }
+#ifdef M6A_AB_PHASE
+// A/B build only: the second workgroup to arrive on a CU starts its tile loop M6A_AB_PHASE x 8 128 cycles late, so the two waves of a
+// SIMD run half a tile apart (atomicInc wraps 0 -> 1 -> 0: the counter is back at 0 when both have arrived).
+__device__ unsigned m6a_ab_cu_slot[2048];
+__device__ __forceinline__ void phase_shift_second_workgroup()
+{
+    __shared__ unsigned s_slot;
+    if (threadIdx.x == 0) {
+        const unsigned hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)), xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11)) & 7;
+        s_slot = atomicInc(&m6a_ab_cu_slot[(xcc << 8) | (((hw >> 13) & 7) << 5) | (((hw >> 12) & 1) << 4) | ((hw >> 8) & 0xf)], 1u);
+    }
+    __syncthreads();
+    if (s_slot)
+        for (int i = 0; i < M6A_AB_PHASE; i++) __builtin_amdgcn_s_sleep(127);
+}
+#else
+__device__ __forceinline__ void phase_shift_second_workgroup() {}
+#endif
 
 __device__ __forceinline__ void clamp_keeps_nan()
 {
@@ -135,6 +157,9 @@ __device__ __forceinline__ void layer2_with_bn(f32x16 &acc2, f32x16 &cur, const 
     constexpr int n = L2_REGS(M), m_next = M < 4 ? M + 1 : 0;
 #pragma unroll
     for (int b = 0; b * BN_BLOCK < n; b++) {
+#ifdef M6A_AB_PRIO_BLOCK
+        __builtin_amdgcn_s_setprio(M6A_AB_PRIO_BLOCK == 1 ? 0 : 3);       // A/B build only: the block's fmas below / above its MFMAs
+#endif
 #pragma unroll
         for (int i = 0; i < BN_BLOCK / 2; i++) {
             const int q = b * BN_BLOCK + 2 * i;
@@ -153,6 +178,9 @@ __device__ __forceinline__ void layer2_with_bn(f32x16 &acc2, f32x16 &cur, const 
         }
         bn_pairs_load(pq, (b + 1) * BN_BLOCK < n ? bn_half + M * 64 + 2 * (b + 1) * BN_BLOCK : bn_half + m_next * 64);
         __builtin_amdgcn_sched_barrier(0);
+#ifdef M6A_AB_PRIO_BLOCK
+        __builtin_amdgcn_s_setprio(M6A_AB_PRIO_BLOCK == 1 ? 3 : 1);
+#endif
 #pragma unroll
         for (int q = b * BN_BLOCK; q < (b + 1) * BN_BLOCK; q++)
             acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(w2[M * 16 + q], cur[q], acc2, 0, 0, 0);
@@ -434,6 +462,26 @@ __global__ __launch_bounds__(256, 2) void enc_kernel(EncArgs a)
 // A tile that would need a fourth site raises the error flag (the host launches this kernel only when the smallest bag
 // has >= 16 reads and the job fits 32-bit indices; enc_kernel stays the path for everything else).
 // =====================================================================================
+#ifdef M6A_AB_STAMPS
+// Diagnostic build only (tools/encoder_timeline.py; never the product): every wave of enc_site16_kernel stamps s_memtime at ten points
+// of each of M6A_AB_STAMP_TILES consecutive tiles from its M6A_AB_STAMP_FIRST-th on, with its hardware slot (HW_ID, XCC_ID), so the two
+// waves that share a SIMD can be laid side by side.  The stamps are scalar instructions with no wait; lane 0 stores them after the
+// last stamp of a tile.
+#define M6A_AB_STAMP_TILES 16
+#define M6A_AB_STAMP_FIRST 100
+#define M6A_AB_STAMP_POINTS 10
+__device__ unsigned long long m6a_ab_stamp_buf[4096][M6A_AB_STAMP_TILES][M6A_AB_STAMP_POINTS];
+__device__ unsigned m6a_ab_stamp_hw[4096][2];
+extern "C" int m6a_ab_read_stamps(unsigned long long *stamps, unsigned *hw)
+{
+    if (hipMemcpyFromSymbol(stamps, HIP_SYMBOL(m6a_ab_stamp_buf), sizeof(m6a_ab_stamp_buf)) != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(hw, HIP_SYMBOL(m6a_ab_stamp_hw), sizeof(m6a_ab_stamp_hw)) != hipSuccess) return -1;
+    return 0;
+}
+#define M6A_STAMP(k) do { __builtin_amdgcn_sched_barrier(0); ts[k] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define M6A_STAMP(k) do { } while (0)
+#endif
 __global__ __launch_bounds__(256, 2) void enc_site16_kernel(EncArgs a)
 {
     clamp_keeps_nan();
@@ -536,6 +584,7 @@ __global__ __launch_bounds__(256, 2) void enc_site16_kernel(EncArgs a)
         s_base += __builtin_amdgcn_readfirstlane(__shfl(rel, 31, 64));
     }
 
+    phase_shift_second_workgroup();
     BnPairs bnq;
     bn_pairs_load(bnq, bn_half);
     for (int tile = tile0; tile < tile1; ++tile) {
@@ -544,6 +593,10 @@ __global__ __launch_bounds__(256, 2) void enc_site16_kernel(EncArgs a)
         float fn[8], evn;
         int64_t o[3];
         int reln, kidn;
+#ifdef M6A_AB_STAMPS
+        unsigned long long ts[M6A_AB_STAMP_POINTS];
+#endif
+        M6A_STAMP(0);
         link0(s_base, o);
         tile_body_priority();
 
@@ -553,6 +606,7 @@ __global__ __launch_bounds__(256, 2) void enc_site16_kernel(EncArgs a)
 #pragma unroll
         for (int st = 0; st < 8; st++)
             h1a = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[st], f[st], h1a, 0, 0, 0);
+        M6A_STAMP(1);
 #pragma unroll
         for (int m = 0; m < 5; m++) {
             f32x16 &cur = (m & 1) ? h1b : h1a;
@@ -573,6 +627,7 @@ __global__ __launch_bounds__(256, 2) void enc_site16_kernel(EncArgs a)
             if (m == 2) layer2_with_bn<2>(acc2, cur, w2, bnq, bn_half);
             if (m == 3) layer2_with_bn<3>(acc2, cur, w2, bnq, bn_half);
             if (m == 4) layer2_with_bn<4>(acc2, cur, w2, bnq, bn_half);
+            M6A_STAMP(2 + m);
         }
         tile_epilogue_priority();
 #ifdef M6A_AB_NO_EPILOGUE
@@ -581,12 +636,28 @@ __global__ __launch_bounds__(256, 2) void enc_site16_kernel(EncArgs a)
         const float p = (acc2[0] + acc2[5]) + w3[0];
 #else
         const float z = gemv32_as_mkl(acc2, w3, half) + a.b3;
+        M6A_STAMP(7);
         const float p = 1.0f / (1.0f + sleef_expf_u10(-z));
 #endif
         if (half == 0 && col <= (tile == n_tiles - 1 ? last_lim : 31)) (a.read_prob + (int64_t)tile * 32)[col] = p;
+        M6A_STAMP(8);
         if (tn != tile) s_base += __builtin_amdgcn_readfirstlane(__shfl(reln, 31, 64));
 #pragma unroll
         for (int i = 0; i < 8; i++) f[i] = fn[i];
+#ifdef M6A_AB_STAMPS
+        M6A_STAMP(9);
+        {
+            const int k = tile - tile0 - M6A_AB_STAMP_FIRST;
+            if (k >= 0 && k < M6A_AB_STAMP_TILES && wave < 4096 && lane == 0) {
+#pragma unroll
+                for (int i = 0; i < M6A_AB_STAMP_POINTS; i++) m6a_ab_stamp_buf[wave][k][i] = ts[i];
+                if (k == 0) {
+                    m6a_ab_stamp_hw[wave][0] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));       // HW_REG_HW_ID
+                    m6a_ab_stamp_hw[wave][1] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11));      // HW_REG_XCC_ID
+                }
+            }
+        }
+#endif
     }
     if (too_small && lane == 0) atomicExch(a.err, 2);
     m6a_clk_stamp(a.clk, 1);

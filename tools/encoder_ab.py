@@ -11,6 +11,7 @@ Variants = the product source with ONE macro each (m6a_kernels.hip, `#ifdef M6A_
   csite_pin          the 30 v_pk_fma_f32 kept where they are written (hipcc otherwise sinks them behind the epilogue; same bits)
   no_prio            the product WITHOUT its wave-priority split (s_setprio 3 through a tile's MFMA body, 0 through its epilogue; same bits)
   bn_pk              batch norm + ReLU of two hidden units per instruction: 38 v_pk_fma_f32 ... clamp instead of 76 v_fma_f32 ... clamp (same bits)
+  prio_block_valu_low / _high   inside the body: a block's four batch-norm fmas at priority 0 and its MFMAs at 3 / the fmas at 3 and the MFMAs at 1 (same bits)
   no_epilogue        knock-out, WRONG results: the 32 -> 1 layer + sigmoid removed from enc_site16_kernel (what the epilogue costs in
                      place = the most that hiding it under the next tile's MFMAs could buy)
 """
@@ -23,7 +24,8 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 KO = os.path.join(REPO, "tools", "ko")
 VARIANTS = {"base": [], "no_prio": ["-DM6A_AB_NO_PRIO"], "csite_scalar_fma": ["-DM6A_AB_CSITE_SCALAR_FMA"], "csite_pin": ["-DM6A_AB_CSITE_PIN"],
-            "no_epilogue": ["-DM6A_AB_NO_EPILOGUE"], "bn_pk": ["-DM6A_AB_BN_PK"]}
+            "no_epilogue": ["-DM6A_AB_NO_EPILOGUE"], "bn_pk": ["-DM6A_AB_BN_PK"],
+            "prio_block_valu_low": ["-DM6A_AB_PRIO_BLOCK=1"], "prio_block_valu_high": ["-DM6A_AB_PRIO_BLOCK=2"]}
 EXTRA = [a for a in sys.argv[1:] if a.startswith("+")]       # +name=-DMACRO adds a variant from the command line
 
 
