@@ -113,6 +113,12 @@ __device__ __forceinline__ void tile_epilogue_priority()
 __device__ unsigned m6a_ab_cu_slot[2048];
 __device__ __forceinline__ void phase_shift_second_workgroup()
 {
+#ifdef M6A_AB_PHASE_HWID
+    // the partner by its hardware wave slot: the two waves of a SIMD sit in slots 0 and 1 (tools/encoder_timeline.py: every pair)
+    if (__builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11)) & 1)
+        for (int i = 0; i < M6A_AB_PHASE; i++) __builtin_amdgcn_s_sleep(127);
+    return;
+#endif
     __shared__ unsigned s_slot;
     if (threadIdx.x == 0) {
         const unsigned hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)), xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11)) & 7;

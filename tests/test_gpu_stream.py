@@ -680,7 +680,9 @@ def test_bench_default_line_has_the_contract_and_one_encoder_for_product_and_hea
     # the clock the kernels ran at, from inside them
     assert 1.2 < r["clock_ghz_measured"] <= 2.45 and r["clock_detail"]["waves"] >= 16, r.get("clock_detail")
     assert abs(r["peak_at_measured_clock"] - r["peak"] * r["clock_ghz_measured"] / 2.4) < 1e-6
-    assert r["frac"] <= r["frac_at_measured_clock"] * 1.001 and r["frac_executed_at_measured_clock"] < 1.02
+    # (the stamped clock may read a little ABOVE the nominal 2.4 GHz -- 2.4036 on one round-6 box: the 100 MHz reference counter's granularity over
+    # a 2 ms kernel and the part's own tolerance -- so "at the measured clock" may be up to 2 % below the nominal-clock figure, never more)
+    assert r["frac"] <= r["frac_at_measured_clock"] * 1.021 and r["frac_executed_at_measured_clock"] < 1.02
     assert abs(r["clock_detail"]["span_ms"] - r["avg_launch_ms"]) < 0.25 * r["avg_launch_ms"], r["clock_detail"]
     fo = d["fast_encoder_optin"]
     assert fo["kernel"] == "enc_csite_kernel" and len(fo["ms_per_step_of_each_leg"]) == 3 and 2.0 < fo["ms_per_step"] < 4.0
@@ -694,7 +696,7 @@ def test_bench_default_line_has_the_contract_and_one_encoder_for_product_and_hea
     assert d["value"] > 3 * h["pinned"]["sites_per_s"]                      # PCIe-inclusive rates are never the headline
     p = d["pool_roofline"]
     assert p["bound"] == "valu" and 0.5 < p["frac"] < 1.0 and (p["measured_ceiling"] is None or p["measured_ceiling"]["frac"] < 1.05)
-    assert 1.2 < p["clock_ghz_measured"] <= 2.45 and p["frac"] <= p["frac_at_measured_clock"] * 1.001 < 1.05, p.get("clock_detail")
+    assert 1.2 < p["clock_ghz_measured"] <= 2.45 and p["frac"] <= p["frac_at_measured_clock"] * 1.021 < 1.05, p.get("clock_detail")
     g = d["ragged"]
     assert g["value"] > 1e7 and g["config"]["pool_kernel"] == "ragged-table" and 0.6 < g["roofline"]["frac"] < 1.0
     assert g["config"]["encoder_kernel_function"] == "enc_site16_kernel" and g["pool_roofline"]["clock_ghz_measured"] is not None

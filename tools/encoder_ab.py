@@ -12,6 +12,8 @@ Variants = the product source with ONE macro each (m6a_kernels.hip, `#ifdef M6A_
   no_prio            the product WITHOUT its wave-priority split (s_setprio 3 through a tile's MFMA body, 0 through its epilogue; same bits)
   bn_pk              batch norm + ReLU of two hidden units per instruction: 38 v_pk_fma_f32 ... clamp instead of 76 v_fma_f32 ... clamp (same bits)
   prio_block_valu_low / _high   inside the body: a block's four batch-norm fmas at priority 0 and its MFMAs at 3 / the fmas at 3 and the MFMAs at 1 (same bits)
+  invprio / phase / phase_invprio / phase_hwid_invprio   enc_site16_kernel only: the epilogue at priority 3 and the body at 0; the second workgroup of a CU
+                     (or the wave in hardware slot 1) starting its tile loop half a tile late; both (same bits) -- tools/encoder_timeline.py shows the phases
   no_epilogue        knock-out, WRONG results: the 32 -> 1 layer + sigmoid removed from enc_site16_kernel (what the epilogue costs in
                      place = the most that hiding it under the next tile's MFMAs could buy)
 """
@@ -25,8 +27,12 @@ sys.path.insert(0, REPO)
 KO = os.path.join(REPO, "tools", "ko")
 VARIANTS = {"base": [], "no_prio": ["-DM6A_AB_NO_PRIO"], "csite_scalar_fma": ["-DM6A_AB_CSITE_SCALAR_FMA"], "csite_pin": ["-DM6A_AB_CSITE_PIN"],
             "no_epilogue": ["-DM6A_AB_NO_EPILOGUE"], "bn_pk": ["-DM6A_AB_BN_PK"],
-            "prio_block_valu_low": ["-DM6A_AB_PRIO_BLOCK=1"], "prio_block_valu_high": ["-DM6A_AB_PRIO_BLOCK=2"]}
+            "prio_block_valu_low": ["-DM6A_AB_PRIO_BLOCK=1"], "prio_block_valu_high": ["-DM6A_AB_PRIO_BLOCK=2"],
+            "invprio": ["-DM6A_AB_PRIO_BODY=0", "-DM6A_AB_PRIO_EPI=3"], "phase": ["-DM6A_AB_PHASE=1"],
+            "phase_invprio": ["-DM6A_AB_PHASE=1", "-DM6A_AB_PRIO_BODY=0", "-DM6A_AB_PRIO_EPI=3"],
+            "phase_hwid_invprio": ["-DM6A_AB_PHASE=1", "-DM6A_AB_PHASE_HWID", "-DM6A_AB_PRIO_BODY=0", "-DM6A_AB_PRIO_EPI=3"]}
 EXTRA = [a for a in sys.argv[1:] if a.startswith("+")]       # +name=-DMACRO adds a variant from the command line
+ONLY = [a[5:].split(",") for a in sys.argv[1:] if a.startswith("only=")]          # only=base,phase: build / run just these
 
 
 def lib(name):
@@ -38,6 +44,8 @@ def build():
     os.makedirs(KO, exist_ok=True)
     jump = os.path.join(B.PKG, "assets", "mt19937_jump.bin")
     for name, flags in VARIANTS.items():
+        if ONLY and name not in ONLY[0]:
+            continue
         cmd = [os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
                '-DM6A_MT_JUMP_PATH="%s"' % jump, "-I" + B.INCLUDE, "-I" + B.CSRC] + flags + [os.path.join(B.CSRC, s) for s in B.SOURCES] + ["-o", lib(name)]
         subprocess.check_call(cmd)
@@ -81,7 +89,7 @@ def main():
         return
     nums = [a for a in sys.argv[1:] if a.isdigit()]
     legs = int(nums[0]) if nums else 4
-    names = [n for n in list(VARIANTS) + [a[1:].split("=")[0] for a in EXTRA] if os.path.exists(lib(n))]
+    names = [n for n in list(VARIANTS) + [a[1:].split("=")[0] for a in EXTRA] if os.path.exists(lib(n)) and (not ONLY or n in ONLY[0])]
     res = {n: {} for n in names}
     for leg in range(legs):
         for n in names:

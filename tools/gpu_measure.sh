@@ -44,6 +44,9 @@ bash tools/measure_cli_gpus.sh > $O/${T}_cli_gpus.json 2>> $O/${T}_cli.err
 # where the encoder's SIMD cycles go (both kernels, four counter groups) and the A/B builds of tools/encoder_ab.py (if tools/ko/ travelled)
 bash tools/encoder_floor.sh ${T} > /dev/null 2>&1
 if ls tools/ko/libm6a_ab_*.so > /dev/null 2>&1; then python tools/encoder_ab.py 3 > $O/${T}_encoder_ab.json 2> $O/${T}_encoder_ab.err; fi
+# what a VALU instruction costs next to f32 MFMAs by placement, and the tile timeline of every wave from the kernel's own clock (diagnostic builds in tools/ko/)
+./tools/mfma_valu_mix > $O/${T}_mfma_valu_mix.json 2>&1
+if ls tools/ko/libm6a_ab_stamps*.so > /dev/null 2>&1; then python tools/encoder_timeline.py > $O/${T}_encoder_timeline.json 2> $O/${T}_encoder_timeline.err; fi
 # the rows either side of the path, on this box's host: rooflines, the dataprep run DESIGN.md quotes, the whole pipeline, the CLI's CSVs
 python tools/host_rooflines.py 4.0 1400 > $O/${T}_host_rooflines.json 2> $O/${T}_host_rooflines.err
 python tools/measure_dataprep.py ${DATAPREP_GB:-22} --single > $O/${T}_dataprep.json 2> $O/${T}_dataprep.err
