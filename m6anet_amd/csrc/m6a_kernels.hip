@@ -84,16 +84,23 @@ __device__ __forceinline__ float relu2(float x)
 // The (alpha', beta') pairs sit in LDS as [unit tile][lane half][register]: 16 bytes = two hidden units per load, all 32
 // lanes of a half reading the same address (a broadcast, no conflicts) -- 38 ds_read_b128 per tile, whose latency
 // layer2_with_bn (below) hides behind blocks of MFMAs.
-// Wave priority through a tile (round 6).  Two waves share a SIMD, and between them VALU issue is arbitrated by priority, then age.
-// A tile is ~8 000 cycles of MFMAs with the batch-norm fmas woven in (the BODY: every instruction of it is on the matrix pipe's
-// critical path) followed by the 32 -> 1 layer and the sigmoid (the EPILOGUE: ~85 dependent VALU instructions, no MFMA).  With the
-// body at priority 3 and the epilogue at 0, a wave in its epilogue takes only the issue slots its partner's body leaves free, instead
-// of the two being served by age: enc_site16_kernel 2.238 -> 2.216 ms per 20 M reads over four interleaved legs (priority 1: 2.222;
-// a static priority for one of the two workgroups of a CU: nothing) -- profiles/r06_encoder_ab_priority_and_packed_bn.json.
-// Same instructions, same bits.  -DM6A_AB_NO_PRIO (tools/encoder_ab.py) builds without it.
+// Wave priority through a tile (round 6).  Two waves share a SIMD.  A tile is ~8 000 cycles of MFMAs with the batch-norm fmas woven in
+// (the BODY) followed by the 32 -> 1 layer and the sigmoid (the EPILOGUE: ~85 mostly dependent VALU instructions, no MFMA).  What the
+// kernel's own clock shows (tools/encoder_timeline.py: s_memtime stamps of every wave, pairs matched by hardware slot;
+// profiles/r06_encoder_timeline.json): a VALU instruction cannot start while a 16-pass MFMA occupies the datapath, so next to a partner
+// that streams MFMAs a dependent chain advances ONE instruction per MFMA (64 cycles).
+//   * body 3, epilogue 0 (the round's first setting, +1 % over none): the wave that finishes its body first crawls through its epilogue
+//     on the slots its partner leaves, until the partner's body ends too -- the two lock IN PHASE (partner's tile start at 0.04 of the
+//     own tile), both are outside their bodies 6.8 % of the time, and the matrix pipe has nothing to run then;
+//   * body 0, epilogue 3 (this): the epilogue wins every arbitration, so it ends as early as the partner's MFMA boundaries allow; the
+//     pair settles half a tile apart (phase 0.5-0.6), both-outside falls to 0.5 %, and the partner's MFMAs run through:
+//     enc_site16_kernel 2.229 -> 2.201 ms, enc_csite_kernel 2.070 -> 2.035, enc_kernel 2.241 -> 2.213 per 20 M reads (four interleaved
+//     legs, profiles/r06_encoder_ab_phase.json; epilogue 1 or body 1: the same within noise; starting the second wave of a SIMD half a
+//     tile late on top: +0.1-0.3 %, not taken; priorities inside the body -- the fmas above or below the MFMAs -- cost 1 %).
+// Same instructions, same bits.  -DM6A_AB_NO_PRIO / -DM6A_AB_PRIO_BODY=.. -DM6A_AB_PRIO_EPI=.. (tools/encoder_ab.py) build the others.
 #ifndef M6A_AB_PRIO_BODY
-#define M6A_AB_PRIO_BODY 3
-#define M6A_AB_PRIO_EPI 0
+#define M6A_AB_PRIO_BODY 0
+#define M6A_AB_PRIO_EPI 3
 #endif
 __device__ __forceinline__ void tile_body_priority()
 {
@@ -163,8 +170,8 @@ __device__ __forceinline__ void layer2_with_bn(f32x16 &acc2, f32x16 &cur, const 
     constexpr int n = L2_REGS(M), m_next = M < 4 ? M + 1 : 0;
 #pragma unroll
     for (int b = 0; b * BN_BLOCK < n; b++) {
-#ifdef M6A_AB_PRIO_BLOCK
-        __builtin_amdgcn_s_setprio(M6A_AB_PRIO_BLOCK == 1 ? 0 : 3);       // A/B build only: the block's fmas below / above its MFMAs
+#ifdef M6A_AB_PRIO_BLOCK_VALU
+        __builtin_amdgcn_s_setprio(M6A_AB_PRIO_BLOCK_VALU);               // A/B build only: the block's fmas at another priority than its MFMAs
 #endif
 #pragma unroll
         for (int i = 0; i < BN_BLOCK / 2; i++) {
@@ -184,8 +191,8 @@ __device__ __forceinline__ void layer2_with_bn(f32x16 &acc2, f32x16 &cur, const 
         }
         bn_pairs_load(pq, (b + 1) * BN_BLOCK < n ? bn_half + M * 64 + 2 * (b + 1) * BN_BLOCK : bn_half + m_next * 64);
         __builtin_amdgcn_sched_barrier(0);
-#ifdef M6A_AB_PRIO_BLOCK
-        __builtin_amdgcn_s_setprio(M6A_AB_PRIO_BLOCK == 1 ? 3 : 1);
+#ifdef M6A_AB_PRIO_BLOCK_VALU
+        __builtin_amdgcn_s_setprio(M6A_AB_PRIO_BLOCK_MFMA);
 #endif
 #pragma unroll
         for (int q = b * BN_BLOCK; q < (b + 1) * BN_BLOCK; q++)

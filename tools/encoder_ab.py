@@ -9,11 +9,12 @@ Variants = the product source with ONE macro each (m6a_kernels.hip, `#ifdef M6A_
   base               the product
   csite_scalar_fma   VERDICT r5 item 3(a): link3's 30 v_pk_fma_f32 as 60 plain v_fma_f32, in place between the MFMA groups (same bits)
   csite_pin          the 30 v_pk_fma_f32 kept where they are written (hipcc otherwise sinks them behind the epilogue; same bits)
-  no_prio            the product WITHOUT its wave-priority split (s_setprio 3 through a tile's MFMA body, 0 through its epilogue; same bits)
+  no_prio            the product WITHOUT its wave-priority split (s_setprio 0 through a tile's MFMA body, 3 through its epilogue; same bits)
+  prio_body3_epi0    the round's first split, the other way round (body 3, epilogue 0); p01 / p13 / p23: body / epilogue priorities 0/1, 1/3, 2/3
   bn_pk              batch norm + ReLU of two hidden units per instruction: 38 v_pk_fma_f32 ... clamp instead of 76 v_fma_f32 ... clamp (same bits)
   prio_block_valu_low / _high   inside the body: a block's four batch-norm fmas at priority 0 and its MFMAs at 3 / the fmas at 3 and the MFMAs at 1 (same bits)
-  invprio / phase / phase_invprio / phase_hwid_invprio   enc_site16_kernel only: the epilogue at priority 3 and the body at 0; the second workgroup of a CU
-                     (or the wave in hardware slot 1) starting its tile loop half a tile late; both (same bits) -- tools/encoder_timeline.py shows the phases
+  phase / phase_hwid enc_site16_kernel only: the second workgroup of a CU (or the wave in hardware slot 1) starts its tile loop half a tile late
+                     (same bits) -- tools/encoder_timeline.py shows the phases
   no_epilogue        knock-out, WRONG results: the 32 -> 1 layer + sigmoid removed from enc_site16_kernel (what the epilogue costs in
                      place = the most that hiding it under the next tile's MFMAs could buy)
 """
@@ -27,10 +28,12 @@ sys.path.insert(0, REPO)
 KO = os.path.join(REPO, "tools", "ko")
 VARIANTS = {"base": [], "no_prio": ["-DM6A_AB_NO_PRIO"], "csite_scalar_fma": ["-DM6A_AB_CSITE_SCALAR_FMA"], "csite_pin": ["-DM6A_AB_CSITE_PIN"],
             "no_epilogue": ["-DM6A_AB_NO_EPILOGUE"], "bn_pk": ["-DM6A_AB_BN_PK"],
-            "prio_block_valu_low": ["-DM6A_AB_PRIO_BLOCK=1"], "prio_block_valu_high": ["-DM6A_AB_PRIO_BLOCK=2"],
-            "invprio": ["-DM6A_AB_PRIO_BODY=0", "-DM6A_AB_PRIO_EPI=3"], "phase": ["-DM6A_AB_PHASE=1"],
-            "phase_invprio": ["-DM6A_AB_PHASE=1", "-DM6A_AB_PRIO_BODY=0", "-DM6A_AB_PRIO_EPI=3"],
-            "phase_hwid_invprio": ["-DM6A_AB_PHASE=1", "-DM6A_AB_PHASE_HWID", "-DM6A_AB_PRIO_BODY=0", "-DM6A_AB_PRIO_EPI=3"]}
+            "prio_block_valu_low": ["-DM6A_AB_PRIO_BLOCK_VALU=0", "-DM6A_AB_PRIO_BLOCK_MFMA=3"], "prio_block_valu_high": ["-DM6A_AB_PRIO_BLOCK_VALU=3", "-DM6A_AB_PRIO_BLOCK_MFMA=1"],
+            "p01": ["-DM6A_AB_PRIO_BODY=0", "-DM6A_AB_PRIO_EPI=1"], "p13": ["-DM6A_AB_PRIO_BODY=1", "-DM6A_AB_PRIO_EPI=3"], "p23": ["-DM6A_AB_PRIO_BODY=2", "-DM6A_AB_PRIO_EPI=3"],
+            "p03_bn2": ["-DM6A_AB_PRIO_BLOCK_VALU=2", "-DM6A_AB_PRIO_BLOCK_MFMA=0"],
+            "p13_bn0": ["-DM6A_AB_PRIO_BODY=1", "-DM6A_AB_PRIO_EPI=3", "-DM6A_AB_PRIO_BLOCK_VALU=0", "-DM6A_AB_PRIO_BLOCK_MFMA=1"],
+            "prio_body3_epi0": ["-DM6A_AB_PRIO_BODY=3", "-DM6A_AB_PRIO_EPI=0"], "phase": ["-DM6A_AB_PHASE=1"],
+            "phase_hwid": ["-DM6A_AB_PHASE=1", "-DM6A_AB_PHASE_HWID"]}
 EXTRA = [a for a in sys.argv[1:] if a.startswith("+")]       # +name=-DMACRO adds a variant from the command line
 ONLY = [a[5:].split(",") for a in sys.argv[1:] if a.startswith("only=")]          # only=base,phase: build / run just these
 

@@ -28,9 +28,9 @@ import sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 KO = os.path.join(REPO, "tools", "ko")
-VARIANTS = {"stamps": [], "stamps_noprio": ["-DM6A_AB_NO_PRIO"], "stamps_invprio": ["-DM6A_AB_PRIO_BODY=0", "-DM6A_AB_PRIO_EPI=3"],
+VARIANTS = {"stamps": [], "stamps_noprio": ["-DM6A_AB_NO_PRIO"], "stamps_body3_epi0": ["-DM6A_AB_PRIO_BODY=3", "-DM6A_AB_PRIO_EPI=0"],
             "stamps_phase": ["-DM6A_AB_PHASE=1"], "stamps_phase_noprio": ["-DM6A_AB_PHASE=1", "-DM6A_AB_NO_PRIO"],
-            "stamps_phase_invprio": ["-DM6A_AB_PHASE=1", "-DM6A_AB_PRIO_BODY=0", "-DM6A_AB_PRIO_EPI=3"],
+            "stamps_phase_body3_epi0": ["-DM6A_AB_PHASE=1", "-DM6A_AB_PRIO_BODY=3", "-DM6A_AB_PRIO_EPI=0"],
             "stamps_phase_eqprio": ["-DM6A_AB_PHASE=1", "-DM6A_AB_PRIO_BODY=1", "-DM6A_AB_PRIO_EPI=1"]}
 
 
