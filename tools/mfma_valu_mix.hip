@@ -120,6 +120,84 @@ static void run(int wps)
     first = false;
 }
 
+// The encoder's own block (layer2_with_bn in m6a_kernels.hip): four clamped fmas on (alpha, beta) pairs that came from LDS one block earlier, the NEXT block's two
+// ds_read_b128, four MFMAs whose B operands are the fmas' results.  LOADS = 0: the same without the LDS reads (pairs stay in registers).
+template <int LOADS>
+__global__ __launch_bounds__(256) void encblock(const float *w, float *out, unsigned long long *cyc, int groups)
+{
+    extern __shared__ float lds[];
+    const int lane = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < 2048; i += 256) lds[i] = w[i & 1023];
+    __syncthreads();
+    const float a = w[lane];
+    float h[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) h[i] = w[256 + i * 64 + lane];
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; q++) acc[q] = 0.f;
+    const float *base = lds + (lane >> 5) * 32;
+    float4 p0 = *(const float4 *)(base), p1 = *(const float4 *)(base + 4);
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    for (int g = 0; g < groups; g += 16) {
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+            asm volatile("v_fma_f32 %0, %0, %1, %2 clamp" : "+v"(h[0]) : "v"(p0.x), "v"(p0.y));
+            asm volatile("v_fma_f32 %0, %0, %1, %2 clamp" : "+v"(h[1]) : "v"(p0.z), "v"(p0.w));
+            asm volatile("v_fma_f32 %0, %0, %1, %2 clamp" : "+v"(h[2]) : "v"(p1.x), "v"(p1.y));
+            asm volatile("v_fma_f32 %0, %0, %1, %2 clamp" : "+v"(h[3]) : "v"(p1.z), "v"(p1.w));
+            if (LOADS == 1) {
+                p0 = *(const float4 *)(base + 64 * ((u + 1) & 15));
+                p1 = *(const float4 *)(base + 64 * ((u + 1) & 15) + 4);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, h[0], acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (LOADS >= 2) {                       // behind the block's FIRST MFMA: the wave waits there for the dependent second one anyway
+                p0 = *(const float4 *)(base + 64 * ((u + 1) & 15));
+                p1 = *(const float4 *)(base + 64 * ((u + 1) & 15) + 4);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, h[1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, h[2], acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (LOADS == 3) {                       // ... and the wait for them behind the third
+                __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0), vmcnt / expcnt untouched (gfx9 encoding)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, h[3], acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    float r = p0.x + p1.y;
+#pragma unroll
+    for (int q = 0; q < 16; q++) r += acc[q];
+    out[blockIdx.x * 256 + threadIdx.x] = r;
+    if (lane == 0) cyc[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
+}
+
+template <int LOADS>
+static void run_encblock(int wps)
+{
+    const int blocks = 256 * wps, groups = 4096;
+    const size_t lds = wps == 1 ? 96 * 1024 : 64 * 1024;
+    auto kern = encblock<LOADS>;
+    CHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    std::vector<unsigned long long> h(blocks * 4);
+    double med = 0;
+    for (int rep = 0; rep < 2; rep++) {
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, 0, d_w, d_out, d_cyc, groups);
+        CHK(hipDeviceSynchronize());
+        CHK(hipMemcpy(h.data(), d_cyc, h.size() * 8, hipMemcpyDeviceToHost));
+        std::sort(h.begin(), h.end());
+        med = (double)h[h.size() / 2] / groups;
+    }
+    printf(",\n{\"waves_per_simd\": %d, \"mfma_per_group\": 4, \"valu_per_group\": 4, \"placement\": \"the encoder's block: 4 clamped fmas%s, 4 MFMAs on their results\", "
+           "\"cycles_per_group_per_wave\": %.1f, \"matrix_pipe_busy\": %.4f, \"simd_cycles_per_block_beyond_its_mfmas\": %.2f}",
+           wps, LOADS == 0 ? " (pairs in registers, no LDS)" : LOADS == 1 ? " + the next block's two ds_read_b128" : LOADS == 2 ? ", first MFMA, the next block's two ds_read_b128 behind it" : ", first MFMA, the two ds_read_b128 behind it, s_waitcnt behind the third", med, wps * 256.0 / med, med / wps - 256.0);
+}
+
 template <int G, int M, int SPREAD, int NACC, int PRIO, int VOP>
 static void both() { run<G, M, SPREAD, NACC, PRIO, VOP>(1); run<G, M, SPREAD, NACC, PRIO, VOP>(2); }
 
@@ -172,6 +250,7 @@ int main()
     both<4, 4, 0, 1, 1, 0>();
     both<4, 4, 0, 1, 2, 0>();
     both<16, 64, 0, 1, 1, 0>();
+    run_encblock<0>(1); run_encblock<0>(2); run_encblock<1>(1); run_encblock<1>(2); run_encblock<2>(1); run_encblock<2>(2); run_encblock<3>(1); run_encblock<3>(2);
     printf("\n]}\n");
     return 0;
 }
