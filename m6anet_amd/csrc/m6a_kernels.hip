@@ -185,11 +185,15 @@ __device__ __forceinline__ void layer2_with_bn(f32x16 &acc2, f32x16 &cur, const 
             cur[q] = y.x;
             cur[q + 1] = y.y;
 #else
+#ifndef M6A_AB_NO_BN                    // knock-out build only (WRONG results): layer 2 straight on layer 1's accumulators -- no fmas, no pair loads
             cur[q] = bn_relu(cur[q], pq.v[i].x, pq.v[i].y);
             cur[q + 1] = bn_relu(cur[q + 1], pq.v[i].z, pq.v[i].w);
 #endif
+#endif
         }
+#ifndef M6A_AB_NO_BN
         bn_pairs_load(pq, (b + 1) * BN_BLOCK < n ? bn_half + M * 64 + 2 * (b + 1) * BN_BLOCK : bn_half + m_next * 64);
+#endif
         __builtin_amdgcn_sched_barrier(0);
 #ifdef M6A_AB_PRIO_BLOCK_VALU
         __builtin_amdgcn_s_setprio(M6A_AB_PRIO_BLOCK_MFMA);
@@ -632,9 +636,17 @@ __global__ __launch_bounds__(256, 2) void enc_site16_kernel(EncArgs a)
                     nxt = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[(m + 1) * 8 + st], f[st], nxt, 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
+#ifdef M6A_AB_NO_LINKS                   // knock-out build only (WRONG results): no input chain -- every tile computes on the first tile's features
+            if (m == 0) {
+#pragma unroll
+                for (int i = 0; i < 8; i++) fn[i] = f[i];
+                reln = 0; kidn = 0; evn = 0.0f;
+            }
+#else
             if (m == 0) link1(tn, s_base, o, reln, kidn, fn);
             if (m == 1) link2(kidn, evn);
             if (m == 3) link3(evn, reln, fn);
+#endif
             if (m == 0) layer2_with_bn<0>(acc2, cur, w2, bnq, bn_half);
             if (m == 1) layer2_with_bn<1>(acc2, cur, w2, bnq, bn_half);
             if (m == 2) layer2_with_bn<2>(acc2, cur, w2, bnq, bn_half);

@@ -8,8 +8,9 @@
 // inner loop is 1 SALU + 2 VALU per draw of 4 sites (v_pk_mul_f32 advances two sites), against 5 VALU + 4.25 LDS
 // instructions per draw of 8 sites in the LDS kernel, whose floor is the LDS pipe (0.57 ms per 1 M sites x T=1000,
 // 0.93 ms measured).  This one is bound by VALU issue: two resident waves deliver a v_pk_mul_f32 every 4.7 shader
-// ticks per SIMD (nominal 4; in-kernel stamps, profiles/r05_pool_reg_wave_timeline.txt) at the ~1.85 GHz the part
-// clocks under this load: 0.390 ms per 1 M sites x T=1000 in bench.py (rounds 1-3: 0.445, round 4: 0.413).
+// ticks per SIMD (nominal 4; in-kernel stamps, profiles/r05_pool_reg_wave_timeline.txt) at the 2.33 GHz the part
+// clocks under this load (round 6: s_memtime / s_memrealtime of 64 stamped waves, m6a_profile_clock; the "~1.85 GHz" of rounds 4-5
+// divided a wave's loop ticks by its whole life): 0.39 ms per 1 M sites x T=1000 in bench.py (rounds 1-3: 0.445, round 4: 0.413).
 //
 // The compiler cannot express "this instruction's source register is v[128 + M0]" and has no
 // register class beyond 32 dwords, so the core is one hand-written assembly block with its own

@@ -15,6 +15,8 @@ Variants = the product source with ONE macro each (m6a_kernels.hip, `#ifdef M6A_
   prio_block_valu_low / _high   inside the body: a block's four batch-norm fmas at priority 0 and its MFMAs at 3 / the fmas at 3 and the MFMAs at 1 (same bits)
   phase / phase_hwid enc_site16_kernel only: the second workgroup of a CU (or the wave in hardware slot 1) starts its tile loop half a tile late
                      (same bits) -- tools/encoder_timeline.py shows the phases
+  no_bn / no_links / no_bn_no_epilogue / no_bn_no_epilogue_no_links   knock-outs, WRONG results: layer 2 straight on layer 1's accumulators (no clamped fmas, no pair
+                     loads); enc_site16_kernel without its input chain (every tile on the first tile's features); combinations -- what each part of the non-MFMA work costs in place
   no_epilogue        knock-out, WRONG results: the 32 -> 1 layer + sigmoid removed from enc_site16_kernel (what the epilogue costs in
                      place = the most that hiding it under the next tile's MFMAs could buy)
 """
@@ -26,7 +28,9 @@ import sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 KO = os.path.join(REPO, "tools", "ko")
-VARIANTS = {"base": [], "no_prio": ["-DM6A_AB_NO_PRIO"], "csite_scalar_fma": ["-DM6A_AB_CSITE_SCALAR_FMA"], "csite_pin": ["-DM6A_AB_CSITE_PIN"],
+VARIANTS = {"base": [], "no_bn": ["-DM6A_AB_NO_BN"], "no_links": ["-DM6A_AB_NO_LINKS"], "no_bn_no_epilogue": ["-DM6A_AB_NO_BN", "-DM6A_AB_NO_EPILOGUE"],
+            "no_bn_no_epilogue_no_links": ["-DM6A_AB_NO_BN", "-DM6A_AB_NO_EPILOGUE", "-DM6A_AB_NO_LINKS"],
+            "no_prio": ["-DM6A_AB_NO_PRIO"], "csite_scalar_fma": ["-DM6A_AB_CSITE_SCALAR_FMA"], "csite_pin": ["-DM6A_AB_CSITE_PIN"],
             "no_epilogue": ["-DM6A_AB_NO_EPILOGUE"], "bn_pk": ["-DM6A_AB_BN_PK"],
             "prio_block_valu_low": ["-DM6A_AB_PRIO_BLOCK_VALU=0", "-DM6A_AB_PRIO_BLOCK_MFMA=3"], "prio_block_valu_high": ["-DM6A_AB_PRIO_BLOCK_VALU=3", "-DM6A_AB_PRIO_BLOCK_MFMA=1"],
             "p01": ["-DM6A_AB_PRIO_BODY=0", "-DM6A_AB_PRIO_EPI=1"], "p13": ["-DM6A_AB_PRIO_BODY=1", "-DM6A_AB_PRIO_EPI=3"], "p23": ["-DM6A_AB_PRIO_BODY=2", "-DM6A_AB_PRIO_EPI=3"],
