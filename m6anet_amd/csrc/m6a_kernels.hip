@@ -115,6 +115,9 @@ __device__ __forceinline__ void tile_epilogue_priority()
 #endif
 }
 #ifdef M6A_AB_PHASE
+#ifndef M6A_AB_PHASE_SLEEP
+#define M6A_AB_PHASE_SLEEP 127
+#endif
 // A/B build only: the second workgroup to arrive on a CU starts its tile loop M6A_AB_PHASE x 8 128 cycles late, so the two waves of a
 // SIMD run half a tile apart (atomicInc wraps 0 -> 1 -> 0: the counter is back at 0 when both have arrived).
 __device__ unsigned m6a_ab_cu_slot[2048];
@@ -123,7 +126,7 @@ __device__ __forceinline__ void phase_shift_second_workgroup()
 #ifdef M6A_AB_PHASE_HWID
     // the partner by its hardware wave slot: the two waves of a SIMD sit in slots 0 and 1 (tools/encoder_timeline.py: every pair)
     if (__builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11)) & 1)
-        for (int i = 0; i < M6A_AB_PHASE; i++) __builtin_amdgcn_s_sleep(127);
+        for (int i = 0; i < M6A_AB_PHASE; i++) __builtin_amdgcn_s_sleep(M6A_AB_PHASE_SLEEP);
     return;
 #endif
     __shared__ unsigned s_slot;
@@ -133,7 +136,7 @@ __device__ __forceinline__ void phase_shift_second_workgroup()
     }
     __syncthreads();
     if (s_slot)
-        for (int i = 0; i < M6A_AB_PHASE; i++) __builtin_amdgcn_s_sleep(127);
+        for (int i = 0; i < M6A_AB_PHASE; i++) __builtin_amdgcn_s_sleep(M6A_AB_PHASE_SLEEP);
 }
 #else
 __device__ __forceinline__ void phase_shift_second_workgroup() {}

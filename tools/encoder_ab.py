@@ -37,7 +37,10 @@ VARIANTS = {"base": [], "no_bn": ["-DM6A_AB_NO_BN"], "no_links": ["-DM6A_AB_NO_L
             "p03_bn2": ["-DM6A_AB_PRIO_BLOCK_VALU=2", "-DM6A_AB_PRIO_BLOCK_MFMA=0"],
             "p13_bn0": ["-DM6A_AB_PRIO_BODY=1", "-DM6A_AB_PRIO_EPI=3", "-DM6A_AB_PRIO_BLOCK_VALU=0", "-DM6A_AB_PRIO_BLOCK_MFMA=1"],
             "prio_body3_epi0": ["-DM6A_AB_PRIO_BODY=3", "-DM6A_AB_PRIO_EPI=0"], "phase": ["-DM6A_AB_PHASE=1"],
-            "phase_hwid": ["-DM6A_AB_PHASE=1", "-DM6A_AB_PHASE_HWID"]}
+            "phase_hwid": ["-DM6A_AB_PHASE=1", "-DM6A_AB_PHASE_HWID"],
+            "no_epilogue_phase": ["-DM6A_AB_NO_EPILOGUE", "-DM6A_AB_PHASE=1", "-DM6A_AB_PHASE_HWID"],
+            "no_epilogue_phase_quarter": ["-DM6A_AB_NO_EPILOGUE", "-DM6A_AB_PHASE=1", "-DM6A_AB_PHASE_HWID", "-DM6A_AB_PHASE_SLEEP=64"],
+            "no_epilogue_phase_eighth": ["-DM6A_AB_NO_EPILOGUE", "-DM6A_AB_PHASE=1", "-DM6A_AB_PHASE_HWID", "-DM6A_AB_PHASE_SLEEP=32"]}
 EXTRA = [a for a in sys.argv[1:] if a.startswith("+")]       # +name=-DMACRO adds a variant from the command line
 ONLY = [a[5:].split(",") for a in sys.argv[1:] if a.startswith("only=")]          # only=base,phase: build / run just these
 
