@@ -568,12 +568,27 @@ __global__ __launch_bounds__(256, 2) void enc_site16_kernel(EncArgs a)
         too_small |= lim >= d2 ? 1 : 0;
         const int room = last_site - base;                                        // sites after the base site
         const int ksr = kq_site < room ? kq_site : room;
+#ifdef M6A_AB_ADDR64
         kid = (int)(a.site_kmers + (int64_t)base * 3)[ksr * 3 + kq_byte];
+#else
+        kid = (int)(a.site_kmers + (int64_t)base * 3)[__umul24((unsigned)ksr, 3u) + (unsigned)kq_byte];      // scalar base + unsigned 32-bit lane offset (see the x loads)
+#endif
         // K slot 2i + half holds feature 2i + half, as in enc_kernel
+#ifdef M6A_AB_ADDR64
         const float *xp = a.X + rbase * 9 + (crel * 9 + half);
 #pragma unroll
         for (int i = 0; i < 4; i++) x[i] = xp[2 * i];
         x[4] = xp[half ? 6 : 8];
+#else
+        // the tile's base is wave-uniform and the lane's part fits 32 unsigned bits: global_load ... v_off, s[base] offset:imm -- no 64-bit
+        // address arithmetic on the VALU (a signed lane offset made hipcc form every address with v_mad_u64_u32 / v_lshl_add_u64, quarter-
+        // and half-rate instructions on the datapath the MFMAs use)
+        const float *xt = a.X + rbase * 9;
+        const float *xp = (const float *)((const char *)xt + (unsigned)(4 * (crel * 9 + half)));       // a BYTE offset of 32 bits: what the instruction takes
+#pragma unroll
+        for (int i = 0; i < 4; i++) x[i] = xp[2 * i];
+        x[4] = *(const float *)((const char *)xt + (unsigned)(4 * (crel * 9 + (half ? 7 : 8))));
+#endif
     };
     auto link2 = [&](int kid, float &ev) { ev = s_emb[2 * kid + (lane & 1)]; };
     // lanes 0..17 hold float q % 6 of site a + q / 6; a lane of half h wants floats (1 - h), (1 - h) + 2, (1 - h) + 4 of
@@ -801,15 +816,27 @@ __global__ __launch_bounds__(256, 2) void enc_csite_kernel(EncArgs a)
         too_small |= lim >= d2 ? 1 : 0;
         const int room = last_site - base;                                        // sites after the base site
         const int ksr = kq_site < room ? kq_site : room;
+#ifdef M6A_AB_ADDR64
         kid = (int)(a.site_kmers + (int64_t)base * 3)[ksr * 3 + kq_byte];
+#else
+        kid = (int)(a.site_kmers + (int64_t)base * 3)[__umul24((unsigned)ksr, 3u) + (unsigned)kq_byte];      // scalar base + unsigned 32-bit lane offset (see the x loads)
+#endif
         // K slot 2st+half holds feature 2st+half: the features enter the sum in the order the reference's dot product
         // has them.  (One 16-byte load per lane -- half 0 x0..x3, half 1 x4..x7, weights permuted to match -- is the
         // same speed and moves the summation order away from the reference's: the worst use of the rtol 1e-5 bar over
         // 10 M reads rose from 0.81 to 0.89 on the arabidopsis weights, 0.936 to 0.951 on HEK293T.)
+#ifdef M6A_AB_ADDR64
         const float *xp = a.X + rbase * 9 + (crel * 9 + half);
 #pragma unroll
         for (int i = 0; i < 4; i++) x[i] = xp[2 * i];
         x[4] = xp[half ? 6 : 8];                             // x8 on half 0 (half 1: a valid dummy)
+#else
+        const float *xt = a.X + rbase * 9;                   // scalar base + unsigned 32-bit lane offset, as in enc_site16_kernel
+        const float *xp = (const float *)((const char *)xt + (unsigned)(4 * (crel * 9 + half)));
+#pragma unroll
+        for (int i = 0; i < 4; i++) x[i] = xp[2 * i];
+        x[4] = *(const float *)((const char *)xt + (unsigned)(4 * (crel * 9 + (half ? 7 : 8))));      // x8 on half 0 (half 1: a valid dummy)
+#endif
     };
     // link2: the embedding float itself
     auto link2 = [&](int kid, float &ev) { ev = s_emb[2 * kid + (lane & 1)]; };

@@ -9,6 +9,7 @@ Variants = the product source with ONE macro each (m6a_kernels.hip, `#ifdef M6A_
   base               the product
   csite_scalar_fma   VERDICT r5 item 3(a): link3's 30 v_pk_fma_f32 as 60 plain v_fma_f32, in place between the MFMA groups (same bits)
   csite_pin          the 30 v_pk_fma_f32 kept where they are written (hipcc otherwise sinks them behind the epilogue; same bits)
+  addr64             link1's loads addressed the old way (signed lane offset: 64-bit VALU address arithmetic) instead of scalar base + unsigned 32-bit lane offset
   no_prio            the product WITHOUT its wave-priority split (s_setprio 0 through a tile's MFMA body, 3 through its epilogue; same bits)
   prio_body3_epi0    the round's first split, the other way round (body 3, epilogue 0); p01 / p13 / p23: body / epilogue priorities 0/1, 1/3, 2/3
   bn_pk              batch norm + ReLU of two hidden units per instruction: 38 v_pk_fma_f32 ... clamp instead of 76 v_fma_f32 ... clamp (same bits)
@@ -28,7 +29,7 @@ import sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 KO = os.path.join(REPO, "tools", "ko")
-VARIANTS = {"base": [], "no_bn": ["-DM6A_AB_NO_BN"], "no_links": ["-DM6A_AB_NO_LINKS"], "no_bn_no_epilogue": ["-DM6A_AB_NO_BN", "-DM6A_AB_NO_EPILOGUE"],
+VARIANTS = {"base": [], "addr64": ["-DM6A_AB_ADDR64"], "no_bn": ["-DM6A_AB_NO_BN"], "no_links": ["-DM6A_AB_NO_LINKS"], "no_bn_no_epilogue": ["-DM6A_AB_NO_BN", "-DM6A_AB_NO_EPILOGUE"],
             "no_bn_no_epilogue_no_links": ["-DM6A_AB_NO_BN", "-DM6A_AB_NO_EPILOGUE", "-DM6A_AB_NO_LINKS"],
             "no_prio": ["-DM6A_AB_NO_PRIO"], "csite_scalar_fma": ["-DM6A_AB_CSITE_SCALAR_FMA"], "csite_pin": ["-DM6A_AB_CSITE_PIN"],
             "no_epilogue": ["-DM6A_AB_NO_EPILOGUE"], "bn_pk": ["-DM6A_AB_BN_PK"],
