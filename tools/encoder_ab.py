@@ -29,7 +29,7 @@ import sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 KO = os.path.join(REPO, "tools", "ko")
-VARIANTS = {"base": [], "addr64": ["-DM6A_AB_ADDR64"], "no_bn": ["-DM6A_AB_NO_BN"], "no_links": ["-DM6A_AB_NO_LINKS"], "no_bn_no_epilogue": ["-DM6A_AB_NO_BN", "-DM6A_AB_NO_EPILOGUE"],
+VARIANTS = {"base": [], "prev": [], "addr64": ["-DM6A_AB_ADDR64"], "no_bn": ["-DM6A_AB_NO_BN"], "no_links": ["-DM6A_AB_NO_LINKS"], "no_bn_no_epilogue": ["-DM6A_AB_NO_BN", "-DM6A_AB_NO_EPILOGUE"],
             "no_bn_no_epilogue_no_links": ["-DM6A_AB_NO_BN", "-DM6A_AB_NO_EPILOGUE", "-DM6A_AB_NO_LINKS"],
             "no_prio": ["-DM6A_AB_NO_PRIO"], "csite_scalar_fma": ["-DM6A_AB_CSITE_SCALAR_FMA"], "csite_pin": ["-DM6A_AB_CSITE_PIN"],
             "no_epilogue": ["-DM6A_AB_NO_EPILOGUE"], "bn_pk": ["-DM6A_AB_BN_PK"],
