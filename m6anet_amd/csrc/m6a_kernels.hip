@@ -160,7 +160,9 @@ __device__ __forceinline__ float bn_relu(float y, float alpha, float beta)
 // the 38 loads' latency exposed: 2.135-2.15 ms for the 12-slot kernel against 2.07-2.09 this way, which is what the kernel
 // took with the batch norm folded into the weights; blocks of 8 need 16 registers the 12-slot kernel does not have (spills:
 // 2.25), blocks of 2 measure 2.10.  profiles/r04_encoder_order_timing.txt.)
+#ifndef BN_BLOCK
 #define BN_BLOCK 4
+#endif
 struct BnPairs { float4 v[BN_BLOCK / 2]; };
 __device__ __forceinline__ void bn_pairs_load(BnPairs &pq, const float *p)
 {
@@ -646,6 +648,7 @@ __global__ __launch_bounds__(256, 2) void enc_site16_kernel(EncArgs a)
         for (int m = 0; m < 5; m++) {
             f32x16 &cur = (m & 1) ? h1b : h1a;
             f32x16 &nxt = (m & 1) ? h1a : h1b;
+#ifndef M6A_AB_L2_FIRST
             if (m < 4) {
 #pragma unroll
                 for (int q = 0; q < 16; q++) nxt[q] = 0.0f;
@@ -654,6 +657,15 @@ __global__ __launch_bounds__(256, 2) void enc_site16_kernel(EncArgs a)
                     nxt = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[(m + 1) * 8 + st], f[st], nxt, 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
+#endif
+            // where the three links of the next tile's input chain sit: behind the layer-1 MFMAs of unit tiles 2, 3 and 4 (round 6; rounds 2-6a: 1, 2 and 4 --
+            // m = 0, 1, 3 here).  Measured over two runs of interleaved legs (profiles/r06_encoder_ab_schedule.json, r06_encoder_ab_links.json): -0.5 %;
+            // 0/1/4, 2/3/4, 1/3/4: +-0.2 %; 0/2/3, 0/2/4, 0/3/4: +0.4 .. +1.3 %.  -DM6A_AB_LINK1_AT=.. builds the others.
+#ifndef M6A_AB_LINK1_AT
+#define M6A_AB_LINK1_AT 1
+#define M6A_AB_LINK2_AT 2
+#define M6A_AB_LINK3_AT 3
+#endif
 #ifdef M6A_AB_NO_LINKS                   // knock-out build only (WRONG results): no input chain -- every tile computes on the first tile's features
             if (m == 0) {
 #pragma unroll
@@ -661,15 +673,25 @@ __global__ __launch_bounds__(256, 2) void enc_site16_kernel(EncArgs a)
                 reln = 0; kidn = 0; evn = 0.0f;
             }
 #else
-            if (m == 0) link1(tn, s_base, o, reln, kidn, fn);
-            if (m == 1) link2(kidn, evn);
-            if (m == 3) link3(evn, reln, fn);
+            if (m == M6A_AB_LINK1_AT) link1(tn, s_base, o, reln, kidn, fn);
+            if (m == M6A_AB_LINK2_AT) link2(kidn, evn);
+            if (m == M6A_AB_LINK3_AT) link3(evn, reln, fn);
 #endif
             if (m == 0) layer2_with_bn<0>(acc2, cur, w2, bnq, bn_half);
             if (m == 1) layer2_with_bn<1>(acc2, cur, w2, bnq, bn_half);
             if (m == 2) layer2_with_bn<2>(acc2, cur, w2, bnq, bn_half);
             if (m == 3) layer2_with_bn<3>(acc2, cur, w2, bnq, bn_half);
             if (m == 4) layer2_with_bn<4>(acc2, cur, w2, bnq, bn_half);
+#ifdef M6A_AB_L2_FIRST
+            if (m < 4) {
+#pragma unroll
+                for (int q = 0; q < 16; q++) nxt[q] = 0.0f;
+#pragma unroll
+                for (int st = 0; st < 8; st++)
+                    nxt = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[(m + 1) * 8 + st], f[st], nxt, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#endif
             M6A_STAMP(2 + m);
         }
         tile_epilogue_priority();
