@@ -286,11 +286,12 @@ int m6a_profile_clock(m6a_ctx *ctx, int kind, double *ghz_median, double *ghz_mi
  *   chain would do (A/B and tests);
  *   2 = the 12-slot kernel, strictly (every bag must have >= 16 reads: a call that violates this reports M6A_EINVAL at the
  *   next sync);   4 = "fast": the 12-slot kernel where every bag has >= 16 reads, the 16-slot kernels elsewhere.
- * The 12-slot kernel (enc_csite_kernel) is OPT-IN: it issues 106 MFMAs per 32-read tile instead of 116 (2.07 vs 2.21 ms per
- * 20 M reads, 5-6 % per step) by adding a site's six embedding terms and b1 pre-summed and summing the 32 -> 1 layer in
+ * The 12-slot kernel (enc_csite_kernel) is OPT-IN: it issues 106 MFMAs per 32-read tile instead of 116 (2.03 vs 2.16 ms per
+ * 20 M reads, 4-5 % per step) by adding a site's six embedding terms and b1 pre-summed and summing the 32 -> 1 layer in
  * register order -- two departures from the reference's order.  Its read probabilities are within the reference test's
  * rtol 1e-5 / atol 1e-8 (m6anet/tests/test_inference.py:32) on every fixture and on 218 M reads of the full-size configs; a
- * random fuzz found 4 reads of 20 G at up to 1.005 x that bar (all far inside north_star's absolute 1e-5).
+ * random fuzz finds a few reads in 10^10 beyond that bar -- 4 of 20 G at up to 1.005 x in round 5, none of 20 G and 4 of 14 G at up to
+ * 1.08 x in round 6 -- all far inside north_star's absolute 1e-5.
  * The environment variable M6A_ENCODER=auto|reference|general16|csite12|walk16|fast preselects 0 / 0 / 1 / 2 / 3 / 4 in every
  * context the process creates; any other value makes m6a_create fail with M6A_EINVAL. */
 int m6a_set_encoder_variant(m6a_ctx *ctx, int mode);

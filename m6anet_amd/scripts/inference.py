@@ -46,8 +46,8 @@ def argparser():
                              "host configuration it was validated against (torch + MKL on AVX-512) read probabilities are bit-identical "
                              "to `m6anet inference` wherever MKL groups a batch's rows in fours (every read of 20-read bags, > 99.9 %% "
                              "of ragged ones); activations beyond 2^64 saturate and a -inf pre-activation becomes NaN (DESIGN.md).  "
-                             "fast: opt-in, for jobs whose bags all have >= 16 reads a 12-slot kernel 5-6 %% faster per step and within "
-                             "rtol 1e-5 of the reference on every fixture (a random fuzz: 4 reads of 20 G at up to 1.005 x that bar).  "
+                             "fast: opt-in, for jobs whose bags all have >= 16 reads a 12-slot kernel 4-5 %% faster per step and within "
+                             "rtol 1e-5 of the reference on every fixture (random fuzz: a few reads in 10^10 beyond that bar, worst 1.08 x).  "
                              "The encoder is under 1 %% of this command's wall time either way.  Without this flag the environment "
                              "variable M6A_ENCODER (auto|reference|general16|csite12|walk16|fast), if set, decides; an unknown value is an error.")
     parser.add_argument("--drop_unflushed_tail", action="store_true",

@@ -9,7 +9,8 @@ What the bar can and cannot say at this sample size.  Two float32 evaluations of
 orders differ by rounding noise that is a sizeable share of rtol 1e-5 (small probabilities: one ulp of a logit near -18
 is 1e-6 relative): on the reference's own captures the worst read uses 0.3-0.6 of it, over 10 M random reads 0.30 / 0.81 /
 0.94 / 0.60 (12-slot kernel) and 0.31 / 0.90 / 0.97 / 0.56 (16-slot kernel) for the four checkpoints, and the tail keeps
-growing with the sample: about one read in 10^7 crosses 1.0 on the HEK293T weights (1.03 seen).  The exact float64 result
+growing with the sample: about one read in 10^7 crosses 1.0 on the HEK293T weights (1.03 seen; since the kernels follow the reference's order
+(below) a few in 10^10, 1.08 seen in round 6: profiles/r06_encoder_fuzz_final.json).  The exact float64 result
 itself sits at 0.9-1.0 of the bar against the float32 oracle (HISTORY.md section 8).  So this fuzz fails on a GROSS error --
 any read beyond 1.5x the bar (5x for randomly perturbed weights, where the same noise is larger still) -- and reports how
 many reads went beyond 1.0 and the worst one; the committed tests hold the fixtures and seeded samples to the bar itself.
