@@ -684,7 +684,13 @@ int launch_encode(m6a_ctx *c, const float *X, const uint8_t *km, const int64_t *
     a.wfrag2 = c->d_wfrag2; a.w1e_tab = c->d_w1e; a.bn = c->d_w1e + M6A_W1E_FLOATS; a.err = c->d_err;
     a.n_sites = S; a.n_reads = R; a.n_tiles = (R + 31) / 32; a.b3 = c->b3;
     a.clk = c->prof.clk_for(0);
+#ifdef M6A_AB_W3
+    // A/B build only: enc_site16_kernel at three waves per SIMD (the grid is sized before the kernel is chosen: every encoder gets 12 waves per CU's worth of
+    // work items in this build, the two-wave kernels simply run their blocks in two rounds -- only enc_site16_kernel's time means anything here)
+    const int64_t max_waves = (int64_t)c->n_cu * 12;
+#else
     const int64_t max_waves = (int64_t)c->n_cu * 8;        // 2 blocks/CU x 4 waves
+#endif
     a.tiles_per_wave = (a.n_tiles + max_waves - 1) / max_waves;
     const int64_t waves = (a.n_tiles + a.tiles_per_wave - 1) / a.tiles_per_wave;
     const unsigned blocks = (unsigned)((waves + 3) / 4);

@@ -210,6 +210,43 @@ __device__ __forceinline__ void layer2_with_bn(f32x16 &acc2, f32x16 &cur, const 
     }
 }
 
+#ifdef M6A_AB_W3
+// A/B build only (tools/encoder_ab.py, -DM6A_AB_W3): THREE waves per SIMD.  Layer 2's 80 A-operand registers per lane are what stands between the kernel
+// and 168 registers, so they live in LDS as [block of four hidden units][lane] float4 and come in one block ahead of their MFMAs, behind the block's first
+// MFMA, into two alternating float4 buffers (19 blocks per tile: the last block refills buffer 0 for the next tile after its own MFMAs).
+template <int M>
+__device__ __forceinline__ void layer2_with_bn_lds(f32x16 &acc2, f32x16 &cur, float4 (&wq)[2], const float4 *w2lane, BnPairs &pq, const float *bn_half)
+{
+    static_assert(BN_BLOCK == 4, "one float4 of A operands per block");
+    constexpr int n = L2_REGS(M), m_next = M < 4 ? M + 1 : 0;
+#pragma unroll
+    for (int b = 0; b * 4 < n; b++) {
+        const int g = M * 4 + b;
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int q = b * 4 + 2 * i;
+            cur[q] = bn_relu(cur[q], pq.v[i].x, pq.v[i].y);
+            cur[q + 1] = bn_relu(cur[q + 1], pq.v[i].z, pq.v[i].w);
+        }
+        bn_pairs_load(pq, (b + 1) * 4 < n ? bn_half + M * 64 + 2 * (b + 1) * 4 : bn_half + m_next * 64);
+        __builtin_amdgcn_sched_barrier(0);
+        const float4 w = wq[g & 1];
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, cur[b * 4], acc2, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (g < 18) wq[(g + 1) & 1] = w2lane[(g + 1) * 64];
+        __builtin_amdgcn_sched_barrier(0);
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, cur[b * 4 + 1], acc2, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, cur[b * 4 + 2], acc2, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, cur[b * 4 + 3], acc2, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (g == 18) wq[0] = w2lane[0];
+    }
+}
+#define M6A_SITE16_WAVES_PER_SIMD 3
+#else
+#define M6A_SITE16_WAVES_PER_SIMD 2
+#endif
+
 // exp as torch's vectorised sigmoid computes it -- Sleef's expf with the 1.0-ulp bound (sleefsimdsp.c `xexpf`; restated from the
 // published algorithm): Cody-Waite reduction by ln 2 in two parts, a degree-6 polynomial in fma form,
 // 2^q applied as two factors.  Only the 16-slot kernel uses it (its read probabilities are the reference's bits, below).
@@ -504,7 +541,7 @@ extern "C" int m6a_ab_read_stamps(unsigned long long *stamps, unsigned *hw)
 #else
 #define M6A_STAMP(k) do { } while (0)
 #endif
-__global__ __launch_bounds__(256, 2) void enc_site16_kernel(EncArgs a)
+__global__ __launch_bounds__(256, M6A_SITE16_WAVES_PER_SIMD) void enc_site16_kernel(EncArgs a)
 {
     clamp_keeps_nan();
     m6a_clk_stamp(a.clk, 0);
@@ -515,6 +552,13 @@ __global__ __launch_bounds__(256, 2) void enc_site16_kernel(EncArgs a)
     for (int i = threadIdx.x; i < M6A_BN_FLOATS; i += 256) s_bn[i] = a.bn[(i & ~3) | ((i & 1) << 1) | ((i & 2) >> 1)];   // (a, b, a', b') -> (a, a', b, b')
 #else
     for (int i = threadIdx.x; i < M6A_BN_FLOATS; i += 256) s_bn[i] = a.bn[i];
+#endif
+#ifdef M6A_AB_W3
+    __shared__ float4 s_w2q[19 * 64];
+    for (int idx = threadIdx.x; idx < 19 * 64; idx += 256) {
+        const int g = idx >> 6, ln = idx & 63, u = (g >> 2) * 16 + (g & 3) * 4;
+        s_w2q[idx] = make_float4(a.wfrag[(40 + u) * 64 + ln], a.wfrag[(41 + u) * 64 + ln], a.wfrag[(42 + u) * 64 + ln], a.wfrag[(43 + u) * 64 + ln]);
+    }
 #endif
     __syncthreads();
 
@@ -530,11 +574,20 @@ __global__ __launch_bounds__(256, 2) void enc_site16_kernel(EncArgs a)
     const int n_sites = (int)a.n_sites;
     const int last_lim = (int)(a.n_reads - 1 - (int64_t)(n_tiles - 1) * 32);   // last valid column of the last tile
 
+#ifdef M6A_AB_W3
+    float w1[40], w3[16];
+    float4 wq[2];
+    const float4 *w2lane = s_w2q + lane;
+    wq[0] = w2lane[0];
+#pragma unroll
+    for (int i = 0; i < 40; i++) w1[i] = a.wfrag[i * 64 + lane];
+#else
     float w1[40], w2[80], w3[16];
 #pragma unroll
     for (int i = 0; i < 40; i++) w1[i] = a.wfrag[i * 64 + lane];
 #pragma unroll
     for (int i = 0; i < 80; i++) w2[i] = a.wfrag[(40 + i) * 64 + lane];
+#endif
 #pragma unroll
     for (int i = 0; i < 16; i++) w3[i] = a.wfrag[(120 + i) * 64 + lane];
 
@@ -677,11 +730,19 @@ __global__ __launch_bounds__(256, 2) void enc_site16_kernel(EncArgs a)
             if (m == M6A_AB_LINK2_AT) link2(kidn, evn);
             if (m == M6A_AB_LINK3_AT) link3(evn, reln, fn);
 #endif
+#ifdef M6A_AB_W3
+            if (m == 0) layer2_with_bn_lds<0>(acc2, cur, wq, w2lane, bnq, bn_half);
+            if (m == 1) layer2_with_bn_lds<1>(acc2, cur, wq, w2lane, bnq, bn_half);
+            if (m == 2) layer2_with_bn_lds<2>(acc2, cur, wq, w2lane, bnq, bn_half);
+            if (m == 3) layer2_with_bn_lds<3>(acc2, cur, wq, w2lane, bnq, bn_half);
+            if (m == 4) layer2_with_bn_lds<4>(acc2, cur, wq, w2lane, bnq, bn_half);
+#else
             if (m == 0) layer2_with_bn<0>(acc2, cur, w2, bnq, bn_half);
             if (m == 1) layer2_with_bn<1>(acc2, cur, w2, bnq, bn_half);
             if (m == 2) layer2_with_bn<2>(acc2, cur, w2, bnq, bn_half);
             if (m == 3) layer2_with_bn<3>(acc2, cur, w2, bnq, bn_half);
             if (m == 4) layer2_with_bn<4>(acc2, cur, w2, bnq, bn_half);
+#endif
 #ifdef M6A_AB_L2_FIRST
             if (m < 4) {
 #pragma unroll

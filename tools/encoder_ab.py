@@ -12,6 +12,7 @@ Variants = the product source with ONE macro each (m6a_kernels.hip, `#ifdef M6A_
   addr64             link1's loads addressed the old way (signed lane offset: 64-bit VALU address arithmetic) instead of scalar base + unsigned 32-bit lane offset
   links_abc          enc_site16_kernel: links 1 / 2 / 3 of the input chain at m = a / b / c of the unit-tile loop instead of 1 / 2 / 3 (rounds 2-6a: 0 / 1 / 3); bn_block2 / 8: batch norm woven in blocks of 2 / 8 hidden
                      units; l2_first: batch norm + layer 2 of a unit tile in front of the next unit tile's layer 1 (same bits)
+  w3                 enc_site16_kernel at THREE waves per SIMD: layer 2's A operands from LDS (one float4 per block of four hidden units, a block ahead) instead of 80 registers (same bits)
   no_prio            the product WITHOUT its wave-priority split (s_setprio 0 through a tile's MFMA body, 3 through its epilogue; same bits)
   prio_body3_epi0    the round's first split, the other way round (body 3, epilogue 0); p01 / p13 / p23: body / epilogue priorities 0/1, 1/3, 2/3
   bn_pk              batch norm + ReLU of two hidden units per instruction: 38 v_pk_fma_f32 ... clamp instead of 76 v_fma_f32 ... clamp (same bits)
@@ -35,7 +36,7 @@ def _links(a, b, c):
     return ["-DM6A_AB_LINK1_AT=%d" % a, "-DM6A_AB_LINK2_AT=%d" % b, "-DM6A_AB_LINK3_AT=%d" % c]
 
 
-VARIANTS = {"base": [], "links_013": _links(0, 1, 3), "links_012": _links(0, 1, 2), "links_024": _links(0, 2, 4), "links_124": _links(1, 2, 4), "links_014": _links(0, 1, 4),
+VARIANTS = {"base": [], "w3": ["-DM6A_AB_W3"], "links_013": _links(0, 1, 3), "links_012": _links(0, 1, 2), "links_024": _links(0, 2, 4), "links_124": _links(1, 2, 4), "links_014": _links(0, 1, 4),
             "links_234": _links(2, 3, 4), "links_134": _links(1, 3, 4), "links_034": _links(0, 3, 4), "links_023": _links(0, 2, 3), "bn_block2": ["-DBN_BLOCK=2"], "bn_block8": ["-DBN_BLOCK=8"], "l2_first": ["-DM6A_AB_L2_FIRST"], "prev": [], "addr64": ["-DM6A_AB_ADDR64"], "no_bn": ["-DM6A_AB_NO_BN"], "no_links": ["-DM6A_AB_NO_LINKS"], "no_bn_no_epilogue": ["-DM6A_AB_NO_BN", "-DM6A_AB_NO_EPILOGUE"],
             "no_bn_no_epilogue_no_links": ["-DM6A_AB_NO_BN", "-DM6A_AB_NO_EPILOGUE", "-DM6A_AB_NO_LINKS"],
             "no_prio": ["-DM6A_AB_NO_PRIO"], "csite_scalar_fma": ["-DM6A_AB_CSITE_SCALAR_FMA"], "csite_pin": ["-DM6A_AB_CSITE_PIN"],
