@@ -80,6 +80,9 @@ VARIANTS = {
     "noload": no_loop_loads,
     "pkonly": lambda s: no_loop_loads(VARIANTS["nom0"](s)),
     # the shift moved between the two multiplies of the PREVIOUS draw (same instruction count, SALU never back to back)
+    # CORRECT variants (round 6): wave priority -- the wave in hardware slot 1 of its SIMD at priority 3 (its partner at 0), or every wave at 3
+    "prio_slot1": lambda s: s.replace("    m6a_clk_stamp(a.clk, 0);", "    m6a_clk_stamp(a.clk, 0);\n    if (__builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11)) & 1) __builtin_amdgcn_s_setprio(3);", 1),
+    "prio_all3": lambda s: s.replace("    m6a_clk_stamp(a.clk, 0);", "    m6a_clk_stamp(a.clk, 0);\n    __builtin_amdgcn_s_setprio(3);", 1),
     "vpre640": vprefetch(640),
     "vpre1600": vprefetch(1600),
     "vpre3200": vprefetch(3200),
